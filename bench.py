@@ -1,0 +1,192 @@
+#!/usr/bin/env python
+"""Headline benchmark (BASELINE.json): Msamples/sec (in+out) at 48 kHz stereo presetDefault.
+
+One "step" = one process() pass of the hot path over the whole resident batch (BASELINE configs[1]: 256 stereo
+streams, 48 kHz, presetDefault, 1.5x stretch, fp32, 10 s of input per stream), inputs and outputs resident in HBM.
+N GPUs: one process per GPU, the batch of streams is sharded (256 streams per GPU, weak scaling), no collective on
+the data path; torch.distributed (RCCL) is used only for the barrier and the max-over-ranks clock.
+
+Prints ONE JSON line (rank 0) with `roofline` (dominant kernel, HIP-event timed on the engine's own stream) and
+`cpu_baseline` (the CPU reference timed on this box's host cores; N=1 only)."""
+import argparse
+import importlib
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+SR = 48000
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def algorithmic_bytes_per_channel_hop(B, I, M, r):
+    """SURVEY.md section 8(d) state-streaming model: new input + output + Band.output/Prediction.energy read+write
+    (+ prevInput carried when not re-analysed) + overlap-add partial sums read+write."""
+    return 4*(I/r) + 4*I + 2*12*M + (2*8*M if r == 1 else 0) + 2*4*(B - I)
+
+
+def make_inputs(torch, S, C, n, device, first_stream=0):
+    """Synthetic streams of SURVEY.md 8(d): type = s mod 3 (sine pair / chirp / uniform noise), generated on the GPU."""
+    t = torch.arange(n, device=device, dtype=torch.float64)/SR
+    x = torch.empty((S, C, n), dtype=torch.float32, device=device)
+    gen = torch.Generator(device=device)
+    for s in range(S):
+        sg = first_stream + s
+        for c in range(C):
+            if sg % 3 == 0:
+                f1 = 110*2**((sg % 37)/12)
+                v = 0.4*torch.sin(2*torch.pi*f1*t + 0.5*c) + 0.2*torch.sin(2*torch.pi*3.17*f1*t)
+            elif sg % 3 == 1:
+                k = (0.4*SR - 50)/(n/SR)
+                v = 0.5*torch.sin(2*torch.pi*(50*t + 0.5*k*t*t) + 0.5*c)
+            else:
+                gen.manual_seed(1_000_003*sg + c)
+                v = torch.rand(n, generator=gen, device=device, dtype=torch.float32)*0.6 - 0.3
+            x[s, c] = v.to(torch.float32)
+    return x
+
+
+def cpu_baseline(seconds_budget=15.0):
+    """The CPU reference (oracle/_ref) on this box's host cores: one process per core, bounded sample."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import ref_oracle
+    if not ref_oracle.available():
+        return None
+    cores = os.cpu_count() or 1
+    script = os.path.join(ROOT, "oracle", "cpu_baseline.py")
+    probe = json.loads(subprocess.run([sys.executable, script, "1", "2", "1.5", "0"], capture_output=True, text=True, check=True).stdout.strip().splitlines()[-1])
+    per_stream_10s = probe["process_s"]*5.0
+    streams_per_core = max(1, min(64, int(seconds_budget/max(per_stream_10s, 1e-3))))
+    t0 = time.perf_counter()
+    procs = [subprocess.Popen([sys.executable, script, str(streams_per_core), "10", "1.5", str(i*streams_per_core)],
+                              stdout=subprocess.PIPE, text=True) for i in range(cores)]
+    outs = [json.loads(p.communicate()[0].strip().splitlines()[-1]) for p in procs]
+    wall = time.perf_counter() - t0
+    samples = sum(o["samples"] for o in outs)
+    busy = max(o["process_s"] for o in outs)
+    return dict(value=samples/busy/1e6, unit="Msamples/s", cores=cores, kind="reference",
+                sample="%d processes x %d stereo 48 kHz streams x 10 s at 1.5x (presetDefault), timed around process(); "
+                       "unmodified reference header, g++ -O3, L1 (signalsmith-linear) restated in oracle/linear_shim; "
+                       "wall incl. input synthesis %.1f s" % (cores, streams_per_core, wall),
+                realtime_x=(samples/(1 + 1.5)/2/SR)/busy)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--streams", type=int, default=256, help="streams per GPU (BASELINE configs[1]: 256)")
+    ap.add_argument("--seconds", type=float, default=10.0, help="seconds of input per stream per step")
+    ap.add_argument("--stretch", type=float, default=1.5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus))
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    pkg = importlib.import_module("signalsmith-stretch_amd")
+    S, C = args.streams, 2
+    n_in = int(args.seconds*SR)
+    n_out = int(round(n_in*args.stretch))
+    batch = pkg.StretchBatch(S, C, preset="default", sample_rate=SR, device=local_rank, seed=rank)
+    x = make_inputs(torch, S, C, n_in, device, first_stream=rank*S)
+    y = torch.empty((S, C, n_out), dtype=torch.float32, device=device)
+    torch.cuda.synchronize()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        batch.process(x, n_out, out=y)
+    batch.synchronize()
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        batch.process(x, n_out, out=y)
+    batch.synchronize()
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    ok = bool(torch.isfinite(y).all().item()) and float(y.abs().max().item()) > 0.01
+
+    samples_per_step = world*S*C*(n_in + n_out)
+    value = samples_per_step*args.steps/elapsed/1e6
+    B, I, M = batch.blockSamples(), batch.intervalSamples(), batch.bands()
+    hops_per_stream = -(-n_out//I)
+    bytes_per_chop = algorithmic_bytes_per_channel_hop(B, I, M, args.stretch)
+
+    roofline = None
+    if rank == 0:
+        # per-kernel-class device time: HIP events recorded on the engine's own stream around every launch
+        batch.enableProfiling(True)
+        batch.process(x, n_out, out=y)
+        batch.synchronize()
+        ms, launches = batch.takeTimings()
+        batch.enableProfiling(False)
+        launch_count = {"analyse": launches["analyse"], "predict": launches["predict"], "chain": launches["chain"],
+                        "synth": launches["synth"], "emit": launches["emit"]}
+        dom = max(launch_count, key=lambda k: ms[k])
+        avg_ms = ms[dom]/max(launch_count[dom], 1)
+        chops_per_launch = S*C*hops_per_stream/max(launch_count[dom], 1)
+        achieved = bytes_per_chop*chops_per_launch/(avg_ms*1e-3)/1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get(dom)
+            except Exception:
+                traffic = None
+        roofline = dict(bound="hbm", kernel={"analyse": "kAnalyse", "predict": "kPredict", "chain": "kChain", "synth": "kSynth", "emit": "kEmit"}[dom],
+                        achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved/HBM_PEAK_GBS, traffic=traffic,
+                        avg_launch_ms=avg_ms, launches_per_step=launch_count[dom],
+                        algorithmic_bytes_per_channel_hop=bytes_per_chop, channel_hops_per_launch=chops_per_launch,
+                        kernel_ms_per_step={k: round(v, 3) for k, v in ms.items()},
+                        pipeline_frac=(bytes_per_chop*S*C*hops_per_stream/(elapsed/args.steps))/1e9/HBM_PEAK_GBS)
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        try:
+            cpu = cpu_baseline()
+        except Exception as e:  # the baseline is reported, never required
+            cpu = dict(error=str(e))
+    if rank == 0:
+        line = {
+            "metric": "Msamples/sec (in+out) at 48kHz stereo presetDefault",
+            "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed/args.steps*1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: %d stereo streams per GPU, 48 kHz, presetDefault, %.2fx stretch, fp32, "
+                                   "%.0f s input per stream per step, device-resident I/O" % (S, args.stretch, args.seconds),
+                       "streams_total": world*S, "channels": C, "block": B, "interval": I, "fft": batch.fftSamples(),
+                       "hops_per_stream_per_step": hops_per_stream, "sharding": "streams/%d, no collective" % world},
+            "realtime_x": world*S*args.seconds*args.steps/elapsed,
+            "output_finite_nonzero": ok,
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,151 @@
+/* smst.h -- C ABI of the MI355X (gfx950) implementation of the Signalsmith Stretch spectral hot path.
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no C++/torch types.  Library: libsmst_hip.so.
+ *
+ * Two groups of entry points:
+ *
+ *  (1) single-stream handle API -- one-to-one with the flat ABI the reference itself ships for its WASM
+ *      build (reference: web/emscripten/main.cpp:15-77, 17 functions over a global singleton; here the
+ *      singleton becomes a handle) plus the three members that ABI lacks (outputSeek/exact: reference
+ *      signalsmith-stretch.h:173-207,468-491; setFreqMap in table form: :120-122).  Sample buffers are HOST
+ *      pointers, planar (`buffers[channel][index]`, reference README.md:46).
+ *
+ *  (2) batch API -- S independent streams that share one configuration, processed together on one GPU.
+ *      This is the data-parallel axis the reference does not have (one SignalsmithStretch instance per
+ *      stream, signalsmith-stretch.h:34-35); each stream behaves exactly like one reference instance.
+ *      Buffers are planar with explicit strides: sample (s, c, i) at base[s*streamStride + c*channelStride + i].
+ *      `memory` selects SMST_MEM_HOST (staged through the library's own device buffers) or SMST_MEM_DEVICE
+ *      (pointers are device pointers on the batch's GPU; the call is asynchronous on the batch's stream
+ *      except for one 4-byte-per-stream readback inside process -- use smst_batch_synchronize()).
+ *
+ * Every function returns 0 on success and a negative code on failure (the reference has no error channel:
+ * signalsmith-stretch.h is UB when unconfigured; only exact() reports, :471-480).  smst_last_error()
+ * returns the message of the last failure on the calling thread.
+ */
+#ifndef SMST_H
+#define SMST_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SMST_OK 0
+#define SMST_ERR_INVALID (-1)  /* bad argument / unconfigured handle */
+#define SMST_ERR_DEVICE (-2)   /* HIP runtime error (no GPU, out of memory, launch failure) */
+#define SMST_ERR_SHORT (-3)    /* exact(): input shorter than outputSeekLength (signalsmith-stretch.h:471-480) */
+
+#define SMST_MEM_HOST 0
+#define SMST_MEM_DEVICE 1
+
+const char *smst_last_error(void);
+/* version of the reference API this library mirrors: {1,3,2} (signalsmith-stretch.h:36) */
+void smst_reference_version(int out[3]);
+int smst_device_count(void);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * (1) single-stream handle API
+ * ------------------------------------------------------------------------------------------------------- */
+typedef struct smst_stretch smst_stretch;
+
+/* SignalsmithStretch() / SignalsmithStretch(long seed): signalsmith-stretch.h:38-39.  device = HIP ordinal. */
+int smst_create(smst_stretch **out, long seed, int device);
+void smst_destroy(smst_stretch *h);
+
+/* presetDefault / presetCheaper / configure: signalsmith-stretch.h:63-94; web/emscripten/main.cpp:43-51.
+ * split: 0/1, or -1 for the preset's own default (false for default, true for cheaper). */
+int smst_preset_default(smst_stretch *h, int channels, float sampleRate, int split);
+int smst_preset_cheaper(smst_stretch *h, int channels, float sampleRate, int split);
+int smst_configure(smst_stretch *h, int channels, int blockSamples, int intervalSamples, int split);
+
+/* queries: signalsmith-stretch.h:42-47,96-104,166-168,205-207; main.cpp:28-39 */
+int smst_block_samples(const smst_stretch *h);
+int smst_interval_samples(const smst_stretch *h);
+int smst_input_latency(const smst_stretch *h);
+int smst_output_latency(const smst_stretch *h);
+int smst_split_computation(const smst_stretch *h);
+int smst_seek_length(const smst_stretch *h);
+int smst_output_seek_length(const smst_stretch *h, float playbackRate);
+
+/* reset: signalsmith-stretch.h:49-60; main.cpp:40-42 */
+int smst_reset(smst_stretch *h);
+
+/* parameters: signalsmith-stretch.h:107-135; main.cpp:52-66.  Frequencies are relative to the sample rate. */
+int smst_set_transpose_factor(smst_stretch *h, float multiplier, float tonalityLimit);
+int smst_set_transpose_semitones(smst_stretch *h, float semitones, float tonalityLimit);
+int smst_set_formant_factor(smst_stretch *h, float multiplier, int compensatePitch);
+int smst_set_formant_semitones(smst_stretch *h, float semitones, int compensatePitch);
+int smst_set_formant_base(smst_stretch *h, float baseFreq);
+/* setFreqMap (signalsmith-stretch.h:120-122) in table form: table[i] = map((i + 0.5)/(2n)), linear in between
+ * and beyond; n = 0 removes the map. */
+int smst_set_freq_map_table(smst_stretch *h, const float *table, int n);
+
+/* seek / process / flush: signalsmith-stretch.h:140-165, 210-423, 427-464; main.cpp:68-76 */
+int smst_seek(smst_stretch *h, const float *const *inputs, int inputSamples, double playbackRate);
+int smst_process(smst_stretch *h, const float *const *inputs, int inputSamples, float *const *outputs, int outputSamples);
+int smst_flush(smst_stretch *h, float *const *outputs, int outputSamples, float playbackRate);
+/* outputSeek / exact: signalsmith-stretch.h:173-204, 468-491 */
+int smst_output_seek(smst_stretch *h, const float *const *inputs, int inputLength);
+int smst_exact(smst_stretch *h, const float *const *inputs, int inputSamples, float *const *outputs, int outputSamples);
+
+/* ---------------------------------------------------------------------------------------------------------
+ * (2) batch API
+ * ------------------------------------------------------------------------------------------------------- */
+typedef struct smst_batch smst_batch;
+
+int smst_batch_create(smst_batch **out, int streams, int channels, int blockSamples, int intervalSamples,
+                      int split, int device, long seed);
+/* preset: 0 = presetDefault (block = 0.12 sr, interval = 0.03 sr), 1 = presetCheaper (0.1 sr, 0.04 sr) */
+int smst_batch_create_preset(smst_batch **out, int streams, int channels, int preset, float sampleRate,
+                             int split, int device, long seed);
+void smst_batch_destroy(smst_batch *b);
+
+int smst_batch_streams(const smst_batch *b);
+int smst_batch_channels(const smst_batch *b);
+int smst_batch_block_samples(const smst_batch *b);
+int smst_batch_interval_samples(const smst_batch *b);
+int smst_batch_fft_samples(const smst_batch *b);
+int smst_batch_bands(const smst_batch *b);
+int smst_batch_input_latency(const smst_batch *b);
+int smst_batch_output_latency(const smst_batch *b);
+int smst_batch_seek_length(const smst_batch *b);
+int smst_batch_output_seek_length(const smst_batch *b, float playbackRate);
+long long smst_batch_workspace_bytes(const smst_batch *b);
+
+int smst_batch_reset(smst_batch *b);
+/* stream = -1 applies to every stream */
+int smst_batch_set_transpose_factor(smst_batch *b, int stream, float multiplier, float tonalityLimit);
+int smst_batch_set_transpose_semitones(smst_batch *b, int stream, float semitones, float tonalityLimit);
+int smst_batch_set_formant_factor(smst_batch *b, int stream, float multiplier, int compensatePitch);
+int smst_batch_set_formant_semitones(smst_batch *b, int stream, float semitones, int compensatePitch);
+int smst_batch_set_formant_base(smst_batch *b, int stream, float baseFreq);
+int smst_batch_set_freq_map_table(smst_batch *b, int stream, const float *table, int n);
+
+/* inSamples / outSamples / rates / lengths: HOST arrays with one entry per stream. */
+int smst_batch_seek(smst_batch *b, const float *in, long long inStreamStride, long long inChannelStride,
+                    const int *inSamples, const double *playbackRates, int memory);
+int smst_batch_process(smst_batch *b, const float *in, long long inStreamStride, long long inChannelStride,
+                       const int *inSamples, float *out, long long outStreamStride, long long outChannelStride,
+                       const int *outSamples, int memory);
+int smst_batch_flush(smst_batch *b, float *out, long long outStreamStride, long long outChannelStride,
+                     const int *outSamples, const float *playbackRates, int memory);
+int smst_batch_output_seek(smst_batch *b, const float *in, long long inStreamStride, long long inChannelStride,
+                           const int *inputLengths, int memory);
+int smst_batch_synchronize(smst_batch *b);
+/* raw hipStream_t the batch enqueues on (so callers can order their own device work against it) */
+void *smst_batch_hip_stream(smst_batch *b);
+
+/* measurement hooks: per-kernel-class device time (hipEvent pairs on the batch's stream) accumulated since the
+ * last call.  ms[0..6] = analyse, feed, predict, chain, synth, emit, other; launches[0..4] = analyse, predict,
+ * chain, synth, emit. */
+int smst_batch_enable_profiling(smst_batch *b, int on);
+int smst_batch_take_timings(smst_batch *b, double ms[7], long long launches[5]);
+
+/* test hooks (tests/ only): per-stream state rows.  which: 0 Band.input, 1 Band.prevInput, 2 Band.output
+ * (interleaved re,im: 2*channels*bands floats), 3 Prediction.energy (channels*bands floats). */
+int smst_batch_debug_get_state(smst_batch *b, int stream, int which, float *dst);
+int smst_batch_debug_get_carry(smst_batch *b, int stream, float *sums, float *products);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SMST_H */

@@ -1,0 +1,70 @@
+// Device-side view of a batch (plain pointers, passed to kernels by value) and the kernel launchers.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "smst_types.h"
+
+namespace smst {
+
+struct DevBatch {
+	// geometry (signalsmith-stretch.h:71-94; fftSamples/bands from the L1 contract)
+	int S, C, B, I, M, N, L, T;
+	int histLen, carryLen, delta; // B+I, B+I, split ? I : 0
+	int lag, ringSlots;           // wavefront skew (>= L+1) and LDS ring depth (power of two > lag)
+	int hopStride, emitStride;    // row pitch of the per-call hop / emit tables
+	int mapTableLen;
+	int histCur, carryCur;        // which half of the double buffers is current
+	FftPlan plan;
+	// constant tables
+	const float2 *twH;     // e^{-2 pi i j / H}
+	const float2 *halfTw;  // e^{-i pi m / N}
+	const float2 *rot;     // per-bin hop rotation (signalsmith-stretch.h:647-655)
+	const float *window;   // analysis == synthesis window (Kaiser, perfect reconstruction)
+	const float *wprod;    // window[i]^2 * N
+	// per-stream state
+	float2 *stInput, *stPrev, *stOut; // Band.input / .prevInput / .output   [S][C][M]
+	float *stEnergy;                  // Prediction.energy                   [S][C][M]
+	float *hist[2];                   // last B+I input samples              [S][C][B+I]
+	float *carrySum[2];               // overlap-add partial sums            [S][C][B+I]
+	float *carryWp[2];                // window products                     [S][B+I]
+	float *stFreq;                    // freqEstimateWeighted / Weight       [S][2]
+	const StreamParams *params;       // [S]
+	const float *mapTable;            // [S][mapTableLen] custom frequency maps (table form of setFreqMap)
+	// per-call tables
+	const HopDesc *hops;   // [S][hopStride]
+	const EmitDesc *emit;  // [S][emitStride]
+	// per-tile workspace, [subS][T][C][M] unless noted
+	float2 *Xcur, *Xprev, *P, *Sx, *Tx, *Sdn, *Tdn, *TW, *OUT;
+	float *E;
+	float2 *map;    // [subS][T][M]
+	float *ratio;   // [subS][T][M]
+	float *esum;    // [subS][T][M]
+	float *est;     // [subS][T][2]
+	float *frames;  // [subS][T][C][B]
+	const int *nHops;      // [subS] hops of this tile
+	const int *lastNewHop; // [subS] tile-local index of the last hop with a new spectrum, or -1
+};
+
+struct IoArgs {
+	const float *in;
+	float *out;
+	long long inStreamStride, inChannelStride, outStreamStride, outChannelStride;
+	const int *inSamples;  // [S] device
+	const int *outSamples; // [S] device
+};
+
+void launchEnergy(const DevBatch &d, const IoArgs &io, int sBase, int nStreams, float *energyOut, hipStream_t st);
+void launchAnalyse(const DevBatch &d, const IoArgs &io, int sBase, int nStreams, int hopBase, int tileHops, hipStream_t st);
+void launchFeedMap(const DevBatch &d, int sBase, int nStreams, int hopBase, int tileHops, hipStream_t st);
+void launchFeedFormant(const DevBatch &d, int sBase, int nStreams, int hopBase, int tileHops, hipStream_t st);
+void launchPredict(const DevBatch &d, int sBase, int nStreams, int hopBase, int tileHops, hipStream_t st);
+void launchChain(const DevBatch &d, int sBase, int nStreams, int hopBase, hipStream_t st);
+void launchSynth(const DevBatch &d, int sBase, int nStreams, int hopBase, int tileHops, hipStream_t st);
+void launchEmit(const DevBatch &d, const IoArgs &io, int sBase, int nStreams, int tileIndex, int maxSpan, hipStream_t st);
+void launchCarryState(const DevBatch &d, int sBase, int nStreams, int hopBase, hipStream_t st);
+void launchHistory(const DevBatch &d, const IoArgs &io, hipStream_t st);
+void launchPassThrough(const DevBatch &d, const IoArgs &io, const int *passFlags, int maxOut, hipStream_t st);
+void launchSeekHistory(const DevBatch &d, const IoArgs &io, const int *seekFlags, hipStream_t st);
+void launchAddPreRoll(const DevBatch &d, const float *preRoll, int length, const int *offsets, hipStream_t st);
+void launchFlushTail(const DevBatch &d, const IoArgs &io, const int *tailOffset, const int *outOffset, hipStream_t st);
+
+} // namespace smst

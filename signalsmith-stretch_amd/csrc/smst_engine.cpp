@@ -1,0 +1,716 @@
+// Host-side engine implementation.  See smst_engine.h.
+#include "smst_engine.h"
+
+#include <algorithm>
+#include <cmath>
+#include <complex>
+#include <cstdlib>
+#include <cstring>
+
+namespace smst {
+
+#define SMST_HIP(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) throw Error(std::string(#expr) + ": " + hipGetErrorString(e_)); } while (0)
+
+static constexpr float kNoiseFloor = 1e-15f;     // signalsmith-stretch.h:508
+static constexpr float kMaxCleanStretch = 2.0f;  // :509
+
+// fftSamples chosen by the L1 layer: 2*fastSizeAbove(ceil(block/2)) with fast sizes {4,5,6,8}*2^k
+// (probe-verified for 5760/5292/4800/9600/11520).
+static int fastSizeAbove(int size) {
+	int power2 = 1;
+	while (power2*8 < size) power2 *= 2;
+	int multiple = (size + power2 - 1)/power2;
+	if (multiple == 7) ++multiple;
+	return multiple*power2;
+}
+
+static FftPlan makePlan(int H, int N) {
+	FftPlan plan{};
+	plan.H = H;
+	plan.N = N;
+	int rem = H, odd = 1;
+	while (rem%3 == 0) { rem /= 3; odd *= 3; }
+	while (rem%5 == 0) { rem /= 5; odd *= 5; }
+	int log2 = 0;
+	while (rem%2 == 0) { rem /= 2; ++log2; }
+	if (rem != 1 || (odd != 1 && odd != 3 && odd != 5)) throw Error("unsupported FFT size (need 2^k * {1,3,5})");
+	int n = 0;
+	for (int i = 0; i < log2/2; ++i) plan.radix[n++] = 4;
+	if (log2%2) plan.radix[n++] = 2;
+	if (odd > 1) plan.radix[n++] = odd;
+	if (n > kMaxFftPasses) throw Error("FFT too long");
+	plan.npass = n;
+	return plan;
+}
+
+// Kaiser window, heuristic-optimal bandwidth, forced to perfect reconstruction
+static std::vector<float> makeWindow(int B, int I) {
+	auto bessel0 = [](double x) {
+		double result = 0, term = 1, m = 0;
+		while (term > 1e-4) {
+			result += term;
+			++m;
+			term *= (x*x)/(4*m*m);
+		}
+		return result;
+	};
+	std::vector<float> w(B);
+	double bandwidth = double(B)/double(I);
+	double bw = bandwidth + 8/((bandwidth + 3)*(bandwidth + 3)) + 0.25*std::max(3 - bandwidth, 0.0);
+	bw = std::max(bw, 2.0);
+	double beta = M_PI*std::sqrt(bw*bw*0.25 - 1);
+	double invB0 = 1/bessel0(beta);
+	for (int i = 0; i < B; ++i) {
+		double r = (2*double(i) + 1)/double(B) - 1;
+		double arg = std::sqrt(std::max(0.0, 1 - r*r));
+		w[i] = float(bessel0(beta*arg)*invB0);
+	}
+	for (int j = 0; j < I && j < B; ++j) {
+		float sum2 = 0;
+		for (int i = j; i < B; i += I) sum2 += w[i]*w[i];
+		float gain = 1/std::sqrt(sum2);
+		for (int i = j; i < B; i += I) w[i] *= gain;
+	}
+	return w;
+}
+
+template <typename T> T *Batch::devAlloc(size_t count) {
+	void *p = nullptr;
+	if (count == 0) count = 1;
+	SMST_HIP(hipMalloc(&p, count*sizeof(T)));
+	allocations.push_back(p);
+	return static_cast<T *>(p);
+}
+void Batch::devFree(void *p) {
+	if (!p) return;
+	auto it = std::find(allocations.begin(), allocations.end(), p);
+	if (it != allocations.end()) allocations.erase(it);
+	hipFree(p);
+}
+
+Batch::Batch(int streams, int channels, int block, int interval, bool splitComputation, int device, long seed)
+	: S(streams), C(channels), B(block), I(interval), split(splitComputation), dev(device) {
+	if (S < 1 || C < 1 || C > kMaxChannels || B < 4 || I < 1 || I > B) throw Error("invalid configuration (need 1..8 channels, interval <= block)");
+	SMST_HIP(hipSetDevice(dev));
+	SMST_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+	N = 2*fastSizeAbove((B + 1)/2);
+	M = N/2;
+	if ((size_t)M*sizeof(float2)*2 > 150*1024) throw Error("block too long for the LDS-resident FFT (bands*16 bytes must fit 150 KiB)");
+	L = int(std::round(float(N)/float(I))); // longVerticalStep, signalsmith-stretch.h:636-637
+	if (L < 1) L = 1;
+
+	d.S = S; d.C = C; d.B = B; d.I = I; d.M = M; d.N = N; d.L = L; d.T = kTileHops;
+	d.histLen = B + I;
+	d.carryLen = B + I;
+	d.delta = split ? I : 0;
+	d.lag = L + 1;
+	int ring = 4;
+	while (ring < d.lag + 1) ring *= 2;
+	d.ringSlots = ring;
+	if (ring > 64) throw Error("interval too small relative to the FFT size (vertical step too long)");
+	d.plan = makePlan(M, N);
+	d.mapTableLen = 0;
+
+	// constant tables
+	std::vector<float2> tw(M), half(M), rot(M);
+	for (int j = 0; j < M; ++j) {
+		double a = -2*M_PI*double(j)/double(M);
+		tw[j] = make_float2(float(std::cos(a)), float(std::sin(a)));
+		double h = -M_PI*double(j)/double(N);
+		half[j] = make_float2(float(std::cos(h)), float(std::sin(h)));
+	}
+	{ // hop rotation, evaluated with the reference's own fp32 recurrence (signalsmith-stretch.h:647-655)
+		const float f0 = (0.0f + 0.5f)/float(N), f1 = (1.0f + 0.5f)/float(N);
+		std::complex<float> r = std::polar(1.0f, f0*float(I)*float(2*M_PI));
+		const float freqStep = f1 - f0;
+		const std::complex<float> step = std::polar(1.0f, freqStep*float(I)*float(2*M_PI));
+		for (int b = 0; b < M; ++b) {
+			rot[b] = make_float2(r.real(), r.imag());
+			r = std::complex<float>(r.real()*step.real() - r.imag()*step.imag(), r.real()*step.imag() + r.imag()*step.real());
+		}
+	}
+	std::vector<float> win = makeWindow(B, I), wprod(B);
+	for (int i = 0; i < B; ++i) wprod[i] = win[i]*win[i]*float(N);
+	// reset(0.1) window-product seed: three phantom blocks at weight 0.1, read position one interval in
+	{
+		std::vector<float> wp(B, 0.0f);
+		for (int i = 0; i < B; ++i) wp[i] += wprod[i];
+		for (int i = B - I - 1; i >= 0; --i) wp[i] += wp[i + I];
+		for (auto &v : wp) v = v*0.1f + 1e-30f;
+		seedCarryWp.assign(d.carryLen, 1e-30f);
+		for (int r = 0; r + I < B; ++r) seedCarryWp[r] = wp[r + I];
+	}
+
+	auto upload = [&](const void *src, size_t bytes) {
+		void *p = devAlloc<unsigned char>(bytes);
+		SMST_HIP(hipMemcpy(p, src, bytes, hipMemcpyHostToDevice));
+		return p;
+	};
+	d.twH = static_cast<float2 *>(upload(tw.data(), M*sizeof(float2)));
+	d.halfTw = static_cast<float2 *>(upload(half.data(), M*sizeof(float2)));
+	d.rot = static_cast<float2 *>(upload(rot.data(), M*sizeof(float2)));
+	d.window = static_cast<float *>(upload(win.data(), B*sizeof(float)));
+	d.wprod = static_cast<float *>(upload(wprod.data(), B*sizeof(float)));
+
+	const size_t bandRows = (size_t)S*C*M;
+	d.stInput = devAlloc<float2>(bandRows);
+	d.stPrev = devAlloc<float2>(bandRows);
+	d.stOut = devAlloc<float2>(bandRows);
+	d.stEnergy = devAlloc<float>(bandRows);
+	SMST_HIP(hipMemset(d.stEnergy, 0, bandRows*sizeof(float)));
+	for (int h = 0; h < 2; ++h) {
+		d.hist[h] = devAlloc<float>((size_t)S*C*d.histLen);
+		d.carrySum[h] = devAlloc<float>((size_t)S*C*d.carryLen);
+		d.carryWp[h] = devAlloc<float>((size_t)S*d.carryLen);
+	}
+	d.stFreq = devAlloc<float>((size_t)S*2);
+	dParams = devAlloc<StreamParams>(S);
+	d.params = dParams;
+	dEnergy = devAlloc<float>(S);
+	dInSamples = devAlloc<int>(S);
+	dOutSamples = devAlloc<int>(S);
+	dFlags = devAlloc<int>(S);
+	dAux0 = devAlloc<int>(S);
+	dAux1 = devAlloc<int>(S);
+
+	sched.assign(S, StreamSched());
+	for (int s = 0; s < S; ++s) sched[s].seed = unsigned(seed)*2654435761u + unsigned(s)*40503u + 12345u;
+	StreamParams p{};
+	p.freqMultiplier = 1; p.freqTonalityLimit = 0.5f; // :513
+	p.formantMultiplier = 1; p.invFormantMultiplier = 1; p.formantBaseFreq = 0; p.formantCompensation = 0; p.hasCustomMap = 0;
+	params.assign(S, p);
+	paramsDirty = true;
+
+	allocateWorkspace();
+	reset();
+}
+
+Batch::~Batch() {
+	hipSetDevice(dev);
+	if (st) hipStreamSynchronize(st);
+	for (void *p : allocations) hipFree(p);
+	if (st) hipStreamDestroy(st);
+}
+
+void Batch::allocateWorkspace() {
+	// Per (stream, hop, channel): 7 complex rows + 1 float row of M bins + one B-sample frame.
+	// Sub-batch the streams so the tile workspace stays under a budget (default 48 GiB of the 288 GB HBM).
+	double budgetGiB = 48;
+	if (const char *env = std::getenv("SMST_WORKSPACE_GIB")) budgetGiB = std::max(0.25, atof(env));
+	const size_t perStream = (size_t)d.T*((size_t)C*((size_t)M*(9*sizeof(float2) + sizeof(float)) + (size_t)B*sizeof(float))
+	                                      + (size_t)M*(sizeof(float2) + 2*sizeof(float)) + 2*sizeof(float));
+	size_t maxStreams = size_t(budgetGiB*1024.0*1024.0*1024.0/double(perStream));
+	if (maxStreams < 1) maxStreams = 1;
+	subS = int(std::min<size_t>(S, maxStreams));
+	const size_t rows = (size_t)subS*d.T*C*M;
+	d.Xcur = devAlloc<float2>(rows);
+	d.Xprev = devAlloc<float2>(rows);
+	d.P = devAlloc<float2>(rows);
+	d.Sx = devAlloc<float2>(rows);
+	d.Tx = devAlloc<float2>(rows);
+	d.Sdn = devAlloc<float2>(rows);
+	d.Tdn = devAlloc<float2>(rows);
+	d.TW = devAlloc<float2>(rows);
+	d.OUT = devAlloc<float2>(rows);
+	d.E = devAlloc<float>(rows);
+	d.map = devAlloc<float2>((size_t)subS*d.T*M);
+	d.ratio = devAlloc<float>((size_t)subS*d.T*M);
+	d.esum = devAlloc<float>((size_t)subS*d.T*M);
+	d.est = devAlloc<float>((size_t)subS*d.T*2);
+	d.frames = devAlloc<float>((size_t)subS*d.T*C*B);
+	wsBytes = perStream*subS;
+}
+
+void Batch::uploadParams() {
+	if (!paramsDirty) return;
+	SMST_HIP(hipMemcpyAsync(dParams, params.data(), S*sizeof(StreamParams), hipMemcpyHostToDevice, st));
+	SMST_HIP(hipStreamSynchronize(st));
+	paramsDirty = false;
+}
+
+void Batch::writeSeedCarry(const unsigned char *active) {
+	for (int h = 0; h < 2; ++h) {
+		for (int s = 0; s < S; ++s) {
+			if (active && !active[s]) continue;
+			SMST_HIP(hipMemsetAsync(d.carrySum[h] + (size_t)s*C*d.carryLen, 0, (size_t)C*d.carryLen*sizeof(float), st));
+			SMST_HIP(hipMemcpyAsync(d.carryWp[h] + (size_t)s*d.carryLen, seedCarryWp.data(), d.carryLen*sizeof(float), hipMemcpyHostToDevice, st));
+			SMST_HIP(hipMemsetAsync(d.hist[h] + (size_t)s*C*d.histLen, 0, (size_t)C*d.histLen*sizeof(float), st));
+		}
+	}
+	SMST_HIP(hipStreamSynchronize(st)); // seedCarryWp is pageable host memory
+}
+
+void Batch::zeroBandState(int s, bool input, bool prev, bool output) {
+	const size_t off = (size_t)s*C*M, bytes = (size_t)C*M*sizeof(float2);
+	if (input) SMST_HIP(hipMemsetAsync(d.stInput + off, 0, bytes, st));
+	if (prev) SMST_HIP(hipMemsetAsync(d.stPrev + off, 0, bytes, st));
+	if (output) SMST_HIP(hipMemsetAsync(d.stOut + off, 0, bytes, st));
+}
+
+void Batch::reset() { // signalsmith-stretch.h:49-60
+	SMST_HIP(hipSetDevice(dev));
+	const size_t bandRows = (size_t)S*C*M;
+	SMST_HIP(hipMemsetAsync(d.stInput, 0, bandRows*sizeof(float2), st));
+	SMST_HIP(hipMemsetAsync(d.stPrev, 0, bandRows*sizeof(float2), st));
+	SMST_HIP(hipMemsetAsync(d.stOut, 0, bandRows*sizeof(float2), st));
+	SMST_HIP(hipMemsetAsync(d.stFreq, 0, (size_t)S*2*sizeof(float), st));
+	if (S <= 64) {
+		writeSeedCarry(nullptr);
+	} else { // bulk path: build the whole seed image once
+		std::vector<float> wpAll((size_t)S*d.carryLen);
+		for (int s = 0; s < S; ++s) std::copy(seedCarryWp.begin(), seedCarryWp.end(), wpAll.begin() + (size_t)s*d.carryLen);
+		for (int h = 0; h < 2; ++h) {
+			SMST_HIP(hipMemsetAsync(d.carrySum[h], 0, (size_t)S*C*d.carryLen*sizeof(float), st));
+			SMST_HIP(hipMemsetAsync(d.hist[h], 0, (size_t)S*C*d.histLen*sizeof(float), st));
+			SMST_HIP(hipMemcpyAsync(d.carryWp[h], wpAll.data(), wpAll.size()*sizeof(float), hipMemcpyHostToDevice, st));
+		}
+		SMST_HIP(hipStreamSynchronize(st));
+	}
+	d.histCur = 0;
+	d.carryCur = 0;
+	for (auto &sc : sched) {
+		unsigned seed = sc.seed, counter = sc.rngCounter;
+		sc = StreamSched();
+		sc.seed = seed;
+		sc.rngCounter = counter;
+	}
+}
+
+// ---- parameters ------------------------------------------------------------------------------------------
+template <typename F> static void forStreams(int S, int stream, F &&f) {
+	if (stream < 0) { for (int s = 0; s < S; ++s) f(s); }
+	else if (stream < S) f(stream);
+	else throw Error("stream index out of range");
+}
+void Batch::setTransposeFactor(int stream, float multiplier, float tonalityLimit) { // :107-115
+	forStreams(S, stream, [&](int s) {
+		params[s].freqMultiplier = multiplier;
+		params[s].freqTonalityLimit = (tonalityLimit > 0) ? tonalityLimit/std::sqrt(multiplier) : 1.0f;
+		params[s].hasCustomMap = 0;
+	});
+	paramsDirty = true;
+}
+void Batch::setTransposeSemitones(int stream, float semitones, float tonalityLimit) { // :116-118
+	setTransposeFactor(stream, float(std::pow(2, semitones/12)), tonalityLimit);
+}
+void Batch::setFormantFactor(int stream, float multiplier, bool compensatePitch) { // :124-128
+	forStreams(S, stream, [&](int s) {
+		params[s].formantMultiplier = multiplier;
+		params[s].invFormantMultiplier = 1/multiplier;
+		params[s].formantCompensation = compensatePitch ? 1 : 0;
+	});
+	paramsDirty = true;
+}
+void Batch::setFormantSemitones(int stream, float semitones, bool compensatePitch) { // :129-131
+	setFormantFactor(stream, float(std::pow(2, semitones/12)), compensatePitch);
+}
+void Batch::setFormantBase(int stream, float baseFreq) { // :133-135
+	forStreams(S, stream, [&](int s) { params[s].formantBaseFreq = baseFreq; });
+	paramsDirty = true;
+}
+void Batch::setFreqMapTable(int stream, const float *table, int n) { // table form of :120-122
+	if (n <= 0 || !table) {
+		forStreams(S, stream, [&](int s) { params[s].hasCustomMap = 0; });
+		paramsDirty = true;
+		return;
+	}
+	if (n < 2) throw Error("frequency-map table needs at least 2 points");
+	SMST_HIP(hipSetDevice(dev));
+	if (d.mapTableLen != n) {
+		if (dMapTable) { SMST_HIP(hipStreamSynchronize(st)); devFree(dMapTable); }
+		dMapTable = devAlloc<float>((size_t)S*n);
+		hostMapTable.assign((size_t)S*n, 0.0f);
+		for (auto &p : params) p.hasCustomMap = 0;
+		d.mapTableLen = n;
+		d.mapTable = dMapTable;
+	}
+	forStreams(S, stream, [&](int s) {
+		std::copy(table, table + n, hostMapTable.begin() + (size_t)s*n);
+		params[s].hasCustomMap = 1;
+	});
+	SMST_HIP(hipMemcpyAsync(dMapTable, hostMapTable.data(), hostMapTable.size()*sizeof(float), hipMemcpyHostToDevice, st));
+	SMST_HIP(hipStreamSynchronize(st));
+	paramsDirty = true;
+}
+
+template <typename F> void Batch::timed(double &acc, F &&f) {
+	if (!profiling) { f(); return; }
+	hipEvent_t a, b;
+	SMST_HIP(hipEventCreate(&a));
+	SMST_HIP(hipEventCreate(&b));
+	SMST_HIP(hipEventRecord(a, st));
+	f();
+	SMST_HIP(hipEventRecord(b, st));
+	SMST_HIP(hipEventSynchronize(b));
+	float ms = 0;
+	SMST_HIP(hipEventElapsedTime(&ms, a, b));
+	acc += ms;
+	hipEventDestroy(a);
+	hipEventDestroy(b);
+}
+BatchTimings Batch::takeTimings() {
+	BatchTimings t = timings;
+	timings = BatchTimings();
+	return t;
+}
+void Batch::synchronize() {
+	SMST_HIP(hipSetDevice(dev));
+	SMST_HIP(hipStreamSynchronize(st));
+}
+
+// ---- process ----------------------------------------------------------------------------------------------
+void Batch::process(const float *in, long long inSS, long long inCS, const int *inSamples,
+                    float *out, long long outSS, long long outCS, const int *outSamples, const unsigned char *active) {
+	SMST_HIP(hipSetDevice(dev));
+	uploadParams();
+	const int T = d.T;
+	std::vector<int> nIn(S), nOut(S);
+	int maxOut = 0;
+	for (int s = 0; s < S; ++s) {
+		bool on = !active || active[s];
+		nIn[s] = on ? inSamples[s] : 0;
+		nOut[s] = on ? outSamples[s] : 0;
+		if (nIn[s] < 0 || nOut[s] < 0) throw Error("negative sample count");
+		maxOut = std::max(maxOut, nOut[s]);
+	}
+	SMST_HIP(hipMemcpyAsync(dInSamples, nIn.data(), S*sizeof(int), hipMemcpyHostToDevice, st));
+	SMST_HIP(hipMemcpyAsync(dOutSamples, nOut.data(), S*sizeof(int), hipMemcpyHostToDevice, st));
+	IoArgs io{in, out, inSS, inCS, outSS, outCS, dInSamples, dOutSamples};
+
+	// K5: silence gate needs the input energy on the host (one 4-byte-per-stream readback per call)
+	std::vector<float> energy(S);
+	launchEnergy(d, io, 0, S, dEnergy, st);
+	SMST_HIP(hipMemcpyAsync(energy.data(), dEnergy, S*sizeof(float), hipMemcpyDeviceToHost, st));
+	SMST_HIP(hipStreamSynchronize(st));
+
+	// K0: block scheduler, exactly as signalsmith-stretch.h:231-319 does it per stream
+	std::vector<std::vector<HopDesc>> hopLists(S);
+	std::vector<int> passFlags(S, 0);
+	bool anyPass = false;
+	int maxHops = 0;
+	for (int s = 0; s < S; ++s) {
+		if (active && !active[s]) continue;
+		StreamSched &sc = sched[s];
+		const StreamParams &prm = params[s];
+		if (energy[s] < kNoiseFloor) { // :240-278
+			if (sc.silenceCounter >= size_t(2*B)) {
+				if (sc.silenceFirst) {
+					sc.silenceFirst = false;
+					sc.samplesSinceLast = SIZE_MAX; // blockProcess = {}
+					zeroBandState(s, true, true, true);
+				}
+				passFlags[s] = 1;
+				anyPass = true;
+				continue; // history is still updated below (copyInput, :270)
+			} else {
+				sc.silenceCounter += size_t(nIn[s]);
+			}
+		} else {
+			sc.silenceCounter = 0;
+			sc.silenceFirst = true;
+		}
+		auto &list = hopLists[s];
+		const bool mapped = prm.hasCustomMap || prm.freqMultiplier != 1; // :300
+		const bool formants = prm.formantMultiplier != 1 || (prm.formantCompensation && mapped); // :310
+		int lastNew = -1;
+		int first = (sc.samplesSinceLast >= size_t(I)) ? 0 : int(size_t(I) - sc.samplesSinceLast);
+		int lastHopPos = -1;
+		for (int o = first; o < nOut[s]; o += I) {
+			HopDesc hd{};
+			const int j = int(list.size());
+			int inputOffset = int(std::round(o*float(nIn[s])/nOut[s])); // :288 (fp32 on purpose)
+			int inputInterval = inputOffset - sc.prevInputOffset;
+			sc.prevInputOffset = inputOffset;
+			hd.inputOffset = inputOffset;
+			hd.outPos = o;
+			unsigned flags = HOP_ACTIVE;
+			const bool newSpectrum = sc.didSeek || inputInterval > 0; // :299
+			bool reanalyse = false;
+			if (newSpectrum) {
+				flags |= HOP_NEW_SPECTRUM;
+				reanalyse = sc.didSeek || std::abs(inputInterval - I) > 1; // :303
+				if (reanalyse) flags |= HOP_REANALYSE_PREV;
+			}
+			if (mapped) flags |= HOP_MAPPED;
+			if (formants) flags |= HOP_FORMANTS;
+			float tf = sc.didSeek ? sc.seekTimeFactor : float(I)/std::max<float>(1, float(inputInterval)); // :312
+			sc.didSeek = false;
+			tf = std::max<float>(tf, 1/kMaxCleanStretch); // :638
+			if (tf > kMaxCleanStretch) flags |= HOP_RANDOM_TF; // :639
+			hd.timeFactor = tf;
+			hd.flags = flags;
+			hd.seed = sc.seed ^ (sc.rngCounter++*0x9E3779B1u);
+			const int tile = j/T;
+			const bool lastInTile = lastNew >= 0 && lastNew/T == tile;
+			hd.inSrc = newSpectrum ? j%T : (lastInTile ? lastNew%T : SRC_STATE);
+			if (newSpectrum && reanalyse) hd.prevSrc = SRC_REANALYSED;
+			else hd.prevSrc = lastInTile ? lastNew%T : SRC_STATE;
+			if (newSpectrum) lastNew = j;
+			list.push_back(hd);
+			lastHopPos = o;
+		}
+		if (lastHopPos >= 0) sc.samplesSinceLast = size_t(nOut[s] - lastHopPos);
+		else if (sc.samplesSinceLast != SIZE_MAX) sc.samplesSinceLast += size_t(nOut[s]);
+		sc.prevInputOffset -= nIn[s]; // :419
+		maxHops = std::max(maxHops, int(list.size()));
+	}
+	const int nTiles = std::max(1, (maxHops + T - 1)/T);
+	const int hopStride = nTiles*T;
+
+	// per-call tables -> device
+	std::vector<HopDesc> hopsAll((size_t)S*hopStride);
+	std::memset(hopsAll.data(), 0, hopsAll.size()*sizeof(HopDesc));
+	std::vector<EmitDesc> emitAll((size_t)S*nTiles);
+	const int nSub = (S + subS - 1)/subS;
+	// tileInfo layout: [sub][tile][2][subS] (nHops, lastNewHop)
+	std::vector<int> tileInfo((size_t)nSub*nTiles*2*subS, 0);
+	std::vector<int> maxSpan((size_t)nSub*nTiles, 0);
+	std::vector<unsigned char> tileHas((size_t)nSub*nTiles*4, 0); // any hops / any mapped / any formants / any new spectrum
+	for (int s = 0; s < S; ++s) {
+		const auto &list = hopLists[s];
+		const int sub = s/subS, sl = s%subS;
+		std::copy(list.begin(), list.end(), hopsAll.begin() + (size_t)s*hopStride);
+		const int nh = int(list.size());
+		for (int t = 0; t < nTiles; ++t) {
+			const int h0 = t*T, h1 = std::min(nh, h0 + T);
+			const int cnt = std::max(0, h1 - h0);
+			EmitDesc ed{};
+			const int total = passFlags[s] ? 0 : nOut[s];
+			if (t == 0) ed.nLo = 0; else ed.nLo = (h0 < nh) ? list[h0].outPos : total;
+			ed.nHi = (h1 < nh && cnt > 0) ? list[h1].outPos : total;
+			if (cnt == 0 && t > 0) ed.nLo = ed.nHi = total;
+			ed.firstHopPos = cnt > 0 ? list[h0].outPos : 0;
+			ed.hopCount = cnt;
+			emitAll[(size_t)s*nTiles + t] = ed;
+			int *info = tileInfo.data() + ((size_t)(sub*nTiles + t)*2)*subS;
+			info[sl] = cnt;
+			int lastNewLocal = -1;
+			for (int h = h0; h < h1; ++h) {
+				if (list[h].flags & HOP_NEW_SPECTRUM) lastNewLocal = h - h0;
+				unsigned char *th = tileHas.data() + (size_t)(sub*nTiles + t)*4;
+				th[0] = 1;
+				if (list[h].flags & HOP_MAPPED) th[1] = 1;
+				if (list[h].flags & HOP_FORMANTS) th[2] = 1;
+				if (list[h].flags & HOP_NEW_SPECTRUM) th[3] = 1;
+			}
+			info[subS + sl] = lastNewLocal;
+			maxSpan[(size_t)sub*nTiles + t] = std::max(maxSpan[(size_t)sub*nTiles + t], ed.nHi - ed.nLo);
+		}
+	}
+	if (hopsAll.size() > hopsCapacity) {
+		if (dHops) devFree(dHops);
+		hopsCapacity = hopsAll.size() + hopsAll.size()/4;
+		dHops = devAlloc<HopDesc>(hopsCapacity);
+	}
+	if (emitAll.size() > emitCapacity) {
+		if (dEmit) devFree(dEmit);
+		emitCapacity = emitAll.size() + emitAll.size()/4;
+		dEmit = devAlloc<EmitDesc>(emitCapacity);
+	}
+	if (tileInfo.size() > tileInfoCapacity) {
+		if (dTileInfo) devFree(dTileInfo);
+		tileInfoCapacity = tileInfo.size() + tileInfo.size()/4;
+		dTileInfo = devAlloc<int>(tileInfoCapacity);
+	}
+	SMST_HIP(hipMemcpyAsync(dHops, hopsAll.data(), hopsAll.size()*sizeof(HopDesc), hipMemcpyHostToDevice, st));
+	SMST_HIP(hipMemcpyAsync(dEmit, emitAll.data(), emitAll.size()*sizeof(EmitDesc), hipMemcpyHostToDevice, st));
+	SMST_HIP(hipMemcpyAsync(dTileInfo, tileInfo.data(), tileInfo.size()*sizeof(int), hipMemcpyHostToDevice, st));
+	if (anyPass) SMST_HIP(hipMemcpyAsync(dFlags, passFlags.data(), S*sizeof(int), hipMemcpyHostToDevice, st));
+	SMST_HIP(hipStreamSynchronize(st)); // the staging vectors are pageable and go out of scope
+
+	d.hops = dHops;
+	d.emit = dEmit;
+	d.hopStride = hopStride;
+	d.emitStride = nTiles;
+
+	const int carryBase = d.carryCur;
+	for (int sub = 0; sub < nSub; ++sub) {
+		const int sBase = sub*subS;
+		const int ns = std::min(subS, S - sBase);
+		for (int t = 0; t < nTiles; ++t) {
+			const unsigned char *th = tileHas.data() + (size_t)(sub*nTiles + t)*4;
+			const int hopBase = t*T;
+			const int tileHops = std::min(T, std::max(1, maxHops - hopBase));
+			DevBatch dd = d;
+			dd.carryCur = (carryBase + t) & 1;
+			dd.nHops = dTileInfo + ((size_t)(sub*nTiles + t)*2)*subS;
+			dd.lastNewHop = dd.nHops + subS;
+			if (th[0]) {
+				if (th[3]) timed(timings.analyseMs, [&] { launchAnalyse(dd, io, sBase, ns, hopBase, tileHops, st); ++timings.analyseLaunches; });
+				if (th[1] || th[2]) timed(timings.feedMs, [&] {
+					launchFeedMap(dd, sBase, ns, hopBase, tileHops, st);
+					if (th[2]) launchFeedFormant(dd, sBase, ns, hopBase, tileHops, st);
+				});
+				timed(timings.predictMs, [&] { launchPredict(dd, sBase, ns, hopBase, tileHops, st); ++timings.predictLaunches; });
+				timed(timings.chainMs, [&] { launchChain(dd, sBase, ns, hopBase, st); ++timings.chainLaunches; });
+				timed(timings.synthMs, [&] { launchSynth(dd, sBase, ns, hopBase, tileHops, st); ++timings.synthLaunches; });
+			}
+			timed(timings.emitMs, [&] { launchEmit(dd, io, sBase, ns, t, maxSpan[(size_t)sub*nTiles + t], st); ++timings.emitLaunches; });
+			if (th[0]) timed(timings.otherMs, [&] { launchCarryState(dd, sBase, ns, hopBase, st); });
+		}
+	}
+	d.carryCur = (carryBase + nTiles) & 1;
+	timed(timings.otherMs, [&] {
+		if (anyPass) launchPassThrough(d, io, dFlags, maxOut, st);
+		launchHistory(d, io, st);
+	});
+	d.histCur ^= 1;
+	SMST_HIP(hipGetLastError());
+}
+
+// ---- seek -------------------------------------------------------------------------------------------------
+void Batch::seek(const float *in, long long inSS, long long inCS, const int *inSamples, const double *rates, const unsigned char *active) {
+	SMST_HIP(hipSetDevice(dev));
+	std::vector<int> nIn(S, 0), flags(S, 0), start(S, 0);
+	for (int s = 0; s < S; ++s) {
+		if (active && !active[s]) continue;
+		flags[s] = 1;
+		nIn[s] = inSamples[s];
+		if (nIn[s] < 0) throw Error("negative sample count");
+	}
+	// energy of the copied part only (:144-154): the last min(n, B+I) samples
+	std::vector<int> nTail(S, 0);
+	for (int s = 0; s < S; ++s) nTail[s] = std::min(nIn[s], B + I);
+	SMST_HIP(hipMemcpyAsync(dInSamples, nIn.data(), S*sizeof(int), hipMemcpyHostToDevice, st));
+	SMST_HIP(hipMemcpyAsync(dFlags, flags.data(), S*sizeof(int), hipMemcpyHostToDevice, st));
+	SMST_HIP(hipStreamSynchronize(st));
+	IoArgs io{in, nullptr, inSS, inCS, 0, 0, dInSamples, dOutSamples};
+	launchSeekHistory(d, io, dFlags, st);
+	d.histCur ^= 1;
+	// energy over the new history (zero padding adds nothing)
+	IoArgs ioE{d.hist[d.histCur], nullptr, (long long)C*d.histLen, (long long)d.histLen, 0, 0, dAux0, dOutSamples};
+	std::vector<int> histN(S, d.histLen);
+	SMST_HIP(hipMemcpyAsync(dAux0, histN.data(), S*sizeof(int), hipMemcpyHostToDevice, st));
+	std::vector<float> energy(S);
+	launchEnergy(d, ioE, 0, S, dEnergy, st);
+	SMST_HIP(hipMemcpyAsync(energy.data(), dEnergy, S*sizeof(float), hipMemcpyDeviceToHost, st));
+	SMST_HIP(hipStreamSynchronize(st));
+	for (int s = 0; s < S; ++s) {
+		if (!flags[s]) continue;
+		StreamSched &sc = sched[s];
+		if (energy[s] >= kNoiseFloor) { // :159-162
+			sc.silenceCounter = 0;
+			sc.silenceFirst = true;
+		}
+		sc.didSeek = true; // :163
+		const double rate = rates ? rates[s] : 1.0;
+		sc.seekTimeFactor = (rate*I > 1) ? float(1/rate) : float(I); // :164
+	}
+}
+
+// ---- flush ------------------------------------------------------------------------------------------------
+void Batch::flush(float *out, long long outSS, long long outCS, const int *outSamples, const float *rates, const unsigned char *active) {
+	SMST_HIP(hipSetDevice(dev));
+	std::vector<int> blockOut(S, 0), blockIn(S, 0), tail(S, -1), tailOff(S, 0), outOff(S, 0);
+	std::vector<unsigned char> runBlock(S, 0), on(S, 0);
+	bool anyBlock = false;
+	int maxIn = 0;
+	for (int s = 0; s < S; ++s) {
+		if (active && !active[s]) continue;
+		on[s] = 1;
+		const int n = outSamples[s];
+		if (n < 0) throw Error("negative sample count");
+		const int outputBlock = std::max(0, n - I); // :439
+		const float rate = rates ? rates[s] : 0.0f;
+		if (outputBlock > 0) {
+			runBlock[s] = 1;
+			anyBlock = true;
+			blockOut[s] = outputBlock;
+			blockIn[s] = int(outputBlock*rate); // :440
+			maxIn = std::max(maxIn, blockIn[s]);
+		}
+		tail[s] = n - outputBlock;
+		outOff[s] = outputBlock;
+	}
+	if (anyBlock) {
+		if ((size_t)maxIn + 1 > zerosCapacity) {
+			if (dZeros) { SMST_HIP(hipStreamSynchronize(st)); devFree(dZeros); }
+			zerosCapacity = (size_t)maxIn + 1 + 4096;
+			dZeros = devAlloc<float>(zerosCapacity);
+			SMST_HIP(hipMemsetAsync(dZeros, 0, zerosCapacity*sizeof(float), st));
+		}
+		process(dZeros, 0, 0, blockIn.data(), out, outSS, outCS, blockOut.data(), runBlock.data());
+	}
+	for (int s = 0; s < S; ++s) {
+		if (!on[s]) continue;
+		const StreamSched &sc = sched[s];
+		// where the L1 output ring the reference reads here sits relative to our carry (split: the "ahead" ring)
+		tailOff[s] = (split && sc.samplesSinceLast != SIZE_MAX && sc.samplesSinceLast < size_t(I)) ? int(size_t(I) - sc.samplesSinceLast) : 0;
+	}
+	SMST_HIP(hipMemcpyAsync(dOutSamples, tail.data(), S*sizeof(int), hipMemcpyHostToDevice, st));
+	SMST_HIP(hipMemcpyAsync(dAux0, tailOff.data(), S*sizeof(int), hipMemcpyHostToDevice, st));
+	SMST_HIP(hipMemcpyAsync(dAux1, outOff.data(), S*sizeof(int), hipMemcpyHostToDevice, st));
+	SMST_HIP(hipStreamSynchronize(st));
+	IoArgs io{nullptr, out, 0, 0, outSS, outCS, dInSamples, dOutSamples};
+	launchFlushTail(d, io, dAux0, dAux1, st);
+	// stft.reset(0.1) + zero prevInput/output (:456-463)
+	writeSeedCarry(active ? on.data() : nullptr);
+	for (int s = 0; s < S; ++s) if (on[s]) zeroBandState(s, false, true, true);
+	SMST_HIP(hipGetLastError());
+}
+
+// ---- outputSeek -------------------------------------------------------------------------------------------
+void Batch::outputSeek(const float *in, long long inSS, long long inCS, const int *inputLengths) {
+	// signalsmith-stretch.h:173-204
+	reset();
+	const int outLat = outputLatency(), inLat = inputLatency();
+	std::vector<int> seekSamples(S), surplus(S), preOut(S, outLat);
+	std::vector<double> rates(S);
+	for (int s = 0; s < S; ++s) {
+		surplus[s] = std::max(inputLengths[s] - inLat, 0);
+		float playbackRate = surplus[s]/float(outLat);
+		seekSamples[s] = inputLengths[s] - surplus[s];
+		rates[s] = playbackRate;
+	}
+	seek(in, inSS, inCS, seekSamples.data(), rates.data());
+	// pre-roll output into scratch [S][C][outLat]
+	const size_t need = (size_t)S*C*outLat;
+	if (need > scratchOutCapacity) {
+		if (dScratchOut) { SMST_HIP(hipStreamSynchronize(st)); devFree(dScratchOut); }
+		scratchOutCapacity = need;
+		dScratchOut = devAlloc<float>(need);
+	}
+	// offset input per stream: seekSamples differ per stream, so pass per-stream start through a shifted base when uniform,
+	// otherwise run stream groups with equal offsets
+	std::vector<int> order(S);
+	for (int s = 0; s < S; ++s) order[s] = s;
+	std::vector<unsigned char> mask(S);
+	std::vector<int> done(S, 0);
+	for (int s0 = 0; s0 < S; ++s0) {
+		if (done[s0]) continue;
+		std::fill(mask.begin(), mask.end(), 0);
+		for (int s = s0; s < S; ++s) if (!done[s] && seekSamples[s] == seekSamples[s0]) { mask[s] = 1; done[s] = 1; }
+		process(in + seekSamples[s0], inSS, inCS, surplus.data(), dScratchOut, (long long)C*outLat, outLat, preOut.data(), mask.data());
+	}
+	// "put the thing down, flip it and reverse it" (:198-203): negate, reverse, add into the output ring
+	std::vector<int> off(S, 0);
+	for (int s = 0; s < S; ++s) {
+		const StreamSched &sc = sched[s];
+		off[s] = (split && sc.samplesSinceLast != SIZE_MAX && sc.samplesSinceLast < size_t(I)) ? int(size_t(I) - sc.samplesSinceLast) : 0;
+	}
+	SMST_HIP(hipMemcpyAsync(dAux0, off.data(), S*sizeof(int), hipMemcpyHostToDevice, st));
+	SMST_HIP(hipStreamSynchronize(st));
+	launchAddPreRoll(d, dScratchOut, outLat, dAux0, st);
+	SMST_HIP(hipGetLastError());
+}
+
+// ---- test hooks -------------------------------------------------------------------------------------------
+void Batch::debugGetState(int stream, int which, float *dst) {
+	SMST_HIP(hipSetDevice(dev));
+	SMST_HIP(hipStreamSynchronize(st));
+	const size_t off = (size_t)stream*C*M;
+	if (which == 3) {
+		SMST_HIP(hipMemcpy(dst, d.stEnergy + off, (size_t)C*M*sizeof(float), hipMemcpyDeviceToHost));
+		return;
+	}
+	const float2 *src = which == 0 ? d.stInput : (which == 1 ? d.stPrev : d.stOut);
+	SMST_HIP(hipMemcpy(dst, src + off, (size_t)C*M*sizeof(float2), hipMemcpyDeviceToHost));
+}
+void Batch::debugGetCarry(int stream, float *sums, float *products) {
+	SMST_HIP(hipSetDevice(dev));
+	SMST_HIP(hipStreamSynchronize(st));
+	SMST_HIP(hipMemcpy(sums, d.carrySum[d.carryCur] + (size_t)stream*C*d.carryLen, (size_t)C*d.carryLen*sizeof(float), hipMemcpyDeviceToHost));
+	SMST_HIP(hipMemcpy(products, d.carryWp[d.carryCur] + (size_t)stream*d.carryLen, (size_t)d.carryLen*sizeof(float), hipMemcpyDeviceToHost));
+}
+
+} // namespace smst

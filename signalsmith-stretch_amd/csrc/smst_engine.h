@@ -1,0 +1,129 @@
+// Host-side engine: owns a batch of independent streams on one GPU, mirrors the reference's block scheduler
+// (signalsmith-stretch.h:280-319) per stream, and drives the gfx950 kernels tile by tile.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <string>
+#include <vector>
+#include <hip/hip_runtime.h>
+#include "smst_device.h"
+
+namespace smst {
+
+struct StreamSched { // reference members: signalsmith-stretch.h:494-529
+	size_t samplesSinceLast = SIZE_MAX; // blockProcess.samplesSinceLast, :496
+	int prevInputOffset = -1;           // :527
+	bool didSeek = false;               // :528
+	float seekTimeFactor = 1;           // :529
+	size_t silenceCounter = 0;          // :510
+	bool silenceFirst = true;           // :511
+	unsigned rngCounter = 0;
+	unsigned seed = 0;
+};
+
+struct BatchTimings { // filled when profiling is enabled (hipEvent pairs around each kernel class)
+	double analyseMs = 0, feedMs = 0, predictMs = 0, chainMs = 0, synthMs = 0, emitMs = 0, otherMs = 0;
+	long analyseLaunches = 0, synthLaunches = 0, chainLaunches = 0, predictLaunches = 0, emitLaunches = 0;
+};
+
+class Batch {
+public:
+	Batch(int streams, int channels, int block, int interval, bool split, int device, long seed);
+	~Batch();
+	Batch(const Batch &) = delete;
+	Batch &operator=(const Batch &) = delete;
+
+	// geometry queries (signalsmith-stretch.h:42-47,96-104,166-168,205-207)
+	int streams() const { return S; }
+	int channels() const { return C; }
+	int blockSamples() const { return B; }
+	int intervalSamples() const { return I; }
+	int fftSamples() const { return N; }
+	int bands() const { return M; }
+	bool splitComputation() const { return split; }
+	int inputLatency() const { return B - B/2; }
+	int outputLatency() const { return B/2 + (split ? I : 0); }
+	int seekLength() const { return B + I; }
+	int outputSeekLength(float playbackRate) const { return int(inputLatency() + playbackRate*outputLatency()); }
+
+	void reset(); // :49-60, all streams
+	// parameter setters, stream = -1 for all (signalsmith-stretch.h:107-135)
+	void setTransposeFactor(int stream, float multiplier, float tonalityLimit);
+	void setTransposeSemitones(int stream, float semitones, float tonalityLimit);
+	void setFormantFactor(int stream, float multiplier, bool compensatePitch);
+	void setFormantSemitones(int stream, float semitones, bool compensatePitch);
+	void setFormantBase(int stream, float baseFreq);
+	void setFreqMapTable(int stream, const float *table, int n); // table form of setFreqMap (:120); n == 0 clears
+
+	// All sample pointers are DEVICE pointers here (planar: stream stride, channel stride, contiguous samples).
+	// `active` (host, may be null) masks streams out of the call entirely.
+	void process(const float *in, long long inStreamStride, long long inChannelStride, const int *inSamples,
+	             float *out, long long outStreamStride, long long outChannelStride, const int *outSamples,
+	             const unsigned char *active = nullptr); // :210-423
+	void seek(const float *in, long long inStreamStride, long long inChannelStride, const int *inSamples,
+	          const double *playbackRates, const unsigned char *active = nullptr); // :140-165
+	void flush(float *out, long long outStreamStride, long long outChannelStride, const int *outSamples,
+	           const float *playbackRates, const unsigned char *active = nullptr); // :427-464
+	void outputSeek(const float *in, long long inStreamStride, long long inChannelStride, const int *inputLengths); // :173-204
+	void synchronize();
+
+	hipStream_t stream() const { return st; }
+	int device() const { return dev; }
+	void enableProfiling(bool on) { profiling = on; }
+	BatchTimings takeTimings();
+	size_t workspaceBytes() const { return wsBytes; }
+	int subBatchStreams() const { return subS; }
+
+	// test hooks: copy state rows to the host (which: 0 input, 1 prevInput, 2 output -> 2*C*M floats; 3 energy -> C*M)
+	void debugGetState(int stream, int which, float *dst);
+	void debugGetCarry(int stream, float *sums, float *products); // [C][B+I], [B+I]
+
+private:
+	int S, C, B, I, N, M, L;
+	bool split;
+	int dev;
+	hipStream_t st = nullptr;
+	int subS = 0;
+	size_t wsBytes = 0;
+	DevBatch d{};
+	std::vector<StreamSched> sched;
+	std::vector<StreamParams> params;
+	bool paramsDirty = true;
+	bool profiling = false;
+	BatchTimings timings;
+
+	std::vector<void *> allocations;
+	float *dEnergy = nullptr;
+	int *dInSamples = nullptr, *dOutSamples = nullptr, *dFlags = nullptr, *dAux0 = nullptr, *dAux1 = nullptr;
+	HopDesc *dHops = nullptr;
+	size_t hopsCapacity = 0;
+	EmitDesc *dEmit = nullptr;
+	size_t emitCapacity = 0;
+	int *dTileInfo = nullptr;
+	size_t tileInfoCapacity = 0;
+	float *dZeros = nullptr;
+	size_t zerosCapacity = 0;
+	float *dScratchOut = nullptr;
+	size_t scratchOutCapacity = 0;
+	StreamParams *dParams = nullptr;
+	float *dMapTable = nullptr;
+	std::vector<float> hostMapTable;
+	std::vector<float> seedCarryWp;
+
+	template <typename T> T *devAlloc(size_t count);
+	void devFree(void *p);
+	void uploadParams();
+	void allocateWorkspace();
+	void writeSeedCarry(const unsigned char *active);
+	void zeroBandState(int stream, bool input, bool prev, bool output);
+	template <typename F> void timed(double &acc, F &&f);
+};
+
+// error plumbing for the C ABI
+struct Error : std::exception {
+	std::string msg;
+	explicit Error(std::string m) : msg(std::move(m)) {}
+	const char *what() const noexcept override { return msg.c_str(); }
+};
+
+} // namespace smst

@@ -1,0 +1,925 @@
+// gfx950 (CDNA4, wave64) kernels for the SignalsmithStretch<float>::process() spectral hot path.
+//
+// Written from scratch for MI355X: no hipify, no CUDA shims, no rocFFT.  The reference computes one
+// stream, one hop, one bin at a time (signalsmith-stretch.h:280-416, :633-813); here the batch of streams
+// AND the time axis are the parallel axes:
+//   * everything that depends only on the input (analysis FFTs, energies, peaks, frequency map, formant
+//     envelope, per-bin twist coefficients) is computed for all hops of a tile at once;
+//   * the one true recurrence -- Band.output, serial in the bin index and carried from hop to hop
+//     (signalsmith-stretch.h:727-801) -- runs as a skewed wavefront: lane k of a wave owns hop k of a
+//     64-hop tile and trails lane k-1 by `lag` bins, so 64 hops advance per step instead of one;
+//   * synthesis FFTs and the overlap-add (a gather over the covering frames, no atomics) are again parallel
+//     over (stream, hop, channel).
+#include <hip/hip_runtime.h>
+#include "smst_device.h"
+
+namespace smst {
+
+// ------------------------------------------------------------------------------------------------------
+// small helpers
+// ------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) { // a*b          (reference _impl::mul<false>, :17-26)
+	return make_float2(a.x*b.x - a.y*b.y, a.x*b.y + a.y*b.x);
+}
+__device__ __forceinline__ float2 cmulc(float2 a, float2 b) { // a*conj(b)   (reference _impl::mul<true>)
+	return make_float2(b.x*a.x + b.y*a.y, b.x*a.y - b.y*a.x);
+}
+__device__ __forceinline__ float cnorm(float2 a) { return a.x*a.x + a.y*a.y; } // :27-31
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ float2 cscale(float2 a, float s) { return make_float2(a.x*s, a.y*s); }
+__device__ __forceinline__ float2 cconj(float2 a) { return make_float2(a.x, -a.y); }
+__device__ __forceinline__ float2 mulI(float2 a) { return make_float2(-a.y, a.x); }
+__device__ __forceinline__ float2 mulNegI(float2 a) { return make_float2(a.y, -a.x); }
+
+__device__ __forceinline__ size_t rowOf(const DevBatch &d, int s, int k, int c) {
+	return ((size_t)((size_t)s*d.T + k)*d.C + c)*(size_t)d.M;
+}
+__device__ __forceinline__ size_t stateRow(const DevBatch &d, int sGlobal, int c) {
+	return ((size_t)sGlobal*d.C + c)*(size_t)d.M;
+}
+
+// counter-based uniform in [0,1) (replaces std::default_random_engine of :616,:640 -- implementation-defined
+// in the reference, so no parity is possible there)
+__device__ __forceinline__ float hashUniform(unsigned seed, unsigned a, unsigned b) {
+	unsigned x = seed ^ (a*0x9E3779B9u) ^ (b*0x85EBCA6Bu + 0xC2B2AE35u);
+	x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
+	return (x >> 8)*(1.0f/16777216.0f);
+}
+
+// ------------------------------------------------------------------------------------------------------
+// In-LDS Stockham FFT (decimation in frequency, natural order in and out), H = 2^k * {1,3,5}.
+// Radix-4 passes (+ one radix-2) come first so the stride `s` stays a power of two; the single odd-radix
+// pass comes last, where all its twiddles are 1.  src/dst ping-pong; returns the buffer holding the result.
+// SIGN = -1: forward (e^{-i...}), +1: inverse (unnormalised).
+// ------------------------------------------------------------------------------------------------------
+template <int SIGN>
+__device__ __forceinline__ float2 twiddle(const float2 *__restrict__ tw, int idx) {
+	float2 w = tw[idx];
+	if (SIGN > 0) w.y = -w.y;
+	return w;
+}
+
+template <int SIGN>
+__device__ float2 *fftLds(float2 *src, float2 *dst, const FftPlan &plan, const float2 *__restrict__ tw) {
+	const int H = plan.H;
+	int nCur = H;
+	int shift = 0; // s = 1 << shift while radices are powers of two
+	for (int pass = 0; pass < plan.npass; ++pass) {
+		const int r = plan.radix[pass];
+		const int m = nCur/r;
+		const int nb = H/r;
+		const int twScale = H/nCur;
+		if (r == 4) {
+			const int s = 1 << shift;
+			for (int t = threadIdx.x; t < nb; t += blockDim.x) {
+				const int p = t >> shift, q0 = t & (s - 1);
+				const float2 *in = src + q0 + (p << shift);
+				const int inStride = m << shift;
+				float2 *out = dst + q0 + ((4*p) << shift);
+				float2 a = in[0], b = in[inStride], c = in[2*inStride], e = in[3*inStride];
+				float2 apc = cadd(a, c), amc = csub(a, c), bpe = cadd(b, e), bme = csub(b, e);
+				float2 jb = (SIGN < 0) ? mulNegI(bme) : mulI(bme);
+				const int ti = p*twScale;
+				out[0] = cadd(apc, bpe);
+				out[s] = cmul(cadd(amc, jb), twiddle<SIGN>(tw, ti));
+				out[2*s] = cmul(csub(apc, bpe), twiddle<SIGN>(tw, 2*ti));
+				out[3*s] = cmul(csub(amc, jb), twiddle<SIGN>(tw, 3*ti));
+			}
+			shift += 2;
+		} else if (r == 2) {
+			const int s = 1 << shift;
+			for (int t = threadIdx.x; t < nb; t += blockDim.x) {
+				const int p = t >> shift, q0 = t & (s - 1);
+				const float2 *in = src + q0 + (p << shift);
+				const int inStride = m << shift;
+				float2 *out = dst + q0 + ((2*p) << shift);
+				float2 a = in[0], b = in[inStride];
+				out[0] = cadd(a, b);
+				out[s] = cmul(csub(a, b), twiddle<SIGN>(tw, p*twScale));
+			}
+			shift += 1;
+		} else if (r == 3) { // last pass: m == 1, p == 0, all twiddles are 1
+			const int s = nb;
+			const float s3 = 0.86602540378443864676f;
+			for (int t = threadIdx.x; t < nb; t += blockDim.x) {
+				float2 a = src[t], b = src[t + s], c = src[t + 2*s];
+				float2 bpc = cadd(b, c), bmc = csub(b, c);
+				float2 tt = make_float2(a.x - 0.5f*bpc.x, a.y - 0.5f*bpc.y);
+				float2 u = cscale((SIGN < 0) ? mulNegI(bmc) : mulI(bmc), s3);
+				dst[t] = cadd(a, bpc);
+				dst[t + s] = cadd(tt, u);
+				dst[t + 2*s] = csub(tt, u);
+			}
+		} else { // r == 5, last pass
+			const int s = nb;
+			const float c1 = 0.30901699437494742410f, c2 = -0.80901699437494742410f;
+			const float s1 = 0.95105651629515357212f, s2 = 0.58778525229247312917f;
+			for (int t = threadIdx.x; t < nb; t += blockDim.x) {
+				float2 a = src[t], b = src[t + s], c = src[t + 2*s], e = src[t + 3*s], f = src[t + 4*s];
+				float2 bpf = cadd(b, f), bmf = csub(b, f), cpe = cadd(c, e), cme = csub(c, e);
+				float2 t1 = make_float2(a.x + c1*bpf.x + c2*cpe.x, a.y + c1*bpf.y + c2*cpe.y);
+				float2 t2 = make_float2(a.x + c2*bpf.x + c1*cpe.x, a.y + c2*bpf.y + c1*cpe.y);
+				float2 u1 = make_float2(s1*bmf.x + s2*cme.x, s1*bmf.y + s2*cme.y);
+				float2 u2 = make_float2(s2*bmf.x - s1*cme.x, s2*bmf.y - s1*cme.y);
+				float2 ju1 = (SIGN < 0) ? mulNegI(u1) : mulI(u1);
+				float2 ju2 = (SIGN < 0) ? mulNegI(u2) : mulI(u2);
+				dst[t] = cadd(a, cadd(bpf, cpe));
+				dst[t + s] = cadd(t1, ju1);
+				dst[t + 2*s] = cadd(t2, ju2);
+				dst[t + 3*s] = csub(t2, ju2);
+				dst[t + 4*s] = csub(t1, ju1);
+			}
+		}
+		__syncthreads();
+		float2 *tmp = src; src = dst; dst = tmp;
+		nCur = m;
+	}
+	return src;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// K5: per-stream input energy (silence gate, signalsmith-stretch.h:231-238)
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void kEnergy(DevBatch d, IoArgs io, int sBase, float *__restrict__ energyOut) {
+	const int s = blockIdx.x;
+	const int n = io.inSamples[sBase + s];
+	float acc = 0;
+	for (int c = 0; c < d.C; ++c) {
+		const float *x = io.in + (size_t)(sBase + s)*io.inStreamStride + (size_t)c*io.inChannelStride;
+		for (int i = threadIdx.x; i < n; i += blockDim.x) {
+			float v = x[i];
+			acc += v*v;
+		}
+	}
+	extern __shared__ __attribute__((aligned(16))) unsigned char smemRaw[];
+	float *red = reinterpret_cast<float *>(smemRaw);
+	red[threadIdx.x] = acc;
+	__syncthreads();
+	for (int w = 128; w > 0; w >>= 1) {
+		if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+		__syncthreads();
+	}
+	if (threadIdx.x == 0) energyOut[sBase + s] = red[0];
+}
+
+// ------------------------------------------------------------------------------------------------------
+// K1: analysis.  One workgroup per (hop, channel x {current, previous}, stream):
+// gather B samples ending at the hop's input offset from the contiguous per-channel sample block (or the
+// carried history for negative indices), multiply by the analysis window, fold into the N/2-point complex
+// sequence of the half-bin-shifted real FFT, Stockham FFT in LDS, write the M = N/2 bins.
+// Replaces stft.analyseStep at signalsmith-stretch.h:337,:359 (+ the copies :344-350,:366-372).
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void kAnalyse(DevBatch d, IoArgs io, int sBase, int hopBase) {
+	extern __shared__ __attribute__((aligned(16))) unsigned char smemRaw[];
+	float2 *bufA = reinterpret_cast<float2 *>(smemRaw);
+	float2 *bufB = bufA + d.M;
+
+	const int k = blockIdx.x;
+	const int c = blockIdx.y >> 1;
+	const int which = blockIdx.y & 1; // 0: current window, 1: window one interval earlier
+	const int s = blockIdx.z;
+	const HopDesc hd = d.hops[(size_t)(sBase + s)*d.hopStride + hopBase + k];
+	if (!(hd.flags & HOP_ACTIVE) || !(hd.flags & HOP_NEW_SPECTRUM)) return;
+	if (which == 1 && !(hd.flags & HOP_REANALYSE_PREV)) return;
+
+	const int B = d.B, H = d.M, halfB = B/2;
+	const int base = hd.inputOffset - (which ? d.I : 0) - B; // index of block element 0 in the call's input
+	const float *x = io.in + (size_t)(sBase + s)*io.inStreamStride + (size_t)c*io.inChannelStride;
+	const float *hist = d.hist[d.histCur] + ((size_t)(sBase + s)*d.C + c)*(size_t)d.histLen;
+	const float *__restrict__ win = d.window;
+
+	for (int m = threadIdx.x; m < H; m += blockDim.x) {
+		float re = 0, im = 0;
+		if (m < B - halfB) {
+			int i = m + halfB;
+			int src = base + i;
+			float v = (src >= 0) ? x[src] : hist[d.histLen + src];
+			re = v*win[i];
+		}
+		if (m >= H - halfB) {
+			int i = m - H + halfB;
+			int src = base + i;
+			float v = (src >= 0) ? x[src] : hist[d.histLen + src];
+			im = v*win[i];
+		}
+		bufA[m] = cmul(make_float2(re, im), d.halfTw[m]);
+	}
+	__syncthreads();
+	float2 *res = fftLds<-1>(bufA, bufB, d.plan, d.twH);
+
+	float2 *dst = (which ? d.Xprev : d.Xcur) + rowOf(d, s, k, c);
+	const int N = d.N;
+	for (int j = threadIdx.x; j < H; j += blockDim.x) {
+		float2 u = res[j];
+		int kk = 2*j;
+		if (kk < H) dst[kk] = u;
+		else dst[N - 1 - kk] = cconj(u);
+	}
+}
+
+// ------------------------------------------------------------------------------------------------------
+// Row lookup shared by the feed-forward kernels
+// ------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ const float2 *inputRow(const DevBatch &d, const HopDesc &hd, int s, int sGlobal, int c) {
+	return (hd.inSrc >= 0) ? d.Xcur + rowOf(d, s, hd.inSrc, c) : d.stInput + stateRow(d, sGlobal, c);
+}
+__device__ __forceinline__ const float2 *prevRow(const DevBatch &d, const HopDesc &hd, int s, int k, int sGlobal, int c) {
+	if (hd.prevSrc >= 0) return d.Xcur + rowOf(d, s, hd.prevSrc, c);
+	if (hd.prevSrc == SRC_REANALYSED) return d.Xprev + rowOf(d, s, k, c);
+	return d.stPrev + stateRow(d, sGlobal, c);
+}
+
+__device__ __forceinline__ float mapFreqDev(const DevBatch &d, const StreamParams &p, int sGlobal, float freq) { // :850-856
+	if (p.hasCustomMap) {
+		const float *t = d.mapTable + (size_t)sGlobal*d.mapTableLen;
+		const int n = d.mapTableLen;
+		float pos = freq*2*float(n) - 0.5f;
+		if (pos <= 0) return t[0] + (t[1] - t[0])*pos;
+		if (pos >= n - 1) return t[n - 1] + (t[n - 1] - t[n - 2])*(pos - (n - 1));
+		int lo = (int)floorf(pos);
+		float fr = pos - lo;
+		return t[lo] + (t[lo + 1] - t[lo])*fr;
+	}
+	if (freq > p.freqTonalityLimit) return freq + (p.freqMultiplier - 1)*p.freqTonalityLimit;
+	return freq*p.freqMultiplier;
+}
+
+// ------------------------------------------------------------------------------------------------------
+// K2b-d: channel-summed energy, 4-pass one-pole smoothing, peak centroids, output map.
+// One 64-thread workgroup per (hop, stream).  The recurrences over the bin index are evaluated serially by
+// lane 0 in the reference's own order (signalsmith-stretch.h:818-848, :859-880, :882-917) so every rounding
+// matches; the parallel axis is the (stream, hop) grid.  Also emits the channel-summed energy (formant metric,
+// :974-980) and the raw pitch estimate (:929-960) when formants are on.
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void kFeedMap(DevBatch d, int sBase, int hopBase) {
+	extern __shared__ __attribute__((aligned(16))) unsigned char smemRaw[];
+	float *energy = reinterpret_cast<float *>(smemRaw); // [M]
+	float *smoothed = energy + d.M;                      // [M]
+	float2 *peaks = reinterpret_cast<float2 *>(smoothed + d.M); // [M/2 + 2] {input, output}
+	int *nPeaksShared = reinterpret_cast<int *>(peaks + d.M/2 + 2);
+
+	const int k = blockIdx.x, s = blockIdx.y, sg = sBase + s;
+	const HopDesc hd = d.hops[(size_t)sg*d.hopStride + hopBase + k];
+	if (!(hd.flags & HOP_ACTIVE)) return;
+	const bool mapped = hd.flags & HOP_MAPPED, formants = hd.flags & HOP_FORMANTS;
+	if (!mapped && !formants) return;
+	const int M = d.M, C = d.C;
+	const float Nf = float(d.N);
+
+	for (int b = threadIdx.x; b < M; b += blockDim.x) {
+		float e = 0;
+		for (int c = 0; c < C; ++c) e += cnorm(inputRow(d, hd, s, sg, c)[b]);
+		energy[b] = e;
+		smoothed[b] = e;
+		if (formants) d.esum[((size_t)s*d.T + k)*M + b] = e;
+	}
+	__syncthreads();
+	const StreamParams prm = d.params[sg];
+
+	if (threadIdx.x == 0) {
+		if (formants && prm.formantBaseFreq <= 0) { // estimateFrequency() raw part, :929-960
+			int p0 = 0, p1 = 0, p2 = 0;
+			for (int b = 1; b < M - 1; ++b) {
+				float e = energy[b];
+				if (e < energy[b - 1] || e <= energy[b + 1]) continue;
+				if (e > energy[p0]) {
+					if (e > energy[p1]) {
+						if (e > energy[p2]) { p0 = p1; p1 = p2; p2 = b; }
+						else { p0 = p1; p1 = b; }
+					} else {
+						p0 = b;
+					}
+				}
+			}
+			int peakEstimate = p2;
+			if (energy[p1] > energy[p2]*0.1f) {
+				int diff = abs(peakEstimate - p1);
+				if (diff > peakEstimate/8 && diff < peakEstimate*7/8) peakEstimate = peakEstimate%diff;
+				if (energy[p0] > energy[p2]*0.01f) {
+					int diff2 = abs(peakEstimate - p0);
+					if (diff2 > peakEstimate/8 && diff2 < peakEstimate*7/8) peakEstimate = peakEstimate%diff2;
+				}
+			}
+			float weight = energy[p2];
+			d.est[((size_t)s*d.T + k)*2] = peakEstimate*weight;
+			d.est[((size_t)s*d.T + k)*2 + 1] = weight;
+		}
+		int nPeaks = 0;
+		if (mapped) {
+			// smoothEnergy steps 1,2: (down, up) x 2 with the state carried through, :837-847
+			const float smoothingBins = Nf/float(d.I);
+			const float slew = 1/(1 + smoothingBins*0.5f);
+			float e = 0;
+			for (int rep = 0; rep < 2; ++rep) {
+				for (int b = M - 1; b >= 0; --b) { e += (smoothed[b] - e)*slew; smoothed[b] = e; }
+				for (int b = 0; b < M; ++b) { e += (smoothed[b] - e)*slew; smoothed[b] = e; }
+			}
+			// findPeaks, :859-880
+			int start = 0;
+			while (start < M) {
+				if (energy[start] > smoothed[start]) {
+					int end = start;
+					float bandSum = 0, energySum = 0;
+					while (end < M && energy[end] > smoothed[end]) {
+						bandSum += end*energy[end];
+						energySum += energy[end];
+						++end;
+					}
+					float avgBand = bandSum/energySum;
+					float avgFreq = (avgBand + 0.5f)/Nf;
+					peaks[nPeaks++] = make_float2(avgBand, mapFreqDev(d, prm, sg, avgFreq)*Nf - 0.5f);
+					start = end;
+				}
+				++start;
+			}
+		}
+		*nPeaksShared = nPeaks;
+	}
+	__syncthreads();
+	if (!mapped) return; // the map stays the identity (handled by the readers)
+
+	// updateOutputMap, :882-917 -- per output bin, parallel; segment rules reproduce the reference's write order
+	const int nPeaks = *nPeaksShared;
+	float2 *mapRow = d.map + ((size_t)s*d.T + k)*M;
+	for (int b = threadIdx.x; b < M; b += blockDim.x) {
+		float2 mp = make_float2(float(b), 1.0f);
+		if (nPeaks > 0) {
+			const float2 first = peaks[0], lastP = peaks[nPeaks - 1];
+			// (with one peak every bin is below ceil(out) or at/above trunc(out), so the search branch needs >= 2)
+			if (b >= max(0, (int)lastP.y)) { // top segment is written last, :913-916
+				mp = make_float2(b + (lastP.x - lastP.y), 1.0f);
+			} else if (b < min(M, (int)ceilf(first.y))) { // :889-892
+				mp = make_float2(b + (first.x - first.y), 1.0f);
+			} else if (nPeaks >= 2) {
+				// find p in [1, nPeaks) with ceil(peaks[p-1].out) <= b < ceil(peaks[p].out); later p wins on ties
+				int lo = 1, hi = nPeaks - 1;
+				while (lo < hi) { // largest p with ceil(peaks[p-1].out) <= b
+					int mid = (lo + hi + 1) >> 1;
+					if (max(0, (int)ceilf(peaks[mid - 1].y)) <= b) lo = mid; else hi = mid - 1;
+				}
+				const float2 prev = peaks[lo - 1], next = peaks[lo];
+				if (b < min(M, (int)ceilf(next.y))) {
+					float rangeScale = 1/(next.y - prev.y);
+					float outOffset = prev.x - prev.y;
+					float outScale = next.x - next.y - prev.x + prev.y;
+					float gradScale = outScale*rangeScale;
+					float r = (b - prev.y)*rangeScale;
+					float h = r*r*(3 - 2*r);
+					float outB = b + outOffset + h*outScale;
+					float gradH = 6*r*(1 - r);
+					mp = make_float2(outB, 1 + gradH*gradScale);
+				} // else: not covered by any segment (non-monotonic map only): identity, see DESIGN.md
+			}
+		}
+		mapRow[b] = mp;
+	}
+}
+
+// ------------------------------------------------------------------------------------------------------
+// K2e: formant envelope and per-bin energy ratio (signalsmith-stretch.h:972-1036).
+// One 64-thread workgroup per (hop, stream); the max-decay / min-grow passes are serial in the bin index
+// and evaluated by lane 0 in the reference's order.
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void kFeedFormant(DevBatch d, int sBase, int hopBase) {
+	extern __shared__ __attribute__((aligned(16))) unsigned char smemRaw[];
+	float *metric = reinterpret_cast<float *>(smemRaw); // [M + 2]
+
+	const int k = blockIdx.x, s = blockIdx.y, sg = sBase + s;
+	const HopDesc hd = d.hops[(size_t)sg*d.hopStride + hopBase + k];
+	if (!(hd.flags & HOP_ACTIVE) || !(hd.flags & HOP_FORMANTS)) return;
+	const int M = d.M;
+	const float Nf = float(d.N);
+	const StreamParams prm = d.params[sg];
+	const float *esum = d.esum + ((size_t)s*d.T + k)*M;
+	for (int b = threadIdx.x; b < M + 2; b += blockDim.x) metric[b] = (b < M) ? esum[b] : 0.0f;
+	__syncthreads();
+
+	if (threadIdx.x == 0) {
+		float freqEstimate = prm.formantBaseFreq*Nf - 0.5f; // freqToBand, :982
+		if (prm.formantBaseFreq <= 0) { // smoothed estimate: replay the recurrence of :962-965 over the tile's hops
+			float w = d.stFreq[2*sg], wt = d.stFreq[2*sg + 1];
+			for (int j = 0; j <= k; ++j) {
+				const HopDesc hj = d.hops[(size_t)sg*d.hopStride + hopBase + j];
+				if (!(hj.flags & HOP_ACTIVE) || !(hj.flags & HOP_FORMANTS)) continue;
+				float pw = d.est[((size_t)s*d.T + j)*2], ww = d.est[((size_t)s*d.T + j)*2 + 1];
+				w += (pw - w)*0.25f;
+				wt += (ww - wt)*0.25f;
+			}
+			freqEstimate = w/(wt + 1e-30f);
+		}
+		float decay = 1 - 1/(freqEstimate*0.5f + 1);
+		float e = 0;
+		for (int rep = 0; rep < 2; ++rep) {
+			for (int b = M - 1; b >= 0; --b) { e = fmaxf(metric[b], e*decay); metric[b] = e; }
+			for (int b = 0; b < M; ++b) { e = fmaxf(metric[b], e*decay); metric[b] = e; }
+		}
+		decay = 1/decay;
+		for (int rep = 0; rep < 2; ++rep) {
+			for (int b = M - 1; b >= 0; --b) { e = fminf(metric[b], e*decay); metric[b] = e; }
+			for (int b = 0; b < M; ++b) { e = fminf(metric[b], e*decay); metric[b] = e; }
+		}
+	}
+	__syncthreads();
+	float *ratio = d.ratio + ((size_t)s*d.T + k)*M;
+	for (int b = threadIdx.x; b < M; b += blockDim.x) {
+		float inputF = (b + 0.5f)/Nf;
+		float outputF = prm.formantCompensation ? mapFreqDev(d, prm, sg, inputF) : inputF;
+		// invMapFormant, :920-925
+		if (outputF*prm.invFormantMultiplier > prm.freqTonalityLimit) outputF = outputF + (1 - prm.formantMultiplier)*prm.freqTonalityLimit;
+		else outputF = outputF*prm.invFormantMultiplier;
+		float inputE = metric[b];
+		float band = outputF*Nf - 0.5f;
+		float targetE = 0;
+		if (!(band < 0)) {
+			band = fminf(band, float(M));
+			int fl = (int)floorf(band);
+			float fr = band - fl;
+			float low = metric[fl], high = metric[fl + 1];
+			targetE = low + (high - low)*fr;
+		}
+		ratio[b] = targetE/(inputE + 1e-30f);
+	}
+}
+
+// ------------------------------------------------------------------------------------------------------
+// K2a+K2f: per-(hop, channel, bin) prediction coefficients -- everything the bin recurrence needs that does
+// not depend on previous outputs (signalsmith-stretch.h:642-660 rotation, :697-719 preliminary prediction,
+// :748-785 vertical twists):
+//   P  = lerp(input, map.inputBin)                      (Prediction.input)
+//   E  = lerp(inputEnergy, map.inputBin)*max(0, grad)   (Prediction.energy)
+//   TW = rot[b] * P * conj(lerp(rot*prevInput, map.inputBin))      (output twist of the preliminary prediction)
+//   S  = P * conj(lerp(input, map.inputBin - tf)),  T = P * conj(lerp(input, map.inputBin - L*tf))
+// ------------------------------------------------------------------------------------------------------
+struct LerpIndex {
+	int lo;
+	float fr;
+};
+__device__ __forceinline__ LerpIndex lerpIndex(float x) { // :559-562
+	LerpIndex r;
+	float fl = floorf(x);
+	r.lo = (int)fl;
+	r.fr = x - fl;
+	return r;
+}
+__device__ __forceinline__ float2 bandAt(const float2 *row, int idx, int M) { // getBand, :548-551
+	return (idx < 0 || idx >= M) ? make_float2(0.f, 0.f) : row[idx];
+}
+__device__ __forceinline__ float2 lerpBand(const float2 *row, LerpIndex li, int M) { // getFractional, :553-557
+	float2 low = bandAt(row, li.lo, M), high = bandAt(row, li.lo + 1, M);
+	return make_float2(low.x + (high.x - low.x)*li.fr, low.y + (high.y - low.y)*li.fr);
+}
+
+__global__ __launch_bounds__(256) void kPredict(DevBatch d, int sBase, int hopBase) {
+	const int b = blockIdx.x*blockDim.x + threadIdx.x;
+	const int k = blockIdx.y, s = blockIdx.z, sg = sBase + s;
+	const HopDesc hd = d.hops[(size_t)sg*d.hopStride + hopBase + k];
+	if (!(hd.flags & HOP_ACTIVE) || b >= d.M) return;
+	const int M = d.M, L = d.L;
+	const bool rotate = hd.flags & HOP_NEW_SPECTRUM;
+	const bool mapped = hd.flags & HOP_MAPPED, formants = hd.flags & HOP_FORMANTS, randomTf = hd.flags & HOP_RANDOM_TF;
+
+	float2 mp = mapped ? d.map[((size_t)s*d.T + k)*M + b] : make_float2(float(b), 1.0f);
+	const LerpIndex li = lerpIndex(mp.x);
+	const float gradScale = fmaxf(0.0f, mp.y);
+	const float *ratio = formants ? d.ratio + ((size_t)s*d.T + k)*M : nullptr;
+
+	float tfUp = hd.timeFactor, tfDnS = hd.timeFactor, tfDnL = hd.timeFactor;
+	if (randomTf) { // uniform(4 - tf, tf), one draw per bin and direction (:640,:749,:769)
+		const float lo = 4.0f - hd.timeFactor, span = hd.timeFactor - lo;
+		tfUp = lo + span*hashUniform(hd.seed, b, 0);
+		tfDnS = lo + span*hashUniform(hd.seed, b - 1, 1);  // the draw made while the reference processed bin b-1
+		tfDnL = lo + span*hashUniform(hd.seed, b - L, 1);  // ... and bin b-L
+	}
+	const float2 rotB = rotate ? d.rot[b] : make_float2(1.f, 0.f);
+	const bool loIn = li.lo >= 0 && li.lo < M, hiIn = li.lo + 1 >= 0 && li.lo + 1 < M;
+	const float2 rotLo = (rotate && loIn) ? d.rot[li.lo] : make_float2(1.f, 0.f);
+	const float2 rotHi = (rotate && hiIn) ? d.rot[li.lo + 1] : make_float2(1.f, 0.f);
+
+	for (int c = 0; c < d.C; ++c) {
+		const float2 *in = inputRow(d, hd, s, sg, c);
+		const float2 *pv = prevRow(d, hd, s, k, sg, c);
+		const size_t o = rowOf(d, s, k, c) + b;
+
+		float2 inLo = bandAt(in, li.lo, M), inHi = bandAt(in, li.lo + 1, M);
+		float eLo = cnorm(inLo), eHi = cnorm(inHi);
+		if (formants) {
+			if (loIn) eLo *= ratio[li.lo];
+			if (hiIn) eHi *= ratio[li.lo + 1];
+		}
+		float E = (eLo + (eHi - eLo)*li.fr)*gradScale;
+		float2 P = make_float2(inLo.x + (inHi.x - inLo.x)*li.fr, inLo.y + (inHi.y - inLo.y)*li.fr);
+		float2 pvLo = cmul(bandAt(pv, li.lo, M), rotLo), pvHi = cmul(bandAt(pv, li.lo + 1, M), rotHi);
+		float2 Q = make_float2(pvLo.x + (pvHi.x - pvLo.x)*li.fr, pvLo.y + (pvHi.y - pvLo.y)*li.fr);
+
+		d.P[o] = P;
+		d.E[o] = E;
+		d.TW[o] = cmul(rotB, cmulc(P, Q));
+		d.Sx[o] = cmulc(P, lerpBand(in, lerpIndex(mp.x - tfUp), M));
+		d.Tx[o] = cmulc(P, lerpBand(in, lerpIndex(mp.x - L*tfUp), M));
+		if (randomTf) {
+			d.Sdn[o] = cmulc(P, lerpBand(in, lerpIndex(mp.x - tfDnS), M));
+			d.Tdn[o] = cmulc(P, lerpBand(in, lerpIndex(mp.x - L*tfDnL), M));
+		}
+	}
+}
+
+// ------------------------------------------------------------------------------------------------------
+// K3: the bin recurrence (main prediction + channel locking, signalsmith-stretch.h:722-803) as a skewed
+// wavefront.  One wave per stream; lane k = hop k of the tile; at step t lane k finalises bin t - lag*k.
+// Hop k at bin b needs hop k's own outputs at b-1 and b-L, and hop k-1's FINAL outputs at b+1 and b+L
+// (they enter through the preliminary prediction of hop k); lag >= L+1 guarantees they exist.  Outputs of the
+// last `ringSlots` bins of every lane live in an LDS ring that the next lane reads; lane 0 reads the carried
+// Band.output state, staged through LDS 64 bins at a time with one coalesced load per channel.
+// ------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float2 makeOutput(float2 phase, float2 input, float energy) { // :596-603
+	float n = cnorm(phase);
+	if (n <= 1e-15f) {
+		phase = input;
+		n = cnorm(input) + 1e-15f;
+	}
+	float g = sqrtf(energy)*__builtin_amdgcn_rsqf(n);
+	return cscale(phase, g);
+}
+
+template <int CH>
+__global__ __launch_bounds__(64) void kChain(DevBatch d, int sBase, int hopBase) {
+	extern __shared__ __attribute__((aligned(16))) unsigned char smemRaw[];
+	const int R = d.ringSlots, Rm = R - 1;
+	float2 *ring = reinterpret_cast<float2 *>(smemRaw);   // [CH][R][64]
+	float2 *stage = ring + (size_t)CH*R*64;                // [CH][128]: carried Band.output of the previous tile
+
+	const int s = blockIdx.x, sg = sBase + s, k = threadIdx.x;
+	const int nh = d.nHops[s];
+	if (nh == 0) return;
+	const int M = d.M, L = d.L, lag = d.lag;
+	const bool active = k < nh;
+	const bool isLast = (k == nh - 1);
+	const HopDesc hd = d.hops[(size_t)sg*d.hopStride + hopBase + (active ? k : 0)];
+	const bool randomTf = hd.flags & HOP_RANDOM_TF;
+
+	const size_t row0 = rowOf(d, s, active ? k : 0, 0);
+	const float2 *P = d.P + row0, *Sx = d.Sx + row0, *Tx = d.Tx + row0, *TW = d.TW + row0;
+	const float2 *Sdn = (randomTf ? d.Sdn : d.Sx) + row0, *Tdn = (randomTf ? d.Tdn : d.Tx) + row0;
+	const float *E = d.E + row0;
+	const float *Eprev = (k == 0) ? d.stEnergy + stateRow(d, sg, 0) : d.E + rowOf(d, s, (active ? k : 1) - 1, 0);
+	float2 *OUT = d.OUT + row0;
+	float2 *stOut = d.stOut + stateRow(d, sg, 0);
+
+	// prologue: stage bins [0,128) of the carried output
+	for (int c = 0; c < CH; ++c) {
+		stage[c*128 + k] = (k < M) ? stOut[(size_t)c*M + k] : make_float2(0.f, 0.f);
+		stage[c*128 + 64 + k] = (64 + k < M) ? stOut[(size_t)c*M + 64 + k] : make_float2(0.f, 0.f);
+	}
+	float2 pf[CH];
+#pragma unroll
+	for (int c = 0; c < CH; ++c) pf[c] = make_float2(0.f, 0.f);
+	float2 own1[CH]; // this lane's outputs at bin b-1
+#pragma unroll
+	for (int c = 0; c < CH; ++c) own1[c] = make_float2(0.f, 0.f);
+	__syncthreads();
+
+	const int steps = M + lag*(nh - 1);
+	for (int t = 0; t < steps; ++t) {
+		if ((t & 63) == 0) {
+			// bins [t+64, t+128) were fetched 64 steps ago: publish them, then fetch [t+128, t+192)
+			if (t > 0) {
+#pragma unroll
+				for (int c = 0; c < CH; ++c) stage[c*128 + ((t + 64 + k) & 127)] = pf[c];
+			}
+			const int bb = t + 128 + k;
+#pragma unroll
+			for (int c = 0; c < CH; ++c) pf[c] = (bb < M) ? stOut[(size_t)c*M + bb] : make_float2(0.f, 0.f);
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+			__builtin_amdgcn_wave_barrier();
+			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+		}
+		const int b = t - lag*k;
+		if (active && b >= 0 && b < M) {
+			float e[CH];
+			float2 p[CH];
+#pragma unroll
+			for (int c = 0; c < CH; ++c) {
+				e[c] = E[(size_t)c*M + b];
+				p[c] = P[(size_t)c*M + b];
+			}
+			int mc = 0; // maximum-energy channel, first maximum wins (:729-737)
+			float eMax = e[0];
+#pragma unroll
+			for (int c = 1; c < CH; ++c) {
+				if (e[c] > eMax) { mc = c; eMax = e[c]; }
+			}
+			const size_t mo = (size_t)mc*M;
+			float2 pm = p[0], o1 = own1[0];
+#pragma unroll
+			for (int c = 1; c < CH; ++c) {
+				if (c == mc) { pm = p[c]; o1 = own1[c]; }
+			}
+			float2 phi = make_float2(0.f, 0.f);
+			if (b > 0) phi = cmul(o1, Sx[mo + b]); // :748-754
+			if (b >= L) { // :756-762
+				float2 oL = ring[((size_t)mc*R + ((b - L) & Rm))*64 + k];
+				phi = cadd(phi, cmul(oL, Tx[mo + b]));
+			}
+			if (b < M - 1) { // :765-774: bin b+1 still holds this hop's preliminary prediction
+				const int b1 = b + 1;
+				float2 po = (k == 0) ? stage[mc*128 + (b1 & 127)] : ring[((size_t)mc*R + (b1 & Rm))*64 + k - 1];
+				float den = fmaxf(Eprev[mo + b1], E[mo + b1]) + 1e-15f; // :716
+				float2 pre = cscale(cmul(po, TW[mo + b1]), __builtin_amdgcn_rcpf(den));
+				phi = cadd(phi, cmulc(pre, Sdn[mo + b1]));
+			}
+			if (b < M - L) { // :776-785
+				const int bL = b + L;
+				float2 po = (k == 0) ? stage[mc*128 + (bL & 127)] : ring[((size_t)mc*R + (bL & Rm))*64 + k - 1];
+				float den = fmaxf(Eprev[mo + bL], E[mo + bL]) + 1e-15f;
+				float2 pre = cscale(cmul(po, TW[mo + bL]), __builtin_amdgcn_rcpf(den));
+				phi = cadd(phi, cmulc(pre, Tdn[mo + bL]));
+			}
+			const float2 om = makeOutput(phi, pm, eMax); // :788
+#pragma unroll
+			for (int c = 0; c < CH; ++c) {
+				float2 oc;
+				if (c == mc) {
+					oc = om;
+				} else { // all other channels are locked in phase to the maximum channel, :791-800
+					float2 tw = cmulc(p[c], pm);
+					oc = makeOutput(cmul(om, tw), p[c], e[c]);
+				}
+				own1[c] = oc;
+				ring[((size_t)c*R + (b & Rm))*64 + k] = oc;
+				OUT[(size_t)c*M + b] = oc;
+				if (isLast) stOut[(size_t)c*M + b] = oc;
+			}
+		}
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+	}
+}
+
+// ------------------------------------------------------------------------------------------------------
+// K4a: synthesis.  One workgroup per (hop, channel, stream): inverse half-bin-shifted real FFT (gain N),
+// multiply by the synthesis window, store the B-sample frame.  Replaces the copy at
+// signalsmith-stretch.h:384-394 + stft.synthesiseStep (:397-399).
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void kSynth(DevBatch d, int sBase, int hopBase) {
+	extern __shared__ __attribute__((aligned(16))) unsigned char smemRaw[];
+	float2 *bufA = reinterpret_cast<float2 *>(smemRaw);
+	float2 *bufB = bufA + d.M;
+	const int k = blockIdx.x, c = blockIdx.y, s = blockIdx.z;
+	const HopDesc hd = d.hops[(size_t)(sBase + s)*d.hopStride + hopBase + k];
+	if (!(hd.flags & HOP_ACTIVE)) return;
+	const int B = d.B, H = d.M, N = d.N, halfB = B/2;
+	const float2 *X = d.OUT + rowOf(d, s, k, c);
+	for (int j = threadIdx.x; j < H; j += blockDim.x) {
+		int kk = 2*j;
+		bufA[j] = (kk < H) ? X[kk] : cconj(X[N - 1 - kk]);
+	}
+	__syncthreads();
+	float2 *res = fftLds<+1>(bufA, bufB, d.plan, d.twH);
+	float *frame = d.frames + ((size_t)((size_t)s*d.T + k)*d.C + c)*(size_t)B;
+	const float *__restrict__ win = d.window;
+	for (int m = threadIdx.x; m < H; m += blockDim.x) {
+		float2 v = cmulc(res[m], d.halfTw[m]); // * e^{+i pi m / N}
+		if (m < B - halfB) {
+			int i = m + halfB;
+			frame[i] = (2*v.x)*win[i];
+		}
+		if (m >= H - halfB) {
+			int i = m - H + halfB;
+			frame[i] = (2*v.y)*win[i];
+		}
+	}
+}
+
+// ------------------------------------------------------------------------------------------------------
+// K4b: overlap-add as a gather + window-product normalisation + emission (stft.readOutput/moveOutput at
+// signalsmith-stretch.h:406-415), and the new carry (the part of the ring that outlives the tile).
+// Sums are formed oldest-frame-first, as the reference's ring accumulates them.
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void kEmit(DevBatch d, IoArgs io, int sBase, int tileIndex) {
+	const int s = blockIdx.z, sg = sBase + s, c = blockIdx.y;
+	const EmitDesc ed = d.emit[(size_t)sg*d.emitStride + tileIndex];
+	const int span = ed.nHi - ed.nLo;
+	const int i = blockIdx.x*blockDim.x + threadIdx.x;
+	const int CL = d.carryLen;
+	if (i >= span + CL) return;
+	const int B = d.B, I = d.I;
+	const int n = ed.nLo + i;
+	const size_t carryRow = ((size_t)sg*d.C + c)*(size_t)CL;
+	const float *carrySumOld = d.carrySum[d.carryCur] + carryRow;
+	const float *carryWpOld = d.carryWp[d.carryCur] + (size_t)sg*CL;
+	float sum = (i < CL) ? carrySumOld[i] : 0.0f;
+	float wp = (i < CL) ? carryWpOld[i] : 1e-30f;
+	if (ed.hopCount > 0) {
+		// frames q with pos_q <= n < pos_q + B, pos_q = firstHopPos + q*I + delta
+		const int rel = n - ed.firstHopPos - d.delta;
+		int qHi = (rel >= 0) ? rel/I : -1;
+		int qLo = (rel - B + 1 > 0) ? (rel - B + 1 + I - 1)/I : 0;
+		if (qHi > ed.hopCount - 1) qHi = ed.hopCount - 1;
+		for (int q = qLo; q <= qHi; ++q) {
+			const int idx = rel - q*I;
+			sum += d.frames[((size_t)((size_t)s*d.T + q)*d.C + c)*(size_t)B + idx];
+			wp += d.wprod[idx];
+		}
+	}
+	if (i < span) {
+		float *out = io.out + (size_t)sg*io.outStreamStride + (size_t)c*io.outChannelStride;
+		out[n] = sum/wp;
+	} else {
+		const int j = i - span;
+		d.carrySum[d.carryCur ^ 1][carryRow + j] = sum;
+		if (c == 0) d.carryWp[d.carryCur ^ 1][(size_t)sg*CL + j] = wp;
+	}
+}
+
+// ------------------------------------------------------------------------------------------------------
+// State that outlives a tile: Band.input / Band.prevInput (= input of the last hop that analysed a new
+// spectrum, signalsmith-stretch.h:806-811), Prediction.energy of the last hop (:707), pitch-estimate state.
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void kCarryState(DevBatch d, int sBase, int hopBase) {
+	const int s = blockIdx.z, sg = sBase + s, c = blockIdx.y;
+	const int b = blockIdx.x*blockDim.x + threadIdx.x;
+	const int nh = d.nHops[s];
+	if (nh == 0 || b >= d.M) return;
+	const int lastNew = d.lastNewHop[s];
+	if (lastNew >= 0) {
+		float2 v = d.Xcur[rowOf(d, s, lastNew, c) + b];
+		d.stInput[stateRow(d, sg, c) + b] = v;
+		d.stPrev[stateRow(d, sg, c) + b] = v;
+	}
+	d.stEnergy[stateRow(d, sg, c) + b] = d.E[rowOf(d, s, nh - 1, c) + b];
+	if (b == 0 && c == 0) {
+		float w = d.stFreq[2*sg], wt = d.stFreq[2*sg + 1];
+		bool any = false;
+		for (int j = 0; j < nh; ++j) {
+			const HopDesc hj = d.hops[(size_t)sg*d.hopStride + hopBase + j];
+			if (!(hj.flags & HOP_FORMANTS) || d.params[sg].formantBaseFreq > 0) continue;
+			w += (d.est[((size_t)s*d.T + j)*2] - w)*0.25f;
+			wt += (d.est[((size_t)s*d.T + j)*2 + 1] - wt)*0.25f;
+			any = true;
+		}
+		if (any) { d.stFreq[2*sg] = w; d.stFreq[2*sg + 1] = wt; }
+	}
+}
+
+// Input history for the next call: the last B+I samples of (history ++ this call's input)  (copyInput, :215-229,:418)
+__global__ __launch_bounds__(256) void kHistory(DevBatch d, IoArgs io) {
+	const int sg = blockIdx.z, c = blockIdx.y;
+	const int j = blockIdx.x*blockDim.x + threadIdx.x;
+	const int HL = d.histLen;
+	if (j >= HL) return;
+	const int n = io.inSamples[sg];
+	const size_t row = ((size_t)sg*d.C + c)*(size_t)HL;
+	const int rel = n - HL + j;
+	float v;
+	if (rel >= 0) v = io.in[(size_t)sg*io.inStreamStride + (size_t)c*io.inChannelStride + rel];
+	else v = d.hist[d.histCur][row + HL + rel];
+	d.hist[d.histCur ^ 1][row + j] = v;
+}
+
+// Silence pass-through (signalsmith-stretch.h:252-267): outputs[c][i] = inputs[c][i % inputSamples] (or 0)
+__global__ __launch_bounds__(256) void kPassThrough(DevBatch d, IoArgs io, const int *__restrict__ passFlags) {
+	const int sg = blockIdx.z, c = blockIdx.y;
+	if (!passFlags[sg]) return;
+	const int nOut = io.outSamples[sg], nIn = io.inSamples[sg];
+	const float *x = io.in + (size_t)sg*io.inStreamStride + (size_t)c*io.inChannelStride;
+	float *y = io.out + (size_t)sg*io.outStreamStride + (size_t)c*io.outChannelStride;
+	for (int i = blockIdx.x*blockDim.x + threadIdx.x; i < nOut; i += gridDim.x*blockDim.x) {
+		y[i] = (nIn > 0) ? x[i%nIn] : 0.0f;
+	}
+}
+
+// seek(): history = the last B+I samples of the (zero-padded) pre-roll  (signalsmith-stretch.h:140-158)
+__global__ __launch_bounds__(256) void kSeekHistory(DevBatch d, IoArgs io, const int *__restrict__ seekFlags) {
+	const int sg = blockIdx.z, c = blockIdx.y;
+	const int j = blockIdx.x*blockDim.x + threadIdx.x;
+	const int HL = d.histLen;
+	if (j >= HL) return;
+	const size_t row = ((size_t)sg*d.C + c)*(size_t)HL;
+	float v;
+	if (seekFlags[sg]) {
+		const int n = io.inSamples[sg];
+		const int rel = n - HL + j;
+		v = (rel >= 0) ? io.in[(size_t)sg*io.inStreamStride + (size_t)c*io.inChannelStride + rel] : 0.0f;
+	} else {
+		v = d.hist[d.histCur][row + j];
+	}
+	d.hist[d.histCur ^ 1][row + j] = v;
+}
+
+// flush() tail (signalsmith-stretch.h:442-455): finishOutput(1) = running maximum of the window products from the
+// read position, then out[i] = ring[i]/wp[i] - ring[2*tail-1-i]/wp[2*tail-1-i] for i < tail.  One thread per
+// (stream): the running maximum is a serial scan over at most B entries.
+__global__ __launch_bounds__(64) void kFlushTail(DevBatch d, IoArgs io, const int *__restrict__ tailOffset, const int *__restrict__ outOffset) {
+	const int sg = blockIdx.x;
+	const int tail = io.outSamples[sg];
+	if (tail < 0) return; // stream not part of this flush
+	const int off = tailOffset[sg]; // where the L1 read position sits relative to our carry (split mode: I - samplesSinceLast)
+	const int CL = d.carryLen, B = d.B;
+	float *wpRow = d.carryWp[d.carryCur] + (size_t)sg*CL;
+	if (threadIdx.x == 0) {
+		float mx = 0;
+		for (int i = 0; i < B; ++i) {
+			int idx = off + i;
+			float wp = (idx < CL) ? wpRow[idx] : 1e-30f;
+			mx = fmaxf(wp, mx);
+			if (idx < CL) wpRow[idx] = wp + (mx - wp)*1.0f;
+		}
+	}
+	__syncthreads();
+	for (int c = 0; c < d.C; ++c) {
+		const float *sumRow = d.carrySum[d.carryCur] + ((size_t)sg*d.C + c)*(size_t)CL;
+		float *y = io.out + (size_t)sg*io.outStreamStride + (size_t)c*io.outChannelStride + outOffset[sg];
+		for (int i = threadIdx.x; i < tail; i += blockDim.x) {
+			int a = off + i, r = off + 2*tail - 1 - i;
+			float va = (a < CL) ? sumRow[a]/wpRow[a] : 0.0f;
+			float vr = (r < CL) ? sumRow[r]/wpRow[r] : 0.0f;
+			y[i] = va - vr;
+		}
+	}
+}
+
+// outputSeek() pre-roll fold-back (signalsmith-stretch.h:198-203): negate, reverse, stft.addOutput
+__global__ __launch_bounds__(256) void kAddPreRoll(DevBatch d, const float *__restrict__ preRoll, int length, const int *__restrict__ offsets) {
+	const int sg = blockIdx.z, c = blockIdx.y;
+	const int i = blockIdx.x*blockDim.x + threadIdx.x;
+	if (i >= length) return;
+	const int CL = d.carryLen;
+	const int idx = offsets[sg] + i;
+	if (idx >= CL) return;
+	const float v = -preRoll[((size_t)sg*d.C + c)*(size_t)length + (length - 1 - i)];
+	d.carrySum[d.carryCur][((size_t)sg*d.C + c)*(size_t)CL + idx] += v*d.carryWp[d.carryCur][(size_t)sg*CL + idx];
+}
+
+// ------------------------------------------------------------------------------------------------------
+// host-side launchers
+// ------------------------------------------------------------------------------------------------------
+static inline int divUp(int a, int b) { return (a + b - 1)/b; }
+
+void launchEnergy(const DevBatch &d, const IoArgs &io, int sBase, int nStreams, float *energyOut, hipStream_t st) {
+	hipLaunchKernelGGL(kEnergy, dim3(nStreams), dim3(256), 256*sizeof(float), st, d, io, sBase, energyOut);
+}
+void launchAnalyse(const DevBatch &d, const IoArgs &io, int sBase, int nStreams, int hopBase, int tileHops, hipStream_t st) {
+	size_t lds = 2*(size_t)d.M*sizeof(float2);
+	hipLaunchKernelGGL(kAnalyse, dim3(tileHops, d.C*2, nStreams), dim3(256), lds, st, d, io, sBase, hopBase);
+}
+void launchFeedMap(const DevBatch &d, int sBase, int nStreams, int hopBase, int tileHops, hipStream_t st) {
+	size_t lds = 2*(size_t)d.M*sizeof(float) + ((size_t)d.M/2 + 2)*sizeof(float2) + 16;
+	hipLaunchKernelGGL(kFeedMap, dim3(tileHops, nStreams), dim3(64), lds, st, d, sBase, hopBase);
+}
+void launchFeedFormant(const DevBatch &d, int sBase, int nStreams, int hopBase, int tileHops, hipStream_t st) {
+	size_t lds = ((size_t)d.M + 2)*sizeof(float);
+	hipLaunchKernelGGL(kFeedFormant, dim3(tileHops, nStreams), dim3(64), lds, st, d, sBase, hopBase);
+}
+void launchPredict(const DevBatch &d, int sBase, int nStreams, int hopBase, int tileHops, hipStream_t st) {
+	hipLaunchKernelGGL(kPredict, dim3(divUp(d.M, 256), tileHops, nStreams), dim3(256), 0, st, d, sBase, hopBase);
+}
+template <int CH>
+static void launchChainT(const DevBatch &d, int sBase, int nStreams, int hopBase, hipStream_t st) {
+	size_t lds = ((size_t)CH*d.ringSlots*64 + (size_t)CH*128)*sizeof(float2);
+	hipLaunchKernelGGL(kChain<CH>, dim3(nStreams), dim3(64), lds, st, d, sBase, hopBase);
+}
+void launchChain(const DevBatch &d, int sBase, int nStreams, int hopBase, hipStream_t st) {
+	switch (d.C) {
+	case 1: launchChainT<1>(d, sBase, nStreams, hopBase, st); break;
+	case 2: launchChainT<2>(d, sBase, nStreams, hopBase, st); break;
+	case 3: launchChainT<3>(d, sBase, nStreams, hopBase, st); break;
+	case 4: launchChainT<4>(d, sBase, nStreams, hopBase, st); break;
+	case 5: launchChainT<5>(d, sBase, nStreams, hopBase, st); break;
+	case 6: launchChainT<6>(d, sBase, nStreams, hopBase, st); break;
+	case 7: launchChainT<7>(d, sBase, nStreams, hopBase, st); break;
+	default: launchChainT<8>(d, sBase, nStreams, hopBase, st); break;
+	}
+}
+void launchSynth(const DevBatch &d, int sBase, int nStreams, int hopBase, int tileHops, hipStream_t st) {
+	size_t lds = 2*(size_t)d.M*sizeof(float2);
+	hipLaunchKernelGGL(kSynth, dim3(tileHops, d.C, nStreams), dim3(256), lds, st, d, sBase, hopBase);
+}
+void launchEmit(const DevBatch &d, const IoArgs &io, int sBase, int nStreams, int tileIndex, int maxSpan, hipStream_t st) {
+	hipLaunchKernelGGL(kEmit, dim3(divUp(maxSpan + d.carryLen, 256), d.C, nStreams), dim3(256), 0, st, d, io, sBase, tileIndex);
+}
+void launchCarryState(const DevBatch &d, int sBase, int nStreams, int hopBase, hipStream_t st) {
+	hipLaunchKernelGGL(kCarryState, dim3(divUp(d.M, 256), d.C, nStreams), dim3(256), 0, st, d, sBase, hopBase);
+}
+void launchHistory(const DevBatch &d, const IoArgs &io, hipStream_t st) {
+	hipLaunchKernelGGL(kHistory, dim3(divUp(d.histLen, 256), d.C, d.S), dim3(256), 0, st, d, io);
+}
+void launchPassThrough(const DevBatch &d, const IoArgs &io, const int *passFlags, int maxOut, hipStream_t st) {
+	int bx = divUp(maxOut, 256);
+	if (bx > 64) bx = 64;
+	if (bx < 1) bx = 1;
+	hipLaunchKernelGGL(kPassThrough, dim3(bx, d.C, d.S), dim3(256), 0, st, d, io, passFlags);
+}
+void launchSeekHistory(const DevBatch &d, const IoArgs &io, const int *seekFlags, hipStream_t st) {
+	hipLaunchKernelGGL(kSeekHistory, dim3(divUp(d.histLen, 256), d.C, d.S), dim3(256), 0, st, d, io, seekFlags);
+}
+void launchFlushTail(const DevBatch &d, const IoArgs &io, const int *tailOffset, const int *outOffset, hipStream_t st) {
+	hipLaunchKernelGGL(kFlushTail, dim3(d.S), dim3(64), 0, st, d, io, tailOffset, outOffset);
+}
+
+void launchAddPreRoll(const DevBatch &d, const float *preRoll, int length, const int *offsets, hipStream_t st) {
+	hipLaunchKernelGGL(kAddPreRoll, dim3(divUp(length, 256), d.C, d.S), dim3(256), 0, st, d, preRoll, length, offsets);
+}
+
+} // namespace smst

@@ -1,0 +1,63 @@
+// Shared host/device plain-data types for the gfx950 stretch engine.
+#pragma once
+#include <cstdint>
+
+namespace smst {
+
+constexpr int kTileHops = 64;   // hops per tile = lanes of the wave that runs the bin recurrence
+constexpr int kMaxChannels = 8; // compile-time bound of the chain kernel's per-lane channel arrays
+constexpr int kMaxFftPasses = 12;
+
+// Hop flags (reference: signalsmith-stretch.h:299-313)
+enum : unsigned {
+	HOP_ACTIVE = 1u,
+	HOP_NEW_SPECTRUM = 2u,   // :299
+	HOP_REANALYSE_PREV = 4u, // :303
+	HOP_MAPPED = 8u,         // :300
+	HOP_FORMANTS = 16u,      // :310
+	HOP_RANDOM_TF = 32u,     // :639
+};
+
+// Source codes for the per-hop spectra (which row holds Band.input / Band.prevInput for this hop)
+constexpr int SRC_STATE = -1;      // carried state row (st_input resp. st_prev)
+constexpr int SRC_REANALYSED = -2; // this hop's own re-analysed previous window (Xprev row k)
+
+// One hop of one stream inside a tile.  Filled by the host scheduler (K0), read by every kernel.
+struct HopDesc {
+	int inputOffset;  // window end of the current analysis, relative to the call's first input sample (:288)
+	int inSrc;        // >=0: Xcur row of that tile-local hop; SRC_STATE
+	int prevSrc;      // >=0: Xcur row; SRC_STATE; SRC_REANALYSED
+	unsigned flags;
+	float timeFactor; // already clamped to >= 1/maxCleanStretch (:638)
+	int outPos;       // output index (within the call) at which this hop fires (:280-285)
+	unsigned seed;    // counter-based RNG stream for timeFactor > 2 (:639-640)
+	int pad;
+};
+
+// Per-stream emission window of a tile (K4 overlap-add gather)
+struct EmitDesc {
+	int nLo, nHi;     // output samples [nLo, nHi) of the call are final after this tile
+	int firstHopPos;  // outPos of the tile's first hop
+	int hopCount;     // hops of this stream in this tile
+};
+
+// Per-stream parameters (reference: signalsmith-stretch.h:107-135, 513-517)
+struct StreamParams {
+	float freqMultiplier;     // :108
+	float freqTonalityLimit;  // :110-113
+	float formantMultiplier;  // :125
+	float invFormantMultiplier;
+	float formantBaseFreq;    // :134
+	int formantCompensation;  // :127
+	int hasCustomMap;         // :120 (table form)
+	int pad;
+};
+
+struct FftPlan {
+	int H;      // complex FFT length = fftSamples/2 = bands
+	int N;      // fftSamples
+	int npass;
+	int radix[kMaxFftPasses];
+};
+
+} // namespace smst

@@ -1,0 +1,80 @@
+import ctypes
+import importlib
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "oracle")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run by the driver with -m gpu)")
+
+
+def package():
+    return importlib.import_module("signalsmith-stretch_amd")
+
+
+def rel_rms(a, b):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    return float(np.sqrt(np.mean((a - b)**2)/max(np.mean(b**2), 1e-30)))
+
+
+def synth_input(stream, channels, n, sr):
+    """Synthetic inputs of SURVEY.md section 8(d): stream type = s mod 3 (sine / chirp / noise)."""
+    t = np.arange(n)/sr
+    kind = stream % 3
+    out = np.zeros((channels, n), np.float32)
+    for c in range(channels):
+        if kind == 0:
+            f1 = 110*2**((stream % 37)/12)
+            out[c] = 0.4*np.sin(2*np.pi*f1*t + 0.5*c) + 0.2*np.sin(2*np.pi*3.17*f1*t)
+        elif kind == 1:
+            k = (0.4*sr - 50)/max(n/sr, 1e-9)
+            out[c] = 0.5*np.sin(2*np.pi*(50*t + 0.5*k*t*t) + 0.5*c)
+        else:
+            g = np.random.Generator(np.random.PCG64(1_000_003*stream + c))
+            out[c] = g.uniform(-0.3, 0.3, n)
+    return out
+
+
+@pytest.fixture(scope="session")
+def ref():
+    """The checker: oracle/_ref = unmodified reference header + L1 restatement (prebuilt .so travels to the GPU box)."""
+    import ref_oracle
+    if not ref_oracle.available():
+        if os.path.exists("/root/reference/signalsmith-stretch.h"):
+            subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "ref"], check=True, capture_output=True)
+        if not ref_oracle.available():
+            pytest.skip("oracle/_ref/libsmst_ref.so not built (needs /root/reference at build time)")
+    return ref_oracle
+
+
+@pytest.fixture(scope="session")
+def emu():
+    """Product sources compiled against the CPU stand-in for the HIP runtime (tests/emu) -- host-logic checks only."""
+    pkg = package()
+    so = os.path.join(ROOT, "tests", "emu", "libsmst_emu.so")
+    srcs = [os.path.join(pkg.CSRC_DIR, f) for f in os.listdir(pkg.CSRC_DIR)] + [
+        os.path.join(ROOT, "tests", "emu", "hip_emu.cpp"), os.path.join(ROOT, "tests", "emu", "hip", "hip_runtime.h"),
+        os.path.join(ROOT, "include", "smst.h")]
+    if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+        subprocess.run([os.path.join(ROOT, "tests", "emu", "build_emu.sh")], check=True, capture_output=True)
+    return pkg.bind(ctypes.CDLL(so))
+
+
+@pytest.fixture(scope="session")
+def hip():
+    """The product library on a real GPU.  Fails (not skips) if the extension is missing on a GPU box."""
+    pkg = package()
+    lib = pkg.load_library()
+    if lib.smst_device_count() < 1:
+        pytest.fail("libsmst_hip.so loaded but no HIP device is visible")
+    return lib

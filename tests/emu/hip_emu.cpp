@@ -1,0 +1,67 @@
+// TEST INFRASTRUCTURE ONLY -- see tests/emu/hip/hip_runtime.h.
+// Runs each workgroup's threads as ucontext fibers, round-robin between barriers.
+#include <hip/hip_runtime.h>
+#include <ucontext.h>
+#include <vector>
+#include <stdexcept>
+
+EmuIdx threadIdx, blockIdx, blockDim, gridDim;
+namespace smst { alignas(16) unsigned char smemRaw[160*1024]; }
+
+namespace {
+struct Fiber {
+	ucontext_t ctx;
+	std::vector<unsigned char> stack;
+	bool done = false;
+	EmuIdx tid;
+};
+ucontext_t schedulerCtx;
+Fiber *current = nullptr;
+const std::function<void()> *currentBody = nullptr;
+
+void fiberEntry() {
+	(*currentBody)();
+	current->done = true;
+	swapcontext(&current->ctx, &schedulerCtx);
+}
+}
+
+void emuSyncThreads() {
+	swapcontext(&current->ctx, &schedulerCtx);
+}
+
+void emuLaunch(dim3 grid, dim3 block, size_t ldsBytes, const std::function<void()> &body) {
+	if (ldsBytes > sizeof(smst::smemRaw)) throw std::runtime_error("emu: LDS request too large");
+	const unsigned nThreads = block.x*block.y*block.z;
+	static std::vector<Fiber> fibers;
+	if (fibers.size() < nThreads) fibers.resize(nThreads);
+	for (unsigned i = 0; i < nThreads; ++i) if (fibers[i].stack.empty()) fibers[i].stack.resize(256*1024);
+	currentBody = &body;
+	gridDim = {grid.x, grid.y, grid.z};
+	blockDim = {block.x, block.y, block.z};
+	for (unsigned bz = 0; bz < grid.z; ++bz) for (unsigned by = 0; by < grid.y; ++by) for (unsigned bx = 0; bx < grid.x; ++bx) {
+		for (unsigned i = 0; i < nThreads; ++i) {
+			Fiber &f = fibers[i];
+			f.done = false;
+			f.tid = {i%block.x, (i/block.x)%block.y, i/(block.x*block.y)};
+			getcontext(&f.ctx);
+			f.ctx.uc_stack.ss_sp = f.stack.data();
+			f.ctx.uc_stack.ss_size = f.stack.size();
+			f.ctx.uc_link = &schedulerCtx;
+			makecontext(&f.ctx, fiberEntry, 0);
+		}
+		bool anyAlive = true;
+		while (anyAlive) {
+			anyAlive = false;
+			for (unsigned i = 0; i < nThreads; ++i) {
+				Fiber &f = fibers[i];
+				if (f.done) continue;
+				current = &f;
+				threadIdx = f.tid;
+				blockIdx = {bx, by, bz};
+				swapcontext(&schedulerCtx, &f.ctx);
+				if (!f.done) anyAlive = true;
+			}
+		}
+	}
+}

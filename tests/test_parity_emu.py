@@ -1,0 +1,40 @@
+"""Host logic + kernel index logic on the CPU stand-in for the HIP runtime (tests/emu) against the checker.
+This is NOT the product path (that is test_parity_gpu.py on a real gfx950); it runs in the GPU-less container."""
+import pytest
+
+import parity_cases as pc
+import scenarios
+
+
+@pytest.mark.parametrize("name", ["identity_mono_44k", "stretch_1p5_stereo", "pitch_p12_stereo", "cheaper_96k_3ch",
+                                  "flush_short_stereo"])
+def test_golden(emu, ref, name):
+    pc.case_golden(emu, ref, name)
+
+
+def test_api_surface(emu, ref):
+    pc.case_api_surface(emu, ref)
+
+
+def test_split_mode(emu, ref):
+    pc.case_split_mode(emu, ref)
+
+
+def test_pitch_and_formants(emu, ref):
+    pc.case_pitch_and_formants(emu, ref)
+
+
+def test_silence(emu, ref):
+    pc.case_silence(emu, ref)
+
+
+def test_channels(emu, ref):
+    pc.case_channels(emu, ref)
+
+
+def test_batch_ragged(emu, ref):
+    pc.case_batch_ragged(emu, ref)
+
+
+def test_random_time_factor(emu, ref):
+    pc.case_random_time_factor(emu, ref)
