@@ -1,0 +1,146 @@
+// Drop-in C++ front-end for the MI355X implementation: same class name, namespace and member signatures as the
+// reference header (reference: signalsmith-stretch.h:34-491; include path as include/signalsmith-stretch/
+// signalsmith-stretch.h:1), forwarding every call to the C ABI in include/smst.h (libsmst_hip.so).
+// Existing callers (e.g. the reference's cmd/main.cpp:44-82) compile unchanged against this header.
+//
+// Differences a caller can observe are listed in DESIGN.md ("deviations"): only Sample=float exists; setFreqMap
+// samples the std::function into a 4096-point table; the RandomEngine parameter is accepted and ignored (the
+// >2x-stretch randomisation uses a counter-based generator on the device).
+#ifndef SIGNALSMITH_STRETCH_H
+#define SIGNALSMITH_STRETCH_H
+
+#include <cmath>
+#include <cstddef>
+#include <functional>
+#include <random>
+#include <stdexcept>
+#include <type_traits>
+#include <vector>
+
+#include "../smst.h"
+
+namespace signalsmith { namespace stretch {
+
+template <typename Sample = float, class RandomEngine = void>
+struct SignalsmithStretch {
+	static_assert(std::is_same<Sample, float>::value, "the gfx950 implementation computes in fp32 only");
+	static constexpr size_t version[3] = {1, 3, 2};
+
+	SignalsmithStretch() : SignalsmithStretch(long(std::random_device{}())) {}
+	SignalsmithStretch(long seed) {
+		if (smst_create(&handle, seed, defaultDevice()) != SMST_OK) throw std::runtime_error(smst_last_error());
+	}
+	~SignalsmithStretch() { smst_destroy(handle); }
+	SignalsmithStretch(const SignalsmithStretch &) = delete;
+	SignalsmithStretch &operator=(const SignalsmithStretch &) = delete;
+
+	int inputLatency() const { return smst_input_latency(handle); }
+	int outputLatency() const { return smst_output_latency(handle); }
+	void reset() { check(smst_reset(handle)); }
+
+	void presetDefault(int nChannels, Sample sampleRate, bool splitComputation = false) {
+		channels = nChannels;
+		check(smst_preset_default(handle, nChannels, sampleRate, splitComputation));
+	}
+	void presetCheaper(int nChannels, Sample sampleRate, bool splitComputation = true) {
+		channels = nChannels;
+		check(smst_preset_cheaper(handle, nChannels, sampleRate, splitComputation));
+	}
+	void configure(int nChannels, int blockSamples, int intervalSamples, bool splitComputation = false) {
+		channels = nChannels;
+		check(smst_configure(handle, nChannels, blockSamples, intervalSamples, splitComputation));
+	}
+	int blockSamples() const { return smst_block_samples(handle); }
+	int intervalSamples() const { return smst_interval_samples(handle); }
+	bool splitComputation() const { return smst_split_computation(handle) != 0; }
+
+	void setTransposeFactor(Sample multiplier, Sample tonalityLimit = 0) { check(smst_set_transpose_factor(handle, multiplier, tonalityLimit)); }
+	void setTransposeSemitones(Sample semitones, Sample tonalityLimit = 0) { check(smst_set_transpose_semitones(handle, semitones, tonalityLimit)); }
+	void setFreqMap(std::function<Sample(Sample)> inputToOutput) {
+		if (!inputToOutput) { check(smst_set_freq_map_table(handle, nullptr, 0)); return; }
+		const int n = 4096;
+		std::vector<float> table(n);
+		for (int i = 0; i < n; ++i) table[i] = inputToOutput((i + 0.5f)/(2*n));
+		check(smst_set_freq_map_table(handle, table.data(), n));
+	}
+	void setFormantFactor(Sample multiplier, bool compensatePitch = false) { check(smst_set_formant_factor(handle, multiplier, compensatePitch)); }
+	void setFormantSemitones(Sample semitones, bool compensatePitch = false) { check(smst_set_formant_semitones(handle, semitones, compensatePitch)); }
+	void setFormantBase(Sample baseFreq = 0) { check(smst_set_formant_base(handle, baseFreq)); }
+
+	template <class Inputs>
+	void seek(Inputs &&inputs, int inputSamples, double playbackRate) {
+		gather(inputs, inputSamples, 0);
+		check(smst_seek(handle, inPtrs.data(), inputSamples, playbackRate));
+	}
+	int seekLength() const { return smst_seek_length(handle); }
+	template <class Inputs>
+	void outputSeek(Inputs &&inputs, int inputLength) {
+		gather(inputs, inputLength, 0);
+		check(smst_output_seek(handle, inPtrs.data(), inputLength));
+	}
+	int outputSeekLength(Sample playbackRate) const { return smst_output_seek_length(handle, playbackRate); }
+
+	template <class Inputs, class Outputs>
+	void process(Inputs &&inputs, int inputSamples, Outputs &&outputs, int outputSamples) {
+		gather(inputs, inputSamples, 0);
+		prepareOut(outputSamples);
+		check(smst_process(handle, inPtrs.data(), inputSamples, outPtrs.data(), outputSamples));
+		scatter(outputs, outputSamples);
+	}
+	template <class Outputs>
+	void flush(Outputs &&outputs, int outputSamples, Sample playbackRate = 0) {
+		prepareOut(outputSamples);
+		check(smst_flush(handle, outPtrs.data(), outputSamples, playbackRate));
+		scatter(outputs, outputSamples);
+	}
+	template <class Inputs, class Outputs>
+	bool exact(Inputs &&inputs, int inputSamples, Outputs &&outputs, int outputSamples) {
+		gather(inputs, inputSamples, 0);
+		prepareOut(outputSamples);
+		int rc = smst_exact(handle, inPtrs.data(), inputSamples, outPtrs.data(), outputSamples);
+		if (rc != SMST_OK && rc != SMST_ERR_SHORT) check(rc);
+		scatter(outputs, outputSamples);
+		return rc == SMST_OK;
+	}
+
+private:
+	smst_stretch *handle = nullptr;
+	int channels = 0;
+	std::vector<float> inPlanar, outPlanar;
+	std::vector<const float *> inPtrs;
+	std::vector<float *> outPtrs;
+
+	static int defaultDevice() { return 0; }
+	static void check(int rc) {
+		if (rc != SMST_OK) throw std::runtime_error(smst_last_error());
+	}
+	// the reference accepts anything indexable as buffer[channel][index] (README.md:46): copy to planar floats
+	template <class Inputs>
+	void gather(Inputs &&inputs, int n, int offset) {
+		inPlanar.resize(size_t(channels)*size_t(n > 0 ? n : 1));
+		inPtrs.resize(channels);
+		for (int c = 0; c < channels; ++c) {
+			auto &&channel = inputs[c];
+			float *dst = inPlanar.data() + size_t(c)*size_t(n > 0 ? n : 1);
+			for (int i = 0; i < n; ++i) dst[i] = channel[i + offset];
+			inPtrs[c] = dst;
+		}
+	}
+	void prepareOut(int n) {
+		outPlanar.assign(size_t(channels)*size_t(n > 0 ? n : 1), 0.0f);
+		outPtrs.resize(channels);
+		for (int c = 0; c < channels; ++c) outPtrs[c] = outPlanar.data() + size_t(c)*size_t(n > 0 ? n : 1);
+	}
+	template <class Outputs>
+	void scatter(Outputs &&outputs, int n) {
+		for (int c = 0; c < channels; ++c) {
+			auto &&channel = outputs[c];
+			for (int i = 0; i < n; ++i) channel[i] = outPtrs[c][i];
+		}
+	}
+};
+template <typename Sample, class RandomEngine>
+constexpr size_t SignalsmithStretch<Sample, RandomEngine>::version[3];
+
+}} // namespace
+#endif

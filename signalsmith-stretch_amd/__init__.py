@@ -117,6 +117,12 @@ def load_library():
             raise StretchError(
                 "libsmst_hip.so not found at %s -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(there is no CPU fallback)" % LIBRARY_PATH)
+        # PyTorch ships its own HIP runtime; when both live in one process it has to be the first one loaded
+        # (torch is the plumbing for device tensors/streams here, so load it first whenever it is installed).
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         _lib = bind(C.CDLL(LIBRARY_PATH))
     return _lib
 

@@ -536,16 +536,16 @@ void Batch::process(const float *in, long long inSS, long long inCS, const int *
 			dd.nHops = dTileInfo + ((size_t)(sub*nTiles + t)*2)*subS;
 			dd.lastNewHop = dd.nHops + subS;
 			if (th[0]) {
-				if (th[3]) timed(timings.analyseMs, [&] { launchAnalyse(dd, io, sBase, ns, hopBase, tileHops, st); ++timings.analyseLaunches; });
+				if (th[3]) timed(timings.analyseMs, [&] { launchAnalyse(dd, io, sBase, ns, hopBase, tileHops, st); if (profiling) ++timings.analyseLaunches; });
 				if (th[1] || th[2]) timed(timings.feedMs, [&] {
 					launchFeedMap(dd, sBase, ns, hopBase, tileHops, st);
 					if (th[2]) launchFeedFormant(dd, sBase, ns, hopBase, tileHops, st);
 				});
-				timed(timings.predictMs, [&] { launchPredict(dd, sBase, ns, hopBase, tileHops, st); ++timings.predictLaunches; });
-				timed(timings.chainMs, [&] { launchChain(dd, sBase, ns, hopBase, st); ++timings.chainLaunches; });
-				timed(timings.synthMs, [&] { launchSynth(dd, sBase, ns, hopBase, tileHops, st); ++timings.synthLaunches; });
+				timed(timings.predictMs, [&] { launchPredict(dd, sBase, ns, hopBase, tileHops, st); if (profiling) ++timings.predictLaunches; });
+				timed(timings.chainMs, [&] { launchChain(dd, sBase, ns, hopBase, st); if (profiling) ++timings.chainLaunches; });
+				timed(timings.synthMs, [&] { launchSynth(dd, sBase, ns, hopBase, tileHops, st); if (profiling) ++timings.synthLaunches; });
 			}
-			timed(timings.emitMs, [&] { launchEmit(dd, io, sBase, ns, t, maxSpan[(size_t)sub*nTiles + t], st); ++timings.emitLaunches; });
+			timed(timings.emitMs, [&] { launchEmit(dd, io, sBase, ns, t, maxSpan[(size_t)sub*nTiles + t], st); if (profiling) ++timings.emitLaunches; });
 			if (th[0]) timed(timings.otherMs, [&] { launchCarryState(dd, sBase, ns, hopBase, st); });
 		}
 	}

@@ -2,38 +2,70 @@
 Every case drives the product through its C ABI (python ctypes mirror of the reference API) and the checker
 (oracle/_ref: the unmodified reference header) with the same seeded inputs, and compares.
 
-Tolerances (fp32 path, chaotic recurrence -- SURVEY.md App. D): rel-RMS <= TOL_SHORT over short horizons
-(<= 16 hops), TOL_LONG over long tonal horizons; identity and pure-bookkeeping cases <= TOL_EXACT."""
+TOLERANCE (stated here once).  The whole path is fp32 and the phase recurrence is chaotic (a 1e-7
+relative perturbation of the INPUT changes the reference's own output by 1e-5..1e-2 within 16 hops, more for noise
+and for pitch-mapped material where peak decisions flip).  So the bound is conditioning-aware, as App. D.2 prescribes:
+over every horizon h in HORIZONS (hops), rel-RMS(product, checker) <= max(FLOOR, SELF_FACTOR * rel-RMS(checker on the
+input perturbed by 1e-7 relative, checker)).  FLOOR = 1e-4 covers the fp32 rounding differences of a different FFT
+factorisation / FMA contraction when the self-sensitivity is tiny; cases with no phase-vocoder feedback (1.0x
+identity, ring bookkeeping) use TOL_EXACT = 2e-6 instead."""
 import numpy as np
 
 from conftest import package, rel_rms, synth_input
 import scenarios
 
-TOL_EXACT = 2e-6   # no phase-vocoder feedback involved (identity, carry/ring bookkeeping)
-TOL_SHORT = 1e-3   # SURVEY App. D.2 (ii)
-TOL_LONG = 5e-3    # SURVEY App. D.2 (iii), tonal input
+TOL_EXACT = 2e-6
+FLOOR = 1e-4
+SELF_FACTOR = 10.0
+HORIZONS = (6, 12, 24, 48, 1 << 30)
 
 
-def make_pair(lib, ref, channels, cfg, seed=0):
-    pkg = package()
-    g = pkg.SignalsmithStretch(seed=seed, lib=lib)
-    r = ref.RefStretch(seed)
-    scenarios.configure(g, channels, cfg)
-    scenarios.configure(r, channels, cfg)
-    return g, r
+def make(kind, lib, ref, channels, cfg, setup=None, seed=0):
+    obj = package().SignalsmithStretch(seed=seed, lib=lib) if kind == "product" else ref.RefStretch(seed)
+    scenarios.configure(obj, channels, cfg)
+    if setup:
+        setup(obj)
+    return obj
+
+
+def perturbed(x, seed=1):
+    u = np.random.default_rng(seed).uniform(-1, 1, x.shape)
+    return (x*(1 + 1e-7*u)).astype(np.float32)
+
+
+def assert_parity(y, o, o_self, interval, label):
+    assert y.shape == o.shape, (label, y.shape, o.shape)
+    total = o.shape[1]
+    for h in HORIZONS:
+        n = min(total, h*interval)
+        if n <= 0:
+            continue
+        err, own = rel_rms(y[:, :n], o[:, :n]), rel_rms(o_self[:, :n], o[:, :n])
+        tol = max(FLOOR, SELF_FACTOR*own)
+        assert err <= tol, "%s: horizon %d hops: rel-RMS %.3e > %.3e (checker self-sensitivity %.3e)" % (label, min(h, total//interval), err, tol, own)
+        if n == total:
+            break
+
+
+def check_scenario(lib, ref, cfg, x, play, label, setup=None):
+    """play(obj, x) -> concatenated output; run on the product, the checker, and the checker with perturbed input."""
+    C = x.shape[0]
+    g, r, r2 = (make(k, lib, ref, C, cfg, setup) for k in ("product", "ref", "ref"))
+    y, o, o2 = play(g, x), play(r, x), play(r2, perturbed(x))
+    assert_parity(y, o, o2, r.intervalSamples(), label)
+    return y, o
 
 
 def case_golden(lib, ref, name):
-    """Product vs. the WASM golden vector AND vs. the checker."""
+    """Product vs. the WASM golden vector AND vs. the checker (short fixtures, <= 16 hops)."""
     x, y, ops, cfg, info = scenarios.load_golden(name)
-    g, r = make_pair(lib, ref, x.shape[0], cfg)
+    g = make("product", lib, ref, x.shape[0], cfg)
     assert (g.blockSamples(), g.intervalSamples(), g.inputLatency(), g.outputLatency()) == \
         (info["block"], info["interval"], info["inputLatency"], info["outputLatency"])
-    out = scenarios.replay(g, x, ops)
-    chk = scenarios.replay(r, x, ops)
+    out, chk = check_scenario(lib, ref, cfg, x, lambda obj, xx: scenarios.replay(obj, xx, ops), name)
     assert out.shape == y.shape
-    assert rel_rms(out, y) <= scenarios.GOLDEN_TOL[name], ("vs wasm", name, rel_rms(out, y))
-    assert rel_rms(out, chk) <= scenarios.GOLDEN_TOL[name], ("vs ref", name, rel_rms(out, chk))
+    # vs the WASM itself: the checker's distance to the WASM plus the product's distance to the checker
+    assert rel_rms(out, y) <= max(scenarios.GOLDEN_TOL[name], 2*rel_rms(chk, y) + FLOOR), (name, rel_rms(out, y))
 
 
 SMALL = dict(preset="configure", block=512, interval=128, split=False)
@@ -44,51 +76,49 @@ def case_api_surface(lib, ref, cfg=SMALL):
     """seek / process in ragged chunks / flush / process-after-flush / outputSeek / exact, small geometry."""
     C, sr = 2, 48000
     x = synth_input(0, C, 128*150, sr) + 0.3*synth_input(1, C, 128*150, sr)
-    g, r = make_pair(lib, ref, C, cfg)
     # many hops in one call (crosses the 64-hop tile boundary twice)
-    a, b = g.process(x, int(x.shape[1]*1.25)), r.process(x, int(x.shape[1]*1.25))
-    assert rel_rms(a, b) < TOL_SHORT
-    # ragged chunk sizes, ratio 1.3 (0..5 hops per call)
-    g, r = make_pair(lib, ref, C, cfg)
-    rng = np.random.default_rng(0)
-    pos = 0
-    while pos < x.shape[1] - 700:
-        ni = int(rng.integers(1, 600))
-        no = int(ni*1.3)
-        a, b = g.process(x[:, pos:pos + ni], no), r.process(x[:, pos:pos + ni], no)
-        assert rel_rms(a, b) < TOL_SHORT or np.abs(b).max() < 1e-6, pos
-        pos += ni
-    # seek, then process, then flush (short), process again, flush (exactly one interval)
-    g, r = make_pair(lib, ref, C, cfg)
-    g.seek(x[:, :640], 0.8)
-    r.seek(x[:, :640], 0.8)
-    assert rel_rms(g.process(x[:, 640:4640], 5000), r.process(x[:, 640:4640], 5000)) < TOL_SHORT
-    assert rel_rms(g.flush(100), r.flush(100)) < TOL_SHORT
-    assert rel_rms(g.process(x[:, 5000:7000], 2000), r.process(x[:, 5000:7000], 2000)) < TOL_SHORT
-    assert rel_rms(g.flush(128), r.flush(128)) < TOL_SHORT
-    # outputSeek + process
-    g, r = make_pair(lib, ref, C, cfg)
+    check_scenario(lib, ref, cfg, x, lambda o, xx: o.process(xx, int(xx.shape[1]*1.25)), "one long call")
+
+    def ragged(o, xx):  # ragged chunk sizes, ratio 1.3 (0..5 hops per call)
+        rng = np.random.default_rng(0)
+        pos, outs = 0, []
+        while pos < xx.shape[1] - 700:
+            ni = int(rng.integers(1, 600))
+            outs.append(o.process(xx[:, pos:pos + ni], int(ni*1.3)))
+            pos += ni
+        return np.concatenate(outs, axis=1)
+    check_scenario(lib, ref, cfg, x, ragged, "ragged chunks")
+
+    def seek_flush(o, xx):  # seek, process, flush (short), process again, flush (exactly one interval)
+        o.seek(xx[:, :640], 0.8)
+        return np.concatenate([o.process(xx[:, 640:4640], 5000), o.flush(100), o.process(xx[:, 5000:7000], 2000), o.flush(128)], axis=1)
+    check_scenario(lib, ref, cfg, x, seek_flush, "seek/process/flush")
+
+    g, r = make("product", lib, ref, C, cfg), make("ref", lib, ref, C, cfg)
     n = r.outputSeekLength(0.8)
     assert g.outputSeekLength(0.8) == n and g.seekLength() == r.seekLength()
-    g.outputSeek(x[:, :n])
-    r.outputSeek(x[:, :n])
-    assert rel_rms(g.process(x[:, n:n + 4000], 5000), r.process(x[:, n:n + 4000], 5000)) < TOL_SHORT
-    # exact(): whole buffer; and the too-short input case (returns false, zeroes the output)
-    g, r = make_pair(lib, ref, C, cfg)
-    (a, ok_a), (b, ok_b) = g.exact(x[:, :6000], 7000), r.exact(x[:, :6000], 7000)
-    assert ok_a and ok_b and rel_rms(a, b) < TOL_SHORT
-    (a, ok_a), (b, ok_b) = g.exact(x[:, :200], 300), r.exact(x[:, :200], 300)
+
+    def output_seek(o, xx):
+        o.outputSeek(xx[:, :n])
+        return o.process(xx[:, n:n + 4000], 5000)
+    check_scenario(lib, ref, cfg, x, output_seek, "outputSeek")
+
+    def exact(o, xx):
+        out, ok = o.exact(xx[:, :6000], 7000)
+        assert ok
+        return out
+    check_scenario(lib, ref, cfg, x, exact, "exact")
+    (a, ok_a), (b, ok_b) = g.exact(x[:, :200], 300), r.exact(x[:, :200], 300)  # too short: false + zeroed output
     assert not ok_a and not ok_b and np.abs(a).max() == 0
 
 
 def case_split_mode(lib, ref):
     C, sr = 2, 48000
     x = synth_input(0, C, 12000, sr)
-    g, r = make_pair(lib, ref, C, SMALL_SPLIT)
+    g, r = make("product", lib, ref, C, SMALL_SPLIT), make("ref", lib, ref, C, SMALL_SPLIT)
     assert g.outputLatency() == r.outputLatency() == 256 + 128
-    assert rel_rms(g.process(x[:, :6000], 7040), r.process(x[:, :6000], 7040)) < TOL_SHORT
     # interval-aligned flush in split mode (mid-interval flushes differ by design, see DESIGN.md "deviations")
-    assert rel_rms(g.flush(90), r.flush(90)) < TOL_SHORT
+    check_scenario(lib, ref, SMALL_SPLIT, x, lambda o, xx: np.concatenate([o.process(xx[:, :6000], 7040), o.flush(90)], axis=1), "split")
 
 
 def case_pitch_and_formants(lib, ref, cfg=SMALL, n=9000):
@@ -102,24 +132,21 @@ def case_pitch_and_formants(lib, ref, cfg=SMALL, n=9000):
         ("freq-map-table", lambda o: o.setFreqMapTable(np.array([(i + 0.5)/128*1.5 for i in range(64)], np.float32)), 1.0),
     ]
     for label, setup, stretch in settings:
-        g, r = make_pair(lib, ref, C, cfg)
-        setup(g)
-        setup(r)
-        no = int(n*stretch)
-        assert rel_rms(g.process(x, no), r.process(x, no)) < TOL_SHORT, label
+        check_scenario(lib, ref, cfg, x, lambda o, xx, stretch=stretch: o.process(xx, int(n*stretch)), label, setup=setup)
 
 
 def case_silence(lib, ref):
     sr = 48000
-    g, r = make_pair(lib, ref, 1, SMALL)
     x = synth_input(0, 1, 4000, sr)
     z = np.zeros((1, 700), np.float32)
-    for chunk in (x[:, :2000], z, z, z, z, x[:, 2000:3000], z, x[:, 3000:]):
-        a, b = g.process(chunk, chunk.shape[1] + 50), r.process(chunk, chunk.shape[1] + 50)
-        if np.abs(b).max() > 0:
-            assert rel_rms(a, b) < TOL_SHORT
-        else:
-            assert np.abs(a).max() == 0
+
+    def play(o, xx):
+        outs = []
+        for chunk in (xx[:, :2000], z, z, z, z, xx[:, 2000:3000], z, xx[:, 3000:]):
+            outs.append(o.process(chunk, chunk.shape[1] + 50))
+        return np.concatenate(outs, axis=1)
+    y, o = check_scenario(lib, ref, SMALL, x, play, "silence")
+    assert np.array_equal(y[:, 3550:4300] == 0, o[:, 3550:4300] == 0)  # the pass-through region is exactly zero in both
 
 
 def case_channels(lib, ref, channel_counts=(1, 3, 8)):
@@ -127,10 +154,8 @@ def case_channels(lib, ref, channel_counts=(1, 3, 8)):
     for C in channel_counts:
         x = synth_input(3, C, 6000, sr)
         x *= (1 + 0.3*np.arange(C))[:, None].astype(np.float32)  # different energies: exercises the max-channel hand-over
-        g, r = make_pair(lib, ref, C, SMALL)
-        g.setTransposeSemitones(2, 0.2)
-        r.setTransposeSemitones(2, 0.2)
-        assert rel_rms(g.process(x, 7000), r.process(x, 7000)) < TOL_SHORT, C
+        check_scenario(lib, ref, SMALL, x, lambda o, xx: o.process(xx, 7000), "%d channels" % C,
+                       setup=lambda o: o.setTransposeSemitones(2, 0.2))
 
 
 def case_batch_ragged(lib, ref, cfg=SMALL, S=5, n=6000):
@@ -148,11 +173,10 @@ def case_batch_ragged(lib, ref, cfg=SMALL, S=5, n=6000):
         b.setTransposeSemitones(float(semis[s]), 0.0, stream=s)
     y = b.process(xs, nout, in_samples=nin)
     for s in range(S):
-        r = ref.RefStretch()
-        scenarios.configure(r, C, cfg)
-        r.setTransposeSemitones(float(semis[s]), 0.0)
-        o = r.process(xs[s][:, :nin[s]], nout[s])
-        assert rel_rms(y[s][:, :nout[s]], o) < TOL_SHORT, s
+        setup = lambda o, s=s: o.setTransposeSemitones(float(semis[s]), 0.0)  # noqa: E731
+        r, r2 = make("ref", lib, ref, C, cfg, setup), make("ref", lib, ref, C, cfg, setup)
+        o, o2 = r.process(xs[s][:, :nin[s]], nout[s]), r2.process(perturbed(xs[s][:, :nin[s]]), nout[s])
+        assert_parity(y[s][:, :nout[s]], o, o2, cfg["interval"], "batch stream %d" % s)
     b.close()
 
 
@@ -161,7 +185,7 @@ def case_random_time_factor(lib, ref):
     implementation-defined in the reference, so only the energy is comparable."""
     C, sr = 1, 48000
     x = synth_input(0, C, 3000, sr)
-    g, r = make_pair(lib, ref, C, SMALL)
+    g, r = make("product", lib, ref, C, SMALL), make("ref", lib, ref, C, SMALL)
     a, b = g.process(x, 9000), r.process(x, 9000)
     ra, rb = np.sqrt(np.mean(a[:, 2000:]**2)), np.sqrt(np.mean(b[:, 2000:]**2))
     assert abs(ra/rb - 1) < 0.1

@@ -64,3 +64,33 @@ def test_modified_spectrum_definition(ref):
     k = np.arange(N//2)
     direct = (block*w)[None, :] @ np.exp(-2j*np.pi*np.outer(n, k + 0.5)/N)
     assert np.abs(X - direct[0]).max() < 2e-5*np.abs(direct).max()
+
+
+@pytest.mark.parametrize("name", scenarios.golden_names())
+def test_port_matches_wasm_golden_and_ref(ref, name):
+    """oracle/stretch_port.cpp (the plain C++ restatement) against the WASM golden vectors and, sample for sample,
+    against oracle/_ref (the unmodified reference header): same L1, same order of operations -> tight bound."""
+    import port_oracle
+    x, y, ops, cfg, info = scenarios.load_golden(name)
+    p, r = port_oracle.PortStretch(), ref.RefStretch()
+    scenarios.configure(p, x.shape[0], cfg)
+    scenarios.configure(r, x.shape[0], cfg)
+    assert (p.blockSamples(), p.intervalSamples(), p.inputLatency(), p.outputLatency()) == \
+        (info["block"], info["interval"], info["inputLatency"], info["outputLatency"])
+    a, b = scenarios.replay(p, x, ops), scenarios.replay(r, x, ops)
+    assert rel_rms(a, y) <= scenarios.GOLDEN_TOL[name]
+    assert rel_rms(a, b) <= 1e-5, rel_rms(a, b)
+
+
+def test_port_formants_match_ref(ref):
+    import port_oracle
+    from conftest import synth_input
+    x = synth_input(0, 2, 20000, 48000) + 0.5*synth_input(4, 2, 20000, 48000)
+    for setup in (lambda o: (o.setTransposeSemitones(4, 8000/48000), o.setFormantFactor(1, True), o.setFormantBase(200/48000)),
+                  lambda o: (o.setFormantSemitones(3, False), o.setFormantBase(0))):
+        p, r = port_oracle.PortStretch(), ref.RefStretch()
+        p.presetDefault(2, 48000.0)
+        r.presetDefault(2, 48000.0)
+        setup(p)
+        setup(r)
+        assert rel_rms(p.process(x, 15000), r.process(x, 15000)) <= 1e-5
