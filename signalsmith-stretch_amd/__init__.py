@@ -210,7 +210,23 @@ class StretchBatch:
             t = np.ascontiguousarray(table, np.float32)
             _check(self.lib, self.lib.smst_batch_set_freq_map_table(self.h, stream, t.ctypes.data_as(_fp), len(t)))
 
-    def synchronize(self): _check(self.lib, self.lib.smst_batch_synchronize(self.h))
+    def synchronize(self):
+        _check(self.lib, self.lib.smst_batch_synchronize(self.h))
+        self._inflight = []
+
+    def _order_after_torch(self, *tensors):
+        """Device-memory calls are asynchronous on the batch's own HIP stream.  Wait for the producer (torch's current
+        stream), and keep the tensors referenced until the batch's stream has drained, so torch's caching allocator
+        cannot recycle their memory while our kernels still read or write it."""
+        import torch
+        torch.cuda.current_stream(tensors[0].device).synchronize()
+        inflight = getattr(self, "_inflight", [])
+        if len(inflight) >= 16:
+            self.synchronize()
+            inflight = []
+        inflight.append(tensors)
+        self._inflight = inflight
+
     def enableProfiling(self, on=True): _check(self.lib, self.lib.smst_batch_enable_profiling(self.h, int(on)))
 
     def takeTimings(self):
@@ -255,8 +271,7 @@ class StretchBatch:
         if on < max_out or int(nin.max()) > n:
             raise StretchError("buffer shorter than the requested sample count")
         if mem == MEM_DEVICE:
-            import torch
-            torch.cuda.current_stream(x.device).synchronize()
+            self._order_after_torch(x, out)
         _check(self.lib, self.lib.smst_batch_process(self.h, ptr, ss, cs, pin, optr, oss, ocs, pout, mem))
         return out
 
@@ -266,8 +281,7 @@ class StretchBatch:
         nin, pin = _int_array(n if in_samples is None else in_samples, S)
         r = np.ascontiguousarray(np.broadcast_to(np.asarray(rates, dtype=np.float64), (S,)))
         if mem == MEM_DEVICE:
-            import torch
-            torch.cuda.current_stream(x.device).synchronize()
+            self._order_after_torch(x)
         _check(self.lib, self.lib.smst_batch_seek(self.h, ptr, ss, cs, pin, r.ctypes.data_as(_dp), mem))
 
     def flush(self, out_samples, rates=0.0, like=None):
@@ -291,8 +305,7 @@ class StretchBatch:
         ptr, ss, cs, n, mem, keep = self._describe(x, "input")
         nin, pin = _int_array(n if input_lengths is None else input_lengths, S)
         if mem == MEM_DEVICE:
-            import torch
-            torch.cuda.current_stream(x.device).synchronize()
+            self._order_after_torch(x)
         _check(self.lib, self.lib.smst_batch_output_seek(self.h, ptr, ss, cs, pin, mem))
 
     # --- test hooks

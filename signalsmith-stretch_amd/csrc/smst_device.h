@@ -8,8 +8,11 @@ namespace smst {
 struct DevBatch {
 	// geometry (signalsmith-stretch.h:71-94; fftSamples/bands from the L1 contract)
 	int S, C, B, I, M, N, L, T;
+	int Mp;                       // row pitch (elements) of the per-tile [.][C][M] arrays: M + 32
+	int recPitch;                 // float4 per wavefront step in REC: chunks*64 + 16
 	int histLen, carryLen, delta; // B+I, B+I, split ? I : 0
 	int lag, ringSlots;           // wavefront skew (>= L+1) and LDS ring depth (power of two > lag)
+	int recSteps;                 // record rows per stream: M + lag*(T-1) rounded up to 64, plus prefetch slack
 	int hopStride, emitStride;    // row pitch of the per-call hop / emit tables
 	int mapTableLen;
 	int histCur, carryCur;        // which half of the double buffers is current
@@ -18,6 +21,8 @@ struct DevBatch {
 	const float2 *twH;     // e^{-2 pi i j / H}
 	const float2 *halfTw;  // e^{-i pi m / N}
 	const float2 *rot;     // per-bin hop rotation (signalsmith-stretch.h:647-655)
+	const float2 *twA, *twB; // fast FFT (H = 256*R3): stage twiddles laid out [n-1][p]
+	const float2 *winA, *winB; // analysis window folded with e^{-i pi m/N}: u[m] = x[m+B/2]*winA[m] + x[m-H+B/2]*winB[m]
 	const float *window;   // analysis == synthesis window (Kaiser, perfect reconstruction)
 	const float *wprod;    // window[i]^2 * N
 	// per-stream state
@@ -33,7 +38,9 @@ struct DevBatch {
 	const HopDesc *hops;   // [S][hopStride]
 	const EmitDesc *emit;  // [S][emitStride]
 	// per-tile workspace, [subS][T][C][M] unless noted
-	float2 *Xcur, *Xprev, *P, *Sx, *Tx, *Sdn, *Tdn, *TW, *OUT;
+	float2 *Xcur, *Xprev, *P, *OUT;
+	float2 *dump;   // [subS][C][64] parking lot for the recurrence kernel's out-of-range lanes
+	float4 *REC;    // skewed per-step records of the bin recurrence [subS][recSteps][chunks][64 lanes]
 	float *E;
 	float2 *map;    // [subS][T][M]
 	float *ratio;   // [subS][T][M]
@@ -56,7 +63,7 @@ void launchEnergy(const DevBatch &d, const IoArgs &io, int sBase, int nStreams, 
 void launchAnalyse(const DevBatch &d, const IoArgs &io, int sBase, int nStreams, int hopBase, int tileHops, hipStream_t st);
 void launchFeedMap(const DevBatch &d, int sBase, int nStreams, int hopBase, int tileHops, hipStream_t st);
 void launchFeedFormant(const DevBatch &d, int sBase, int nStreams, int hopBase, int tileHops, hipStream_t st);
-void launchPredict(const DevBatch &d, int sBase, int nStreams, int hopBase, int tileHops, hipStream_t st);
+void launchPredict(const DevBatch &d, int sBase, int nStreams, int hopBase, int tileHops, bool plain, hipStream_t st);
 void launchChain(const DevBatch &d, int sBase, int nStreams, int hopBase, hipStream_t st);
 void launchSynth(const DevBatch &d, int sBase, int nStreams, int hopBase, int tileHops, hipStream_t st);
 void launchEmit(const DevBatch &d, const IoArgs &io, int sBase, int nStreams, int tileIndex, int maxSpan, hipStream_t st);

@@ -150,6 +150,35 @@ Batch::Batch(int streams, int channels, int block, int interval, bool splitCompu
 	d.halfTw = static_cast<float2 *>(upload(half.data(), M*sizeof(float2)));
 	d.rot = static_cast<float2 *>(upload(rot.data(), M*sizeof(float2)));
 	d.window = static_cast<float *>(upload(win.data(), B*sizeof(float)));
+	{ // folded analysis tables and, for H = 256*R3, the stage twiddles of the register-blocked FFT
+		const int halfB = B/2;
+		std::vector<float2> wa(M), wb(M);
+		for (int m = 0; m < M; ++m) {
+			float a = (m < B - halfB) ? win[m + halfB] : 0.0f;
+			float b = (m >= M - halfB) ? win[m - M + halfB] : 0.0f;
+			wa[m] = make_float2(a*half[m].x, a*half[m].y);        // w * e^{-i pi m/N}
+			wb[m] = make_float2(-b*half[m].y, b*half[m].x);       // i * w * e^{-i pi m/N}
+		}
+		d.winA = static_cast<float2 *>(upload(wa.data(), M*sizeof(float2)));
+		d.winB = static_cast<float2 *>(upload(wb.data(), M*sizeof(float2)));
+		d.twA = d.twB = nullptr;
+		if (M%256 == 0 && (M/256 == 12 || M/256 == 20)) {
+			const int R3 = M/256, MA = 16*R3;
+			std::vector<float2> ta((size_t)15*MA), tb((size_t)15*R3);
+			for (int n = 1; n < 16; ++n) {
+				for (int p = 0; p < MA; ++p) {
+					double a = -2*M_PI*double(p*n)/double(M);
+					ta[(size_t)(n - 1)*MA + p] = make_float2(float(std::cos(a)), float(std::sin(a)));
+				}
+				for (int p = 0; p < R3; ++p) {
+					double a = -2*M_PI*double(p*n)/double(MA);
+					tb[(size_t)(n - 1)*R3 + p] = make_float2(float(std::cos(a)), float(std::sin(a)));
+				}
+			}
+			d.twA = static_cast<float2 *>(upload(ta.data(), ta.size()*sizeof(float2)));
+			d.twB = static_cast<float2 *>(upload(tb.data(), tb.size()*sizeof(float2)));
+		}
+	}
 	d.wprod = static_cast<float *>(upload(wprod.data(), B*sizeof(float)));
 
 	const size_t bandRows = (size_t)S*C*M;
@@ -166,7 +195,7 @@ Batch::Batch(int streams, int channels, int block, int interval, bool splitCompu
 	d.stFreq = devAlloc<float>((size_t)S*2);
 	dParams = devAlloc<StreamParams>(S);
 	d.params = dParams;
-	dEnergy = devAlloc<float>(S);
+	dEnergy = devAlloc<float>((size_t)S*kEnergyParts);
 	dInSamples = devAlloc<int>(S);
 	dOutSamples = devAlloc<int>(S);
 	dFlags = devAlloc<int>(S);
@@ -193,25 +222,28 @@ Batch::~Batch() {
 }
 
 void Batch::allocateWorkspace() {
-	// Per (stream, hop, channel): 7 complex rows + 1 float row of M bins + one B-sample frame.
+	// Per (stream, hop, channel): 4 complex rows + 1 float row of M bins + one B-sample frame, plus the skewed records.
 	// Sub-batch the streams so the tile workspace stays under a budget (default 48 GiB of the 288 GB HBM).
 	double budgetGiB = 48;
 	if (const char *env = std::getenv("SMST_WORKSPACE_GIB")) budgetGiB = std::max(0.25, atof(env));
-	const size_t perStream = (size_t)d.T*((size_t)C*((size_t)M*(9*sizeof(float2) + sizeof(float)) + (size_t)B*sizeof(float))
-	                                      + (size_t)M*(sizeof(float2) + 2*sizeof(float)) + 2*sizeof(float));
+	const size_t recChunks = (9 + 3*(size_t)C + 3)/4;
+	d.recSteps = ((M + d.lag*(d.T - 1) + 63)/64)*64 + 8;
+	d.recPitch = int(recChunks*64 + 16);
+	d.Mp = M + 32;
+	const size_t perStream = (size_t)d.T*((size_t)C*((size_t)d.Mp*(4*sizeof(float2) + sizeof(float)) + (size_t)B*sizeof(float))
+	                                      + (size_t)M*(sizeof(float2) + 2*sizeof(float)) + 2*sizeof(float))
+	                         + (size_t)d.recSteps*d.recPitch*sizeof(float4);
 	size_t maxStreams = size_t(budgetGiB*1024.0*1024.0*1024.0/double(perStream));
 	if (maxStreams < 1) maxStreams = 1;
 	subS = int(std::min<size_t>(S, maxStreams));
-	const size_t rows = (size_t)subS*d.T*C*M;
+	const size_t rows = (size_t)subS*d.T*C*d.Mp;
 	d.Xcur = devAlloc<float2>(rows);
 	d.Xprev = devAlloc<float2>(rows);
 	d.P = devAlloc<float2>(rows);
-	d.Sx = devAlloc<float2>(rows);
-	d.Tx = devAlloc<float2>(rows);
-	d.Sdn = devAlloc<float2>(rows);
-	d.Tdn = devAlloc<float2>(rows);
-	d.TW = devAlloc<float2>(rows);
 	d.OUT = devAlloc<float2>(rows);
+	d.REC = devAlloc<float4>((size_t)subS*d.recSteps*d.recPitch);
+	SMST_HIP(hipMemset(d.REC, 0, (size_t)subS*d.recSteps*d.recPitch*sizeof(float4)));
+	d.dump = devAlloc<float2>((size_t)subS*C*64);
 	d.E = devAlloc<float>(rows);
 	d.map = devAlloc<float2>((size_t)subS*d.T*M);
 	d.ratio = devAlloc<float>((size_t)subS*d.T*M);
@@ -378,10 +410,15 @@ void Batch::process(const float *in, long long inSS, long long inCS, const int *
 	IoArgs io{in, out, inSS, inCS, outSS, outCS, dInSamples, dOutSamples};
 
 	// K5: silence gate needs the input energy on the host (one 4-byte-per-stream readback per call)
-	std::vector<float> energy(S);
+	std::vector<float> energy(S), energyParts((size_t)S*kEnergyParts);
 	launchEnergy(d, io, 0, S, dEnergy, st);
-	SMST_HIP(hipMemcpyAsync(energy.data(), dEnergy, S*sizeof(float), hipMemcpyDeviceToHost, st));
+	SMST_HIP(hipMemcpyAsync(energyParts.data(), dEnergy, energyParts.size()*sizeof(float), hipMemcpyDeviceToHost, st));
 	SMST_HIP(hipStreamSynchronize(st));
+	for (int s = 0; s < S; ++s) {
+		float e = 0;
+		for (int p = 0; p < kEnergyParts; ++p) e += energyParts[(size_t)s*kEnergyParts + p];
+		energy[s] = e;
+	}
 
 	// K0: block scheduler, exactly as signalsmith-stretch.h:231-319 does it per stream
 	std::vector<std::vector<HopDesc>> hopLists(S);
@@ -541,7 +578,7 @@ void Batch::process(const float *in, long long inSS, long long inCS, const int *
 					launchFeedMap(dd, sBase, ns, hopBase, tileHops, st);
 					if (th[2]) launchFeedFormant(dd, sBase, ns, hopBase, tileHops, st);
 				});
-				timed(timings.predictMs, [&] { launchPredict(dd, sBase, ns, hopBase, tileHops, st); if (profiling) ++timings.predictLaunches; });
+				timed(timings.predictMs, [&] { launchPredict(dd, sBase, ns, hopBase, tileHops, !(th[1] || th[2]), st); if (profiling) ++timings.predictLaunches; });
 				timed(timings.chainMs, [&] { launchChain(dd, sBase, ns, hopBase, st); if (profiling) ++timings.chainLaunches; });
 				timed(timings.synthMs, [&] { launchSynth(dd, sBase, ns, hopBase, tileHops, st); if (profiling) ++timings.synthLaunches; });
 			}
@@ -581,10 +618,15 @@ void Batch::seek(const float *in, long long inSS, long long inCS, const int *inS
 	IoArgs ioE{d.hist[d.histCur], nullptr, (long long)C*d.histLen, (long long)d.histLen, 0, 0, dAux0, dOutSamples};
 	std::vector<int> histN(S, d.histLen);
 	SMST_HIP(hipMemcpyAsync(dAux0, histN.data(), S*sizeof(int), hipMemcpyHostToDevice, st));
-	std::vector<float> energy(S);
+	std::vector<float> energy(S), energyParts((size_t)S*kEnergyParts);
 	launchEnergy(d, ioE, 0, S, dEnergy, st);
-	SMST_HIP(hipMemcpyAsync(energy.data(), dEnergy, S*sizeof(float), hipMemcpyDeviceToHost, st));
+	SMST_HIP(hipMemcpyAsync(energyParts.data(), dEnergy, energyParts.size()*sizeof(float), hipMemcpyDeviceToHost, st));
 	SMST_HIP(hipStreamSynchronize(st));
+	for (int s = 0; s < S; ++s) {
+		float e = 0;
+		for (int p = 0; p < kEnergyParts; ++p) e += energyParts[(size_t)s*kEnergyParts + p];
+		energy[s] = e;
+	}
 	for (int s = 0; s < S; ++s) {
 		if (!flags[s]) continue;
 		StreamSched &sc = sched[s];

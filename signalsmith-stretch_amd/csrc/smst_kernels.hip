@@ -33,7 +33,7 @@ __device__ __forceinline__ float2 mulI(float2 a) { return make_float2(-a.y, a.x)
 __device__ __forceinline__ float2 mulNegI(float2 a) { return make_float2(a.y, -a.x); }
 
 __device__ __forceinline__ size_t rowOf(const DevBatch &d, int s, int k, int c) {
-	return ((size_t)((size_t)s*d.T + k)*d.C + c)*(size_t)d.M;
+	return ((size_t)((size_t)s*d.T + k)*d.C + c)*(size_t)d.Mp; // Mp: padded row pitch (keeps lane strides off powers of two)
 }
 __device__ __forceinline__ size_t stateRow(const DevBatch &d, int sGlobal, int c) {
 	return ((size_t)sGlobal*d.C + c)*(size_t)d.M;
@@ -139,15 +139,225 @@ __device__ float2 *fftLds(float2 *src, float2 *dst, const FftPlan &plan, const f
 }
 
 // ------------------------------------------------------------------------------------------------------
+// Register-blocked FFT for H = 256*R3 (R3 = 12: 3072 bins = presetDefault at 44.1/48 kHz; R3 = 20: 5120 bins =
+// presetCheaper at 96 kHz): three Stockham stages 16 x 16 x R3, each butterfly held in registers, so the data
+// crosses LDS only twice (vs. six times in the generic radix-4 ladder) and the stage-A output is padded by one
+// element per 16 so that neither the 128-byte-strided writes nor the stage-B reads conflict on LDS banks.
+// Twiddles come from per-stage tables laid out [n][p] (coalesced across the threads of a stage).
+// ------------------------------------------------------------------------------------------------------
+template <int SIGN>
+__device__ __forceinline__ void dft4(float2 &a, float2 &b, float2 &c, float2 &d) {
+	float2 apc = cadd(a, c), amc = csub(a, c), bpd = cadd(b, d), bmd = csub(b, d);
+	float2 jb = (SIGN < 0) ? mulNegI(bmd) : mulI(bmd);
+	a = cadd(apc, bpd);
+	b = cadd(amc, jb);
+	c = csub(apc, bpd);
+	d = csub(amc, jb);
+}
+template <int SIGN>
+__device__ __forceinline__ float2 mulConst(float2 v, float re, float im) { // v * (re, SIGN<0 ? -im : +im)
+	const float s = (SIGN < 0) ? -im : im;
+	return make_float2(v.x*re - v.y*s, v.x*s + v.y*re);
+}
+// 16-point DFT in place; on return X[e + 4c] sits at v[c + 4e]
+template <int SIGN>
+__device__ __forceinline__ void dft16(float2 (&v)[16]) {
+#pragma unroll
+	for (int i = 0; i < 4; ++i) dft4<SIGN>(v[i], v[i + 4], v[i + 8], v[i + 12]);
+	const float c1 = 0.92387953251128675613f, s1 = 0.38268343236508977173f, h = 0.70710678118654752440f;
+	// t_i[e] (at v[i + 4e]) *= w16^(i e)
+	v[1 + 4] = mulConst<SIGN>(v[1 + 4], c1, s1);   // w^1
+	v[1 + 8] = mulConst<SIGN>(v[1 + 8], h, h);     // w^2
+	v[1 + 12] = mulConst<SIGN>(v[1 + 12], s1, c1); // w^3
+	v[2 + 4] = mulConst<SIGN>(v[2 + 4], h, h);     // w^2
+	v[2 + 8] = (SIGN < 0) ? mulNegI(v[2 + 8]) : mulI(v[2 + 8]); // w^4
+	v[2 + 12] = mulConst<SIGN>(v[2 + 12], -h, h);  // w^6
+	v[3 + 4] = mulConst<SIGN>(v[3 + 4], s1, c1);   // w^3
+	v[3 + 8] = mulConst<SIGN>(v[3 + 8], -h, h);    // w^6
+	v[3 + 12] = mulConst<SIGN>(v[3 + 12], -c1, -s1); // w^9
+#pragma unroll
+	for (int e = 0; e < 4; ++e) dft4<SIGN>(v[4*e], v[4*e + 1], v[4*e + 2], v[4*e + 3]);
+}
+template <int SIGN>
+__device__ __forceinline__ void dft3(float2 &a, float2 &b, float2 &c) {
+	const float s3 = 0.86602540378443864676f;
+	float2 bpc = cadd(b, c), bmc = csub(b, c);
+	float2 t = make_float2(a.x - 0.5f*bpc.x, a.y - 0.5f*bpc.y);
+	float2 u = cscale((SIGN < 0) ? mulNegI(bmc) : mulI(bmc), s3);
+	a = cadd(a, bpc);
+	b = cadd(t, u);
+	c = csub(t, u);
+}
+template <int SIGN>
+__device__ __forceinline__ void dft5(float2 &a, float2 &b, float2 &c, float2 &d, float2 &e) {
+	const float c1 = 0.30901699437494742410f, c2 = -0.80901699437494742410f;
+	const float s1 = 0.95105651629515357212f, s2 = 0.58778525229247312917f;
+	float2 bpe = cadd(b, e), bme = csub(b, e), cpd = cadd(c, d), cmd = csub(c, d);
+	float2 t1 = make_float2(a.x + c1*bpe.x + c2*cpd.x, a.y + c1*bpe.y + c2*cpd.y);
+	float2 t2 = make_float2(a.x + c2*bpe.x + c1*cpd.x, a.y + c2*bpe.y + c1*cpd.y);
+	float2 u1 = make_float2(s1*bme.x + s2*cmd.x, s1*bme.y + s2*cmd.y);
+	float2 u2 = make_float2(s2*bme.x - s1*cmd.x, s2*bme.y - s1*cmd.y);
+	float2 ju1 = (SIGN < 0) ? mulNegI(u1) : mulI(u1);
+	float2 ju2 = (SIGN < 0) ? mulNegI(u2) : mulI(u2);
+	a = cadd(a, cadd(bpe, cpd));
+	b = cadd(t1, ju1);
+	c = cadd(t2, ju2);
+	d = csub(t2, ju2);
+	e = csub(t1, ju1);
+}
+// R3-point DFT (R3 = 4*G, G = 3 or 5) in place; on return X[e + 4c] sits at v[c + G*e]
+template <int SIGN, int R3>
+__device__ __forceinline__ void dftLast(float2 (&v)[R3]) {
+	constexpr int G = R3/4;
+#pragma unroll
+	for (int i = 0; i < G; ++i) dft4<SIGN>(v[i], v[i + G], v[i + 2*G], v[i + 3*G]);
+	// t_i[e] (at v[i + G e]) *= w_R3^(i e)
+#pragma unroll
+	for (int i = 1; i < G; ++i) {
+#pragma unroll
+		for (int e = 1; e < 4; ++e) {
+			// compile-time constant after unrolling
+			const float ang = 6.28318530717958647692f*float(i*e)/float(R3);
+			v[i + G*e] = mulConst<SIGN>(v[i + G*e], __builtin_cosf(ang), __builtin_sinf(ang));
+		}
+	}
+#pragma unroll
+	for (int e = 0; e < 4; ++e) {
+		if (G == 3) dft3<SIGN>(v[G*e], v[G*e + 1], v[G*e + 2]);
+		else dft5<SIGN>(v[G*e], v[G*e + 1], v[G*e + 2], v[G*e + 3 < R3 ? G*e + 3 : 0], v[G*e + 4 < R3 ? G*e + 4 : 0]);
+	}
+}
+
+// load(idx) -> float2 supplies the natural-order input, store(idx, value) receives the natural-order output.
+// lds: H + H/16 float2.  All threads of the block must call this (it synchronises).
+template <int SIGN, int R3, typename Load, typename Store>
+__device__ __forceinline__ void fftFast(float2 *lds, const float2 *__restrict__ twA, const float2 *__restrict__ twB, Load load, Store store) {
+	constexpr int H = 256*R3, MA = 16*R3;
+	const int t = threadIdx.x;
+	float2 v[16];
+	// stage A: radix 16, stride 1
+	if (t < MA) {
+#pragma unroll
+		for (int k = 0; k < 16; ++k) v[k] = load(t + MA*k);
+		dft16<SIGN>(v);
+#pragma unroll
+		for (int pos = 0; pos < 16; ++pos) {
+			const int n = (pos >> 2) + 4*(pos & 3);
+			float2 val = v[pos];
+			if (n > 0) {
+				float2 w = twA[(n - 1)*MA + t];
+				if (SIGN > 0) w.y = -w.y;
+				val = cmul(val, w);
+			}
+			lds[17*t + n] = val; // padded index of 16 t + n
+		}
+	}
+	__syncthreads();
+	// stage B: radix 16, stride 16
+	const int p = t >> 4, q0 = t & 15;
+	if (t < MA) {
+#pragma unroll
+		for (int k = 0; k < 16; ++k) v[k] = lds[q0 + 17*(p + R3*k)];
+	}
+	__syncthreads();
+	if (t < MA) {
+		dft16<SIGN>(v);
+#pragma unroll
+		for (int pos = 0; pos < 16; ++pos) {
+			const int n = (pos >> 2) + 4*(pos & 3);
+			float2 val = v[pos];
+			if (n > 0) {
+				float2 w = twB[(n - 1)*R3 + p];
+				if (SIGN > 0) w.y = -w.y;
+				val = cmul(val, w);
+			}
+			lds[q0 + 256*p + 16*n] = val;
+		}
+	}
+	__syncthreads();
+	// stage C: radix R3, stride 256, no twiddles
+	if (t < 256) {
+		constexpr int G = R3/4;
+		float2 u[R3];
+#pragma unroll
+		for (int k = 0; k < R3; ++k) u[k] = lds[t + 256*k];
+		dftLast<SIGN, R3>(u);
+#pragma unroll
+		for (int pos = 0; pos < R3; ++pos) {
+			const int e = pos/G, c = pos - G*e;
+			store(t + 256*(e + 4*c), u[pos]);
+		}
+	}
+}
+
+template <int R3>
+__global__ __launch_bounds__(16*R3 > 256 ? 16*R3 : 256) void kAnalyseFast(DevBatch d, IoArgs io, int sBase, int hopBase) {
+	extern __shared__ __attribute__((aligned(16))) unsigned char smemRaw[];
+	float2 *lds = reinterpret_cast<float2 *>(smemRaw);
+	const int k = blockIdx.x;
+	const int c = blockIdx.y >> 1;
+	const int which = blockIdx.y & 1;
+	const int s = blockIdx.z;
+	const HopDesc hd = d.hops[(size_t)(sBase + s)*d.hopStride + hopBase + k];
+	if (!(hd.flags & HOP_ACTIVE) || !(hd.flags & HOP_NEW_SPECTRUM)) return;
+	if (which == 1 && !(hd.flags & HOP_REANALYSE_PREV)) return;
+	const int B = d.B, H = d.M, halfB = B/2, N = d.N;
+	const int base = hd.inputOffset - (which ? d.I : 0) - B;
+	const float *x = io.in + (size_t)(sBase + s)*io.inStreamStride + (size_t)c*io.inChannelStride;
+	const float *hist = d.hist[d.histCur] + ((size_t)(sBase + s)*d.C + c)*(size_t)d.histLen + d.histLen;
+	const float2 *__restrict__ winA = d.winA, *__restrict__ winB = d.winB;
+	float2 *dst = (which ? d.Xprev : d.Xcur) + rowOf(d, s, k, c);
+	fftFast<-1, R3>(lds, d.twA, d.twB,
+		[&](int m) {
+			float xr = 0, xi = 0;
+			if (m < B - halfB) { int src = base + m + halfB; xr = (src >= 0) ? x[src] : hist[src]; }
+			if (m >= H - halfB) { int src = base + m - H + halfB; xi = (src >= 0) ? x[src] : hist[src]; }
+			const float2 a = winA[m], b = winB[m];
+			return make_float2(xr*a.x + xi*b.x, xr*a.y + xi*b.y);
+		},
+		[&](int j, float2 u) {
+			const int kk = 2*j;
+			if (kk < H) dst[kk] = u;
+			else dst[N - 1 - kk] = cconj(u);
+		});
+}
+
+template <int R3>
+__global__ __launch_bounds__(16*R3 > 256 ? 16*R3 : 256) void kSynthFast(DevBatch d, int sBase, int hopBase) {
+	extern __shared__ __attribute__((aligned(16))) unsigned char smemRaw[];
+	float2 *lds = reinterpret_cast<float2 *>(smemRaw);
+	const int k = blockIdx.x, c = blockIdx.y, s = blockIdx.z;
+	const HopDesc hd = d.hops[(size_t)(sBase + s)*d.hopStride + hopBase + k];
+	if (!(hd.flags & HOP_ACTIVE)) return;
+	const int B = d.B, H = d.M, N = d.N, halfB = B/2;
+	const float2 *X = d.OUT + rowOf(d, s, k, c);
+	float *frame = d.frames + ((size_t)((size_t)s*d.T + k)*d.C + c)*(size_t)B;
+	const float *__restrict__ win = d.window;
+	const float2 *__restrict__ halfTw = d.halfTw;
+	fftFast<+1, R3>(lds, d.twA, d.twB,
+		[&](int j) {
+			const int kk = 2*j;
+			return (kk < H) ? X[kk] : cconj(X[N - 1 - kk]);
+		},
+		[&](int m, float2 u) {
+			const float2 v = cmulc(u, halfTw[m]); // * e^{+i pi m / N}
+			if (m < B - halfB) { const int i = m + halfB; frame[i] = (2*v.x)*win[i]; }
+			if (m >= H - halfB) { const int i = m - H + halfB; frame[i] = (2*v.y)*win[i]; }
+		});
+}
+
+// ------------------------------------------------------------------------------------------------------
 // K5: per-stream input energy (silence gate, signalsmith-stretch.h:231-238)
 // ------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void kEnergy(DevBatch d, IoArgs io, int sBase, float *__restrict__ energyOut) {
-	const int s = blockIdx.x;
+	// grid (stream, part): partial sums, the host adds the kEnergyParts partials of a stream
+	const int s = blockIdx.x, part = blockIdx.y, parts = gridDim.y;
 	const int n = io.inSamples[sBase + s];
+	const int lo = (int)((long long)n*part/parts), hi = (int)((long long)n*(part + 1)/parts);
 	float acc = 0;
 	for (int c = 0; c < d.C; ++c) {
 		const float *x = io.in + (size_t)(sBase + s)*io.inStreamStride + (size_t)c*io.inChannelStride;
-		for (int i = threadIdx.x; i < n; i += blockDim.x) {
+		for (int i = lo + threadIdx.x; i < hi; i += blockDim.x) {
 			float v = x[i];
 			acc += v*v;
 		}
@@ -160,7 +370,7 @@ __global__ __launch_bounds__(256) void kEnergy(DevBatch d, IoArgs io, int sBase,
 		if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
 		__syncthreads();
 	}
-	if (threadIdx.x == 0) energyOut[sBase + s] = red[0];
+	if (threadIdx.x == 0) energyOut[(size_t)(sBase + s)*parts + part] = red[0];
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -470,57 +680,187 @@ __device__ __forceinline__ float2 lerpBand(const float2 *row, LerpIndex li, int 
 	return make_float2(low.x + (high.x - low.x)*li.fr, low.y + (high.y - low.y)*li.fr);
 }
 
-__global__ __launch_bounds__(256) void kPredict(DevBatch d, int sBase, int hopBase) {
+// pass A: P and E in row layout [s][k][c][M]
+__global__ __launch_bounds__(256) void kPredictA(DevBatch d, int sBase, int hopBase) {
 	const int b = blockIdx.x*blockDim.x + threadIdx.x;
 	const int k = blockIdx.y, s = blockIdx.z, sg = sBase + s;
 	const HopDesc hd = d.hops[(size_t)sg*d.hopStride + hopBase + k];
 	if (!(hd.flags & HOP_ACTIVE) || b >= d.M) return;
-	const int M = d.M, L = d.L;
-	const bool rotate = hd.flags & HOP_NEW_SPECTRUM;
-	const bool mapped = hd.flags & HOP_MAPPED, formants = hd.flags & HOP_FORMANTS, randomTf = hd.flags & HOP_RANDOM_TF;
-
+	const int M = d.M;
+	const bool mapped = hd.flags & HOP_MAPPED, formants = hd.flags & HOP_FORMANTS;
 	float2 mp = mapped ? d.map[((size_t)s*d.T + k)*M + b] : make_float2(float(b), 1.0f);
 	const LerpIndex li = lerpIndex(mp.x);
 	const float gradScale = fmaxf(0.0f, mp.y);
 	const float *ratio = formants ? d.ratio + ((size_t)s*d.T + k)*M : nullptr;
-
-	float tfUp = hd.timeFactor, tfDnS = hd.timeFactor, tfDnL = hd.timeFactor;
-	if (randomTf) { // uniform(4 - tf, tf), one draw per bin and direction (:640,:749,:769)
-		const float lo = 4.0f - hd.timeFactor, span = hd.timeFactor - lo;
-		tfUp = lo + span*hashUniform(hd.seed, b, 0);
-		tfDnS = lo + span*hashUniform(hd.seed, b - 1, 1);  // the draw made while the reference processed bin b-1
-		tfDnL = lo + span*hashUniform(hd.seed, b - L, 1);  // ... and bin b-L
-	}
-	const float2 rotB = rotate ? d.rot[b] : make_float2(1.f, 0.f);
 	const bool loIn = li.lo >= 0 && li.lo < M, hiIn = li.lo + 1 >= 0 && li.lo + 1 < M;
-	const float2 rotLo = (rotate && loIn) ? d.rot[li.lo] : make_float2(1.f, 0.f);
-	const float2 rotHi = (rotate && hiIn) ? d.rot[li.lo + 1] : make_float2(1.f, 0.f);
-
 	for (int c = 0; c < d.C; ++c) {
 		const float2 *in = inputRow(d, hd, s, sg, c);
-		const float2 *pv = prevRow(d, hd, s, k, sg, c);
 		const size_t o = rowOf(d, s, k, c) + b;
-
 		float2 inLo = bandAt(in, li.lo, M), inHi = bandAt(in, li.lo + 1, M);
 		float eLo = cnorm(inLo), eHi = cnorm(inHi);
 		if (formants) {
 			if (loIn) eLo *= ratio[li.lo];
 			if (hiIn) eHi *= ratio[li.lo + 1];
 		}
-		float E = (eLo + (eHi - eLo)*li.fr)*gradScale;
-		float2 P = make_float2(inLo.x + (inHi.x - inLo.x)*li.fr, inLo.y + (inHi.y - inLo.y)*li.fr);
-		float2 pvLo = cmul(bandAt(pv, li.lo, M), rotLo), pvHi = cmul(bandAt(pv, li.lo + 1, M), rotHi);
-		float2 Q = make_float2(pvLo.x + (pvHi.x - pvLo.x)*li.fr, pvLo.y + (pvHi.y - pvLo.y)*li.fr);
+		d.E[o] = (eLo + (eHi - eLo)*li.fr)*gradScale;
+		d.P[o] = make_float2(inLo.x + (inHi.x - inLo.x)*li.fr, inLo.y + (inHi.y - inLo.y)*li.fr);
+	}
+}
 
-		d.P[o] = P;
-		d.E[o] = E;
-		d.TW[o] = cmul(rotB, cmulc(P, Q));
-		d.Sx[o] = cmulc(P, lerpBand(in, lerpIndex(mp.x - tfUp), M));
-		d.Tx[o] = cmulc(P, lerpBand(in, lerpIndex(mp.x - L*tfUp), M));
-		if (randomTf) {
-			d.Sdn[o] = cmulc(P, lerpBand(in, lerpIndex(mp.x - tfDnS), M));
-			d.Tdn[o] = cmulc(P, lerpBand(in, lerpIndex(mp.x - L*tfDnL), M));
+// One record of the bin recurrence = everything hop k needs at bin b, with the maximum-energy channel m(b)
+// already selected (signalsmith-stretch.h:729-737):
+//   phi = out_m[b-1]*A + out_m[b-L]*B + prevHopOut_m[b+1]*Cc + prevHopOut_m[b+L]*Dc         (:744-786)
+//   A  = P_m[b] conj(lerp(in_m, map[b]-tf)),  B = P_m[b] conj(lerp(in_m, map[b]-L tf))      (up-steps, :748-762)
+//   Cc = TW_m[b+1]/(max(Eprev_m[b+1],E_m[b+1])+eps) * conj(P_m[b+1] conj(lerp(in_m, map[b+1]-tf)))   (:765-774 with
+//        the preliminary prediction :714-716 folded in; TW = rot[b+1] P_m[b+1] conj(lerp(rot*prev_m, map[b+1])))
+//   Dc = the same at b+L with L tf                                                          (:776-785)
+// followed, per channel c, by {P_c[b], sqrt(E_c[b])} for makeOutput (:596-603) and the channel lock
+// (:791-800, lock twist P_c conj(P_m) formed in the recurrence kernel).  Floats: 0-7 A,B,Cc,Dc; 8 m; 9+3c.. per channel.  Records live in a SKEWED layout
+// REC[s][t][chunk][lane k] (float4 chunks, t = b + lag*k) so that step t of the wavefront is one contiguous block.
+
+// Fractional read that skips the upper tap when the index is an integer (always the case without a pitch map).
+__device__ __forceinline__ float2 lerpBandFast(const float2 *row, LerpIndex li, int M) {
+	float2 low = bandAt(row, li.lo, M);
+	if (li.fr == 0.0f) return low;
+	float2 high = bandAt(row, li.lo + 1, M);
+	return make_float2(low.x + (high.x - low.x)*li.fr, low.y + (high.y - low.y)*li.fr);
+}
+
+// PLAIN = no hop of the tile has a pitch map or formant processing: then Prediction.input is the input spectrum
+// itself and Prediction.energy its squared magnitude (signalsmith-stretch.h:676-685,:708-710), so pass A is skipped.
+template <int CH, bool PLAIN>
+struct RecordSource {
+	const DevBatch &d;
+	const HopDesc &hd;
+	int s, k, sg, M;
+	const float2 *in0; // channel 0 input row; channel rows are `pitch` apart (tile buffer: Mp, carried state: M)
+	int pitch;
+	__device__ RecordSource(const DevBatch &d_, const HopDesc &hd_, int s_, int k_, int sg_) : d(d_), hd(hd_), s(s_), k(k_), sg(sg_), M(d_.M) {
+		in0 = inputRow(d, hd, s, sg, 0);
+		pitch = (hd.inSrc >= 0) ? d.Mp : d.M;
+	}
+	__device__ __forceinline__ const float2 *inRow(int c) const { return in0 + (size_t)c*pitch; }
+	__device__ __forceinline__ float2 P(int c, int b) const { return PLAIN ? in0[(size_t)c*pitch + b] : d.P[rowOf(d, s, k, c) + b]; }
+	__device__ __forceinline__ float E(int c, int b, float2 p) const { return PLAIN ? cnorm(p) : d.E[rowOf(d, s, k, c) + b]; }
+	__device__ __forceinline__ float2 mapAt(int b) const {
+		return (!PLAIN && (hd.flags & HOP_MAPPED)) ? d.map[((size_t)s*d.T + k)*M + b] : make_float2(float(b), 1.0f);
+	}
+};
+
+// coefficient multiplying the previous hop's final output at bin bx (bx = b+1 or b+L), see the record description
+template <int CH, bool PLAIN>
+__device__ __forceinline__ float2 twistAt(const RecordSource<CH, PLAIN> &src, int mc, int bx, bool rotate, const float2 *in,
+                                          const float2 *pv, const float *EprevRow, const float2 *inPrevHop, float tfDown, float stepMul) {
+	const DevBatch &d = src.d;
+	const int M = src.M;
+	const float2 mp = src.mapAt(bx);
+	const LerpIndex li = lerpIndex(mp.x);
+	const bool loIn = li.lo >= 0 && li.lo < M, hiIn = li.lo + 1 >= 0 && li.lo + 1 < M;
+	const float2 rotLo = (rotate && loIn) ? d.rot[li.lo] : make_float2(1.f, 0.f);
+	float2 Q = cmul(bandAt(pv, li.lo, M), rotLo);
+	if (li.fr != 0.0f) {
+		const float2 rotHi = (rotate && hiIn) ? d.rot[li.lo + 1] : make_float2(1.f, 0.f);
+		float2 pvHi = cmul(bandAt(pv, li.lo + 1, M), rotHi);
+		Q = make_float2(Q.x + (pvHi.x - Q.x)*li.fr, Q.y + (pvHi.y - Q.y)*li.fr);
+	}
+	const float2 rotB = rotate ? d.rot[bx] : make_float2(1.f, 0.f);
+	const float2 Px = src.P(mc, bx);
+	const float2 TW = cmul(rotB, cmulc(Px, Q));
+	const float eNow = src.E(mc, bx, Px);
+	const float ePrev = (PLAIN && inPrevHop) ? cnorm(inPrevHop[bx]) : EprevRow[bx];
+	const float den = fmaxf(ePrev, eNow) + 1e-15f; // :716
+	const float2 down = cmulc(Px, lerpBandFast(in, lerpIndex(mp.x - stepMul*tfDown), M));
+	const float2 r = cmulc(TW, down);
+	const float inv = 1.0f/den;
+	return make_float2(r.x*inv, r.y*inv);
+}
+
+template <int CH, bool PLAIN>
+__global__ __launch_bounds__(256) void kPredictB(DevBatch d, int sBase, int hopBase) {
+	constexpr int NF = 9 + 3*CH, NCH = (NF + 3)/4;
+	const int t = blockIdx.x*blockDim.x + threadIdx.x;
+	const int kq = blockIdx.y, s = blockIdx.z, sg = sBase + s;
+	const int M = d.M, L = d.L;
+	const int nh = d.nHops[s];
+	if (t >= M + d.lag*(d.T - 1)) return;
+	float4 *rec = d.REC + ((size_t)s*d.recSteps + t)*(size_t)d.recPitch + 4*kq;
+	// which of the 4 lanes of this thread's 64-byte lines carry a record
+	bool validAny = false;
+#pragma unroll
+	for (int i = 0; i < 4; ++i) {
+		const int k = 4*kq + i, b = t - d.lag*k;
+		validAny = validAny || (k < nh && b >= 0 && b < M);
+	}
+	if (!validAny) return;
+#pragma unroll
+	for (int i = 0; i < 4; ++i) {
+		const int k = 4*kq + i;
+		const int b = t - d.lag*k;
+		float f[NCH*4];
+#pragma unroll
+		for (int j = 0; j < NCH*4; ++j) f[j] = 0.0f;
+		if (k < nh && b >= 0 && b < M) {
+			const HopDesc hd = d.hops[(size_t)sg*d.hopStride + hopBase + k];
+			const bool rotate = hd.flags & HOP_NEW_SPECTRUM, randomTf = hd.flags & HOP_RANDOM_TF;
+			const RecordSource<CH, PLAIN> src(d, hd, s, k, sg);
+			float2 p[CH];
+			float e[CH];
+#pragma unroll
+			for (int c = 0; c < CH; ++c) {
+				p[c] = src.P(c, b);
+				e[c] = src.E(c, b, p[c]);
+			}
+			int mc = 0; // maximum-energy channel, first maximum wins (:729-737)
+			float eMax = e[0];
+#pragma unroll
+			for (int c = 1; c < CH; ++c) {
+				if (e[c] > eMax) { mc = c; eMax = e[c]; }
+			}
+			float2 Pm = p[0];
+#pragma unroll
+			for (int c = 1; c < CH; ++c) if (c == mc) Pm = p[c];
+			const float2 *in = src.inRow(mc);
+			const float2 *pv = prevRow(d, hd, s, k, sg, mc);
+			// Prediction.energy of the previous hop: the carried state for the tile's first hop, else hop k-1's
+			const float *EprevRow = (k == 0) ? d.stEnergy + stateRow(d, sg, mc) : (PLAIN ? nullptr : d.E + rowOf(d, s, k - 1, mc));
+			const float2 *inPrevHop = nullptr;
+			if (PLAIN && k > 0) {
+				const HopDesc hp = d.hops[(size_t)sg*d.hopStride + hopBase + k - 1];
+				inPrevHop = inputRow(d, hp, s, sg, mc);
+			}
+			const float2 mp = src.mapAt(b);
+			float tfUp = hd.timeFactor, tfDn = hd.timeFactor;
+			if (randomTf) { // uniform(4 - tf, tf): one draw per bin and direction (:640,:749,:769)
+				const float lo = 4.0f - hd.timeFactor, span = hd.timeFactor - lo;
+				tfUp = lo + span*hashUniform(hd.seed, b, 0);
+				tfDn = lo + span*hashUniform(hd.seed, b, 1);
+			}
+			if (b > 0) {
+				float2 A = cmulc(Pm, lerpBandFast(in, lerpIndex(mp.x - tfUp), M));
+				f[0] = A.x; f[1] = A.y;
+			}
+			if (b >= L) {
+				float2 B = cmulc(Pm, lerpBandFast(in, lerpIndex(mp.x - L*tfUp), M));
+				f[2] = B.x; f[3] = B.y;
+			}
+			if (b < M - 1) {
+				float2 Cc = twistAt<CH, PLAIN>(src, mc, b + 1, rotate, in, pv, EprevRow, inPrevHop, tfDn, 1.0f);
+				f[4] = Cc.x; f[5] = Cc.y;
+			}
+			if (b < M - L) {
+				float2 Dc = twistAt<CH, PLAIN>(src, mc, b + L, rotate, in, pv, EprevRow, inPrevHop, tfDn, float(L));
+				f[6] = Dc.x; f[7] = Dc.y;
+			}
+			f[8] = __int_as_float(mc);
+#pragma unroll
+			for (int c = 0; c < CH; ++c) {
+				f[9 + 3*c] = p[c].x; f[10 + 3*c] = p[c].y;
+				f[11 + 3*c] = sqrtf(e[c]);
+			}
 		}
+		// one 16-byte store per chunk; the four lanes (i = 0..3) of a thread complete full 64-byte lines
+#pragma unroll
+		for (int j = 0; j < NCH; ++j) rec[j*64 + i] = make_float4(f[4*j], f[4*j + 1], f[4*j + 2], f[4*j + 3]);
 	}
 }
 
@@ -530,130 +870,128 @@ __global__ __launch_bounds__(256) void kPredict(DevBatch d, int sBase, int hopBa
 // Hop k at bin b needs hop k's own outputs at b-1 and b-L, and hop k-1's FINAL outputs at b+1 and b+L
 // (they enter through the preliminary prediction of hop k); lag >= L+1 guarantees they exist.  Outputs of the
 // last `ringSlots` bins of every lane live in an LDS ring that the next lane reads; lane 0 reads the carried
-// Band.output state, staged through LDS 64 bins at a time with one coalesced load per channel.
+// Band.output state, staged through LDS 64 bins at a time with one coalesced load per channel.  The per-step
+// records are prefetched PD steps ahead with fully coalesced 1-KiB wave loads, so no global-memory latency sits
+// on the serial path.
 // ------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float2 makeOutput(float2 phase, float2 input, float energy) { // :596-603
+__device__ __forceinline__ float2 makeOutput(float2 phase, float2 input, float sqrtEnergy) { // :596-603
 	float n = cnorm(phase);
 	if (n <= 1e-15f) {
 		phase = input;
 		n = cnorm(input) + 1e-15f;
 	}
-	float g = sqrtf(energy)*__builtin_amdgcn_rsqf(n);
+	float g = sqrtEnergy*__builtin_amdgcn_rsqf(n);
 	return cscale(phase, g);
 }
 
 template <int CH>
 __global__ __launch_bounds__(64) void kChain(DevBatch d, int sBase, int hopBase) {
+	constexpr int NF = 9 + 3*CH, NCH = (NF + 3)/4;
+	constexpr int PD = (CH <= 2) ? 4 : ((CH <= 4) ? 2 : 1); // prefetch depth (register budget)
 	extern __shared__ __attribute__((aligned(16))) unsigned char smemRaw[];
 	const int R = d.ringSlots, Rm = R - 1;
-	float2 *ring = reinterpret_cast<float2 *>(smemRaw);   // [CH][R][64]
-	float2 *stage = ring + (size_t)CH*R*64;                // [CH][128]: carried Band.output of the previous tile
+	float2 *lds = reinterpret_cast<float2 *>(smemRaw); // ring [CH][R][64], then stage [CH][128]
+	const int stageBase = CH*R*64;                      // carried Band.output of the previous tile, 128-bin window
 
 	const int s = blockIdx.x, sg = sBase + s, k = threadIdx.x;
 	const int nh = d.nHops[s];
 	if (nh == 0) return;
 	const int M = d.M, L = d.L, lag = d.lag;
 	const bool active = k < nh;
-	const bool isLast = (k == nh - 1);
-	const HopDesc hd = d.hops[(size_t)sg*d.hopStride + hopBase + (active ? k : 0)];
-	const bool randomTf = hd.flags & HOP_RANDOM_TF;
+	const float4 *rec = d.REC + (size_t)s*d.recSteps*(size_t)d.recPitch + k;
+	const size_t recPitch = d.recPitch;
+	float2 *OUT = d.OUT + rowOf(d, s, active ? k : 0, 0);
+	float2 *dump = d.dump + (size_t)s*CH*64 + k; // where lanes outside their bin range park their stores
+	const float2 *stOut = d.stOut + stateRow(d, sg, 0);
 
-	const size_t row0 = rowOf(d, s, active ? k : 0, 0);
-	const float2 *P = d.P + row0, *Sx = d.Sx + row0, *Tx = d.Tx + row0, *TW = d.TW + row0;
-	const float2 *Sdn = (randomTf ? d.Sdn : d.Sx) + row0, *Tdn = (randomTf ? d.Tdn : d.Tx) + row0;
-	const float *E = d.E + row0;
-	const float *Eprev = (k == 0) ? d.stEnergy + stateRow(d, sg, 0) : d.E + rowOf(d, s, (active ? k : 1) - 1, 0);
-	float2 *OUT = d.OUT + row0;
-	float2 *stOut = d.stOut + stateRow(d, sg, 0);
-
-	// prologue: stage bins [0,128) of the carried output
-	for (int c = 0; c < CH; ++c) {
-		stage[c*128 + k] = (k < M) ? stOut[(size_t)c*M + k] : make_float2(0.f, 0.f);
-		stage[c*128 + 64 + k] = (64 + k < M) ? stOut[(size_t)c*M + 64 + k] : make_float2(0.f, 0.f);
+	for (int i = k; i < CH*R*64; i += 64) lds[i] = make_float2(0.f, 0.f);
+	for (int c = 0; c < CH; ++c) { // prologue: stage bins [0,128) of the carried output
+		lds[stageBase + c*128 + k] = (k < M) ? stOut[(size_t)c*M + k] : make_float2(0.f, 0.f);
+		lds[stageBase + c*128 + 64 + k] = (64 + k < M) ? stOut[(size_t)c*M + 64 + k] : make_float2(0.f, 0.f);
 	}
 	float2 pf[CH];
-#pragma unroll
-	for (int c = 0; c < CH; ++c) pf[c] = make_float2(0.f, 0.f);
 	float2 own1[CH]; // this lane's outputs at bin b-1
 #pragma unroll
-	for (int c = 0; c < CH; ++c) own1[c] = make_float2(0.f, 0.f);
-	__syncthreads();
+	for (int c = 0; c < CH; ++c) { pf[c] = make_float2(0.f, 0.f); own1[c] = make_float2(0.f, 0.f); }
 
 	const int steps = M + lag*(nh - 1);
-	for (int t = 0; t < steps; ++t) {
-		if ((t & 63) == 0) {
-			// bins [t+64, t+128) were fetched 64 steps ago: publish them, then fetch [t+128, t+192)
-			if (t > 0) {
+	float4 q[PD][NCH];
 #pragma unroll
-				for (int c = 0; c < CH; ++c) stage[c*128 + ((t + 64 + k) & 127)] = pf[c];
-			}
-			const int bb = t + 128 + k;
+	for (int u = 0; u < PD; ++u) {
 #pragma unroll
-			for (int c = 0; c < CH; ++c) pf[c] = (bb < M) ? stOut[(size_t)c*M + bb] : make_float2(0.f, 0.f);
-			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-			__builtin_amdgcn_wave_barrier();
-			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+		for (int j = 0; j < NCH; ++j) q[u][j] = rec[(size_t)u*recPitch + j*64];
+	}
+	__syncthreads();
+
+	const int chunks = (steps + 63) >> 6; // REC is padded, so running to the end of the last 64-step chunk is safe
+	for (int ch = 0; ch < chunks; ++ch) {
+		const int tb = ch << 6;
+		// bins [tb+64, tb+128) were fetched one chunk ago: publish them, then fetch [tb+128, tb+192)
+		if (ch > 0) {
+#pragma unroll
+			for (int c = 0; c < CH; ++c) lds[stageBase + c*128 + ((tb + 64 + k) & 127)] = pf[c];
 		}
-		const int b = t - lag*k;
-		if (active && b >= 0 && b < M) {
-			float e[CH];
-			float2 p[CH];
+		{
+			const int bb = tb + 128 + k;
+			const int bc = (bb < M) ? bb : M - 1;
 #pragma unroll
 			for (int c = 0; c < CH; ++c) {
-				e[c] = E[(size_t)c*M + b];
-				p[c] = P[(size_t)c*M + b];
-			}
-			int mc = 0; // maximum-energy channel, first maximum wins (:729-737)
-			float eMax = e[0];
-#pragma unroll
-			for (int c = 1; c < CH; ++c) {
-				if (e[c] > eMax) { mc = c; eMax = e[c]; }
-			}
-			const size_t mo = (size_t)mc*M;
-			float2 pm = p[0], o1 = own1[0];
-#pragma unroll
-			for (int c = 1; c < CH; ++c) {
-				if (c == mc) { pm = p[c]; o1 = own1[c]; }
-			}
-			float2 phi = make_float2(0.f, 0.f);
-			if (b > 0) phi = cmul(o1, Sx[mo + b]); // :748-754
-			if (b >= L) { // :756-762
-				float2 oL = ring[((size_t)mc*R + ((b - L) & Rm))*64 + k];
-				phi = cadd(phi, cmul(oL, Tx[mo + b]));
-			}
-			if (b < M - 1) { // :765-774: bin b+1 still holds this hop's preliminary prediction
-				const int b1 = b + 1;
-				float2 po = (k == 0) ? stage[mc*128 + (b1 & 127)] : ring[((size_t)mc*R + (b1 & Rm))*64 + k - 1];
-				float den = fmaxf(Eprev[mo + b1], E[mo + b1]) + 1e-15f; // :716
-				float2 pre = cscale(cmul(po, TW[mo + b1]), __builtin_amdgcn_rcpf(den));
-				phi = cadd(phi, cmulc(pre, Sdn[mo + b1]));
-			}
-			if (b < M - L) { // :776-785
-				const int bL = b + L;
-				float2 po = (k == 0) ? stage[mc*128 + (bL & 127)] : ring[((size_t)mc*R + (bL & Rm))*64 + k - 1];
-				float den = fmaxf(Eprev[mo + bL], E[mo + bL]) + 1e-15f;
-				float2 pre = cscale(cmul(po, TW[mo + bL]), __builtin_amdgcn_rcpf(den));
-				phi = cadd(phi, cmulc(pre, Tdn[mo + bL]));
-			}
-			const float2 om = makeOutput(phi, pm, eMax); // :788
-#pragma unroll
-			for (int c = 0; c < CH; ++c) {
-				float2 oc;
-				if (c == mc) {
-					oc = om;
-				} else { // all other channels are locked in phase to the maximum channel, :791-800
-					float2 tw = cmulc(p[c], pm);
-					oc = makeOutput(cmul(om, tw), p[c], e[c]);
-				}
-				own1[c] = oc;
-				ring[((size_t)c*R + (b & Rm))*64 + k] = oc;
-				OUT[(size_t)c*M + b] = oc;
-				if (isLast) stOut[(size_t)c*M + b] = oc;
+				float2 v = stOut[(size_t)c*M + bc];
+				pf[c] = (bb < M) ? v : make_float2(0.f, 0.f);
 			}
 		}
 		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 		__builtin_amdgcn_wave_barrier();
 		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+		for (int i = 0; i < 64/PD; ++i) {
+#pragma unroll
+			for (int u = 0; u < PD; ++u) {
+				const int t = tb + i*PD + u;
+				float f[NCH*4];
+#pragma unroll
+				for (int j = 0; j < NCH; ++j) { f[4*j] = q[u][j].x; f[4*j + 1] = q[u][j].y; f[4*j + 2] = q[u][j].z; f[4*j + 3] = q[u][j].w; }
+				const int b = t - lag*k;
+				const bool valid = active && b >= 0 && b < M;
+				int mc = __float_as_int(f[8]);
+				mc = (mc < 0) ? 0 : ((mc > CH - 1) ? CH - 1 : mc); // records of out-of-range steps are not initialised
+				float2 o1 = own1[0], pm = make_float2(f[9], f[10]);
+				float sm = f[11];
+#pragma unroll
+				for (int c = 1; c < CH; ++c) {
+					if (c == mc) { o1 = own1[c]; pm = make_float2(f[9 + 3*c], f[10 + 3*c]); sm = f[11 + 3*c]; }
+				}
+				const int ringRow = mc*R;
+				const float2 oL = lds[(ringRow + ((b - L) & Rm))*64 + k];
+				const int a1 = (k == 0) ? stageBase + mc*128 + ((b + 1) & 127) : (ringRow + ((b + 1) & Rm))*64 + k - 1;
+				const int aL = (k == 0) ? stageBase + mc*128 + ((b + L) & 127) : (ringRow + ((b + L) & Rm))*64 + k - 1;
+				const float2 p1 = lds[a1];
+				const float2 pL = lds[aL];
+				float2 phi = cmul(oL, make_float2(f[2], f[3]));
+				phi = cadd(phi, cmul(p1, make_float2(f[4], f[5])));
+				phi = cadd(phi, cmul(pL, make_float2(f[6], f[7])));
+				phi = cadd(phi, cmul(o1, make_float2(f[0], f[1])));
+				const float2 om = makeOutput(phi, pm, sm); // :788
+#pragma unroll
+				for (int c = 0; c < CH; ++c) {
+					const float2 pc = make_float2(f[9 + 3*c], f[10 + 3*c]);
+					float2 oc = makeOutput(cmul(om, cmulc(pc, pm)), pc, f[11 + 3*c]); // channel lock, :791-800
+					if (c == mc) oc = om;
+					if (!valid) oc = make_float2(0.f, 0.f);
+					own1[c] = oc;
+					lds[(c*R + (b & Rm))*64 + k] = oc;
+					float2 *dst = valid ? OUT + ((size_t)c*d.Mp + b) : dump + c*64;
+					*dst = oc;
+				}
+				// refill this slot for step t + PD only now: the old contents are dead, so the new load can reuse
+				// the same registers and nothing has to be copied (or waited for) at the loop back-edge
+#pragma unroll
+				for (int j = 0; j < NCH; ++j) q[u][j] = rec[(size_t)(t + PD)*recPitch + j*64];
+				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+				__builtin_amdgcn_wave_barrier();
+				__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+			}
+		}
 	}
 }
 
@@ -748,7 +1086,12 @@ __global__ __launch_bounds__(256) void kCarryState(DevBatch d, int sBase, int ho
 		d.stInput[stateRow(d, sg, c) + b] = v;
 		d.stPrev[stateRow(d, sg, c) + b] = v;
 	}
-	d.stEnergy[stateRow(d, sg, c) + b] = d.E[rowOf(d, s, nh - 1, c) + b];
+	{
+		const HopDesc hl = d.hops[(size_t)sg*d.hopStride + hopBase + nh - 1];
+		const bool plain = !(hl.flags & (HOP_MAPPED | HOP_FORMANTS));
+		d.stEnergy[stateRow(d, sg, c) + b] = plain ? cnorm(inputRow(d, hl, s, sg, c)[b]) : d.E[rowOf(d, s, nh - 1, c) + b];
+	}
+	d.stOut[stateRow(d, sg, c) + b] = d.OUT[rowOf(d, s, nh - 1, c) + b]; // Band.output after the tile's last hop
 	if (b == 0 && c == 0) {
 		float w = d.stFreq[2*sg], wt = d.stFreq[2*sg + 1];
 		bool any = false;
@@ -858,11 +1201,15 @@ __global__ __launch_bounds__(256) void kAddPreRoll(DevBatch d, const float *__re
 static inline int divUp(int a, int b) { return (a + b - 1)/b; }
 
 void launchEnergy(const DevBatch &d, const IoArgs &io, int sBase, int nStreams, float *energyOut, hipStream_t st) {
-	hipLaunchKernelGGL(kEnergy, dim3(nStreams), dim3(256), 256*sizeof(float), st, d, io, sBase, energyOut);
+	hipLaunchKernelGGL(kEnergy, dim3(nStreams, kEnergyParts), dim3(256), 256*sizeof(float), st, d, io, sBase, energyOut);
 }
 void launchAnalyse(const DevBatch &d, const IoArgs &io, int sBase, int nStreams, int hopBase, int tileHops, hipStream_t st) {
+	const dim3 grid(tileHops, d.C*2, nStreams);
+	const size_t fastLds = ((size_t)d.M + d.M/16)*sizeof(float2);
+	if (d.M == 256*12) { hipLaunchKernelGGL(kAnalyseFast<12>, grid, dim3(256), fastLds, st, d, io, sBase, hopBase); return; }
+	if (d.M == 256*20) { hipLaunchKernelGGL(kAnalyseFast<20>, grid, dim3(320), fastLds, st, d, io, sBase, hopBase); return; }
 	size_t lds = 2*(size_t)d.M*sizeof(float2);
-	hipLaunchKernelGGL(kAnalyse, dim3(tileHops, d.C*2, nStreams), dim3(256), lds, st, d, io, sBase, hopBase);
+	hipLaunchKernelGGL(kAnalyse, grid, dim3(256), lds, st, d, io, sBase, hopBase);
 }
 void launchFeedMap(const DevBatch &d, int sBase, int nStreams, int hopBase, int tileHops, hipStream_t st) {
 	size_t lds = 2*(size_t)d.M*sizeof(float) + ((size_t)d.M/2 + 2)*sizeof(float2) + 16;
@@ -872,8 +1219,27 @@ void launchFeedFormant(const DevBatch &d, int sBase, int nStreams, int hopBase, 
 	size_t lds = ((size_t)d.M + 2)*sizeof(float);
 	hipLaunchKernelGGL(kFeedFormant, dim3(tileHops, nStreams), dim3(64), lds, st, d, sBase, hopBase);
 }
-void launchPredict(const DevBatch &d, int sBase, int nStreams, int hopBase, int tileHops, hipStream_t st) {
-	hipLaunchKernelGGL(kPredict, dim3(divUp(d.M, 256), tileHops, nStreams), dim3(256), 0, st, d, sBase, hopBase);
+template <int CH>
+static void launchPredictT(const DevBatch &d, int sBase, int nStreams, int hopBase, int tileHops, bool plain, hipStream_t st) {
+	const dim3 grid(divUp(d.M + d.lag*(d.T - 1), 256), divUp(tileHops, 4), nStreams);
+	if (plain) {
+		hipLaunchKernelGGL((kPredictB<CH, true>), grid, dim3(256), 0, st, d, sBase, hopBase);
+	} else {
+		hipLaunchKernelGGL(kPredictA, dim3(divUp(d.M, 256), tileHops, nStreams), dim3(256), 0, st, d, sBase, hopBase);
+		hipLaunchKernelGGL((kPredictB<CH, false>), grid, dim3(256), 0, st, d, sBase, hopBase);
+	}
+}
+void launchPredict(const DevBatch &d, int sBase, int nStreams, int hopBase, int tileHops, bool plain, hipStream_t st) {
+	switch (d.C) {
+	case 1: launchPredictT<1>(d, sBase, nStreams, hopBase, tileHops, plain, st); break;
+	case 2: launchPredictT<2>(d, sBase, nStreams, hopBase, tileHops, plain, st); break;
+	case 3: launchPredictT<3>(d, sBase, nStreams, hopBase, tileHops, plain, st); break;
+	case 4: launchPredictT<4>(d, sBase, nStreams, hopBase, tileHops, plain, st); break;
+	case 5: launchPredictT<5>(d, sBase, nStreams, hopBase, tileHops, plain, st); break;
+	case 6: launchPredictT<6>(d, sBase, nStreams, hopBase, tileHops, plain, st); break;
+	case 7: launchPredictT<7>(d, sBase, nStreams, hopBase, tileHops, plain, st); break;
+	default: launchPredictT<8>(d, sBase, nStreams, hopBase, tileHops, plain, st); break;
+	}
 }
 template <int CH>
 static void launchChainT(const DevBatch &d, int sBase, int nStreams, int hopBase, hipStream_t st) {
@@ -893,8 +1259,12 @@ void launchChain(const DevBatch &d, int sBase, int nStreams, int hopBase, hipStr
 	}
 }
 void launchSynth(const DevBatch &d, int sBase, int nStreams, int hopBase, int tileHops, hipStream_t st) {
+	const dim3 grid(tileHops, d.C, nStreams);
+	const size_t fastLds = ((size_t)d.M + d.M/16)*sizeof(float2);
+	if (d.M == 256*12) { hipLaunchKernelGGL(kSynthFast<12>, grid, dim3(256), fastLds, st, d, sBase, hopBase); return; }
+	if (d.M == 256*20) { hipLaunchKernelGGL(kSynthFast<20>, grid, dim3(320), fastLds, st, d, sBase, hopBase); return; }
 	size_t lds = 2*(size_t)d.M*sizeof(float2);
-	hipLaunchKernelGGL(kSynth, dim3(tileHops, d.C, nStreams), dim3(256), lds, st, d, sBase, hopBase);
+	hipLaunchKernelGGL(kSynth, grid, dim3(256), lds, st, d, sBase, hopBase);
 }
 void launchEmit(const DevBatch &d, const IoArgs &io, int sBase, int nStreams, int tileIndex, int maxSpan, hipStream_t st) {
 	hipLaunchKernelGGL(kEmit, dim3(divUp(maxSpan + d.carryLen, 256), d.C, nStreams), dim3(256), 0, st, d, io, sBase, tileIndex);

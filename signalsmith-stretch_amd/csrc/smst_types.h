@@ -7,6 +7,7 @@ namespace smst {
 constexpr int kTileHops = 64;   // hops per tile = lanes of the wave that runs the bin recurrence
 constexpr int kMaxChannels = 8; // compile-time bound of the chain kernel's per-lane channel arrays
 constexpr int kMaxFftPasses = 12;
+constexpr int kEnergyParts = 16; // partial sums per stream in the silence-gate reduction
 
 // Hop flags (reference: signalsmith-stretch.h:299-313)
 enum : unsigned {

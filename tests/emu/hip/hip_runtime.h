@@ -21,6 +21,10 @@
 
 struct float2 { float x, y; };
 static inline float2 make_float2(float x, float y) { float2 r; r.x = x; r.y = y; return r; }
+struct float4 { float x, y, z, w; };
+static inline float4 make_float4(float x, float y, float z, float w) { float4 r; r.x = x; r.y = y; r.z = z; r.w = w; return r; }
+static inline float __int_as_float(int v) { float f; std::memcpy(&f, &v, 4); return f; }
+static inline int __float_as_int(float f) { int v; std::memcpy(&v, &f, 4); return v; }
 struct dim3 {
 	unsigned x, y, z;
 	dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}

