@@ -16,6 +16,7 @@ struct DevBatch {
 	int hopStride, emitStride;    // row pitch of the per-call hop / emit tables
 	int mapTableLen;
 	int histCur, carryCur;        // which half of the double buffers is current
+	int debugMode;                // SMST_DEBUG_MODE experiments (0 = product behaviour)
 	FftPlan plan;
 	// constant tables
 	const float2 *twH;     // e^{-2 pi i j / H}
@@ -67,7 +68,8 @@ void launchPredict(const DevBatch &d, int sBase, int nStreams, int hopBase, int 
 void launchChain(const DevBatch &d, int sBase, int nStreams, int hopBase, hipStream_t st);
 void launchSynth(const DevBatch &d, int sBase, int nStreams, int hopBase, int tileHops, hipStream_t st);
 void launchEmit(const DevBatch &d, const IoArgs &io, int sBase, int nStreams, int tileIndex, int maxSpan, hipStream_t st);
-void launchCarryState(const DevBatch &d, int sBase, int nStreams, int hopBase, hipStream_t st);
+void launchCarryFeed(const DevBatch &d, int sBase, int nStreams, int hopBase, hipStream_t st);
+void launchCarryOut(const DevBatch &d, int sBase, int nStreams, hipStream_t st);
 void launchHistory(const DevBatch &d, const IoArgs &io, hipStream_t st);
 void launchPassThrough(const DevBatch &d, const IoArgs &io, const int *passFlags, int maxOut, hipStream_t st);
 void launchSeekHistory(const DevBatch &d, const IoArgs &io, const int *seekFlags, hipStream_t st);

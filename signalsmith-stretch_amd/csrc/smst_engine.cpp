@@ -93,6 +93,20 @@ Batch::Batch(int streams, int channels, int block, int interval, bool splitCompu
 	if (S < 1 || C < 1 || C > kMaxChannels || B < 4 || I < 1 || I > B) throw Error("invalid configuration (need 1..8 channels, interval <= block)");
 	SMST_HIP(hipSetDevice(dev));
 	SMST_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+	{ // the recurrence is latency-bound with few waves: give its stream the highest priority so its workgroups are
+	  // dispatched ahead of the bulk kernels' when they share the machine
+		int lo = 0, hi = 0;
+		SMST_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+		SMST_HIP(hipStreamCreateWithPriority(&stChain, hipStreamNonBlocking, hi));
+	}
+	SMST_HIP(hipStreamCreateWithFlags(&stSynth, hipStreamNonBlocking));
+	SMST_HIP(hipEventCreateWithFlags(&evStart, hipEventDisableTiming));
+	for (int i = 0; i < 2; ++i) {
+		SMST_HIP(hipEventCreateWithFlags(&evFeed[i], hipEventDisableTiming));
+		SMST_HIP(hipEventCreateWithFlags(&evChain[i], hipEventDisableTiming));
+		SMST_HIP(hipEventCreateWithFlags(&evSynth[i], hipEventDisableTiming));
+	}
+	if (const char *env = std::getenv("SMST_NO_OVERLAP")) overlap = atoi(env) == 0;
 	N = 2*fastSizeAbove((B + 1)/2);
 	M = N/2;
 	if ((size_t)M*sizeof(float2)*2 > 150*1024) throw Error("block too long for the LDS-resident FFT (bands*16 bytes must fit 150 KiB)");
@@ -110,6 +124,8 @@ Batch::Batch(int streams, int channels, int block, int interval, bool splitCompu
 	if (ring > 64) throw Error("interval too small relative to the FFT size (vertical step too long)");
 	d.plan = makePlan(M, N);
 	d.mapTableLen = 0;
+	d.debugMode = 0;
+	if (const char *env = std::getenv("SMST_DEBUG_MODE")) d.debugMode = atoi(env);
 
 	// constant tables
 	std::vector<float2> tw(M), half(M), rot(M);
@@ -217,14 +233,24 @@ Batch::Batch(int streams, int channels, int block, int interval, bool splitCompu
 Batch::~Batch() {
 	hipSetDevice(dev);
 	if (st) hipStreamSynchronize(st);
+	if (stChain) hipStreamSynchronize(stChain);
+	if (stSynth) hipStreamSynchronize(stSynth);
 	for (void *p : allocations) hipFree(p);
+	if (evStart) hipEventDestroy(evStart);
+	for (int i = 0; i < 2; ++i) {
+		if (evFeed[i]) hipEventDestroy(evFeed[i]);
+		if (evChain[i]) hipEventDestroy(evChain[i]);
+		if (evSynth[i]) hipEventDestroy(evSynth[i]);
+	}
+	if (stChain) hipStreamDestroy(stChain);
+	if (stSynth) hipStreamDestroy(stSynth);
 	if (st) hipStreamDestroy(st);
 }
 
 void Batch::allocateWorkspace() {
 	// Per (stream, hop, channel): 4 complex rows + 1 float row of M bins + one B-sample frame, plus the skewed records.
 	// Sub-batch the streams so the tile workspace stays under a budget (default 48 GiB of the 288 GB HBM).
-	double budgetGiB = 48;
+	double budgetGiB = 24; // per workspace; there are two
 	if (const char *env = std::getenv("SMST_WORKSPACE_GIB")) budgetGiB = std::max(0.25, atof(env));
 	const size_t recChunks = (9 + 3*(size_t)C + 3)/4;
 	d.recSteps = ((M + d.lag*(d.T - 1) + 63)/64)*64 + 8;
@@ -237,20 +263,25 @@ void Batch::allocateWorkspace() {
 	if (maxStreams < 1) maxStreams = 1;
 	subS = int(std::min<size_t>(S, maxStreams));
 	const size_t rows = (size_t)subS*d.T*C*d.Mp;
-	d.Xcur = devAlloc<float2>(rows);
-	d.Xprev = devAlloc<float2>(rows);
-	d.P = devAlloc<float2>(rows);
-	d.OUT = devAlloc<float2>(rows);
-	d.REC = devAlloc<float4>((size_t)subS*d.recSteps*d.recPitch);
-	SMST_HIP(hipMemset(d.REC, 0, (size_t)subS*d.recSteps*d.recPitch*sizeof(float4)));
-	d.dump = devAlloc<float2>((size_t)subS*C*64);
-	d.E = devAlloc<float>(rows);
-	d.map = devAlloc<float2>((size_t)subS*d.T*M);
-	d.ratio = devAlloc<float>((size_t)subS*d.T*M);
-	d.esum = devAlloc<float>((size_t)subS*d.T*M);
-	d.est = devAlloc<float>((size_t)subS*d.T*2);
-	d.frames = devAlloc<float>((size_t)subS*d.T*C*B);
-	wsBytes = perStream*subS;
+	// two complete tile workspaces: tile i+1's feed-forward kernels run while tile i is still in the recurrence /
+	// synthesis (the budget above is per workspace)
+	for (int i = 0; i < 2; ++i) {
+		TileBuffers &w = slots[i];
+		w.Xcur = devAlloc<float2>(rows);
+		w.Xprev = devAlloc<float2>(rows);
+		w.P = devAlloc<float2>(rows);
+		w.OUT = devAlloc<float2>(rows);
+		w.REC = devAlloc<float4>((size_t)subS*d.recSteps*d.recPitch);
+		SMST_HIP(hipMemset(w.REC, 0, (size_t)subS*d.recSteps*d.recPitch*sizeof(float4)));
+		w.dump = devAlloc<float2>((size_t)subS*C*64);
+		w.E = devAlloc<float>(rows);
+		w.map = devAlloc<float2>((size_t)subS*d.T*M);
+		w.ratio = devAlloc<float>((size_t)subS*d.T*M);
+		w.esum = devAlloc<float>((size_t)subS*d.T*M);
+		w.est = devAlloc<float>((size_t)subS*d.T*2);
+		w.frames = devAlloc<float>((size_t)subS*d.T*C*B);
+	}
+	wsBytes = 2*perStream*subS;
 }
 
 void Batch::uploadParams() {
@@ -561,29 +592,66 @@ void Batch::process(const float *in, long long inSS, long long inCS, const int *
 	d.emitStride = nTiles;
 
 	const int carryBase = d.carryCur;
+	// Three HIP streams: `st` runs the feed-forward kernels of tile q, `stChain` the recurrence of tile q (a few
+	// hundred waves, instruction-issue bound), `stSynth` synthesis + emission.  Two workspaces alternate, so the bulk
+	// kernels of the next tile fill the machine while the recurrence of the current one is in flight.
+	const bool serial = profiling || !overlap;
+	hipStream_t sF = st, sC = serial ? st : stChain, sS = serial ? st : stSynth;
+	if (!serial) {
+		SMST_HIP(hipEventRecord(evStart, st));
+		SMST_HIP(hipStreamWaitEvent(sC, evStart, 0));
+		SMST_HIP(hipStreamWaitEvent(sS, evStart, 0));
+	}
+	int q = 0;
 	for (int sub = 0; sub < nSub; ++sub) {
 		const int sBase = sub*subS;
 		const int ns = std::min(subS, S - sBase);
-		for (int t = 0; t < nTiles; ++t) {
+		for (int t = 0; t < nTiles; ++t, ++q) {
 			const unsigned char *th = tileHas.data() + (size_t)(sub*nTiles + t)*4;
 			const int hopBase = t*T;
 			const int tileHops = std::min(T, std::max(1, maxHops - hopBase));
+			const int slot = q & 1;
+			const TileBuffers &w = slots[slot];
 			DevBatch dd = d;
+			dd.Xcur = w.Xcur; dd.Xprev = w.Xprev; dd.P = w.P; dd.OUT = w.OUT; dd.REC = w.REC; dd.dump = w.dump; dd.E = w.E;
+			dd.map = w.map; dd.ratio = w.ratio; dd.esum = w.esum; dd.est = w.est; dd.frames = w.frames;
 			dd.carryCur = (carryBase + t) & 1;
 			dd.nHops = dTileInfo + ((size_t)(sub*nTiles + t)*2)*subS;
 			dd.lastNewHop = dd.nHops + subS;
-			if (th[0]) {
-				if (th[3]) timed(timings.analyseMs, [&] { launchAnalyse(dd, io, sBase, ns, hopBase, tileHops, st); if (profiling) ++timings.analyseLaunches; });
-				if (th[1] || th[2]) timed(timings.feedMs, [&] {
-					launchFeedMap(dd, sBase, ns, hopBase, tileHops, st);
-					if (th[2]) launchFeedFormant(dd, sBase, ns, hopBase, tileHops, st);
-				});
-				timed(timings.predictMs, [&] { launchPredict(dd, sBase, ns, hopBase, tileHops, !(th[1] || th[2]), st); if (profiling) ++timings.predictLaunches; });
-				timed(timings.chainMs, [&] { launchChain(dd, sBase, ns, hopBase, st); if (profiling) ++timings.chainLaunches; });
-				timed(timings.synthMs, [&] { launchSynth(dd, sBase, ns, hopBase, tileHops, st); if (profiling) ++timings.synthLaunches; });
+			if (!serial && q >= 2) { // this workspace was last used by tile q-2
+				SMST_HIP(hipStreamWaitEvent(sF, evChain[slot], 0));
+				SMST_HIP(hipStreamWaitEvent(sF, evSynth[slot], 0));
 			}
-			timed(timings.emitMs, [&] { launchEmit(dd, io, sBase, ns, t, maxSpan[(size_t)sub*nTiles + t], st); if (profiling) ++timings.emitLaunches; });
-			if (th[0]) timed(timings.otherMs, [&] { launchCarryState(dd, sBase, ns, hopBase, st); });
+			if (th[0]) {
+				if (th[3]) timed(timings.analyseMs, [&] { launchAnalyse(dd, io, sBase, ns, hopBase, tileHops, sF); if (profiling) ++timings.analyseLaunches; });
+				if (th[1] || th[2]) timed(timings.feedMs, [&] {
+					launchFeedMap(dd, sBase, ns, hopBase, tileHops, sF);
+					if (th[2]) launchFeedFormant(dd, sBase, ns, hopBase, tileHops, sF);
+				});
+				timed(timings.predictMs, [&] { launchPredict(dd, sBase, ns, hopBase, tileHops, !(th[1] || th[2]), sF); if (profiling) ++timings.predictLaunches; });
+				timed(timings.otherMs, [&] { launchCarryFeed(dd, sBase, ns, hopBase, sF); });
+			}
+			if (!serial) {
+				SMST_HIP(hipEventRecord(evFeed[slot], sF));
+				SMST_HIP(hipStreamWaitEvent(sC, evFeed[slot], 0));
+			}
+			if (th[0]) {
+				timed(timings.chainMs, [&] { launchChain(dd, sBase, ns, hopBase, sC); if (profiling) ++timings.chainLaunches; });
+				timed(timings.otherMs, [&] { launchCarryOut(dd, sBase, ns, sC); });
+			}
+			if (!serial) {
+				SMST_HIP(hipEventRecord(evChain[slot], sC));
+				SMST_HIP(hipStreamWaitEvent(sS, evChain[slot], 0));
+			}
+			if (th[0]) timed(timings.synthMs, [&] { launchSynth(dd, sBase, ns, hopBase, tileHops, sS); if (profiling) ++timings.synthLaunches; });
+			timed(timings.emitMs, [&] { launchEmit(dd, io, sBase, ns, t, maxSpan[(size_t)sub*nTiles + t], sS); if (profiling) ++timings.emitLaunches; });
+			if (!serial) SMST_HIP(hipEventRecord(evSynth[slot], sS));
+		}
+	}
+	if (!serial) { // everything the caller can observe is ordered on `st` again
+		for (int i = 0; i < 2 && i < q; ++i) {
+			SMST_HIP(hipStreamWaitEvent(st, evChain[i], 0));
+			SMST_HIP(hipStreamWaitEvent(st, evSynth[i], 0));
 		}
 	}
 	d.carryCur = (carryBase + nTiles) & 1;

@@ -82,7 +82,12 @@ private:
 	int S, C, B, I, N, M, L;
 	bool split;
 	int dev;
-	hipStream_t st = nullptr;
+	hipStream_t st = nullptr;       // feed-forward kernels + everything the caller synchronises on
+	hipStream_t stChain = nullptr;  // the bin recurrence (few waves, latency-bound): overlaps with the bulk kernels
+	hipStream_t stSynth = nullptr;  // synthesis + emission of the previous tile
+	hipEvent_t evStart = nullptr, evFeed[2] = {nullptr, nullptr}, evChain[2] = {nullptr, nullptr}, evSynth[2] = {nullptr, nullptr};
+	struct TileBuffers { float2 *Xcur, *Xprev, *P, *OUT, *dump, *map; float4 *REC; float *E, *ratio, *esum, *est, *frames; } slots[2]{};
+	bool overlap = true;
 	int subS = 0;
 	size_t wsBytes = 0;
 	DevBatch d{};

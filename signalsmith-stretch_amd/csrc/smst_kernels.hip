@@ -775,26 +775,24 @@ __device__ __forceinline__ float2 twistAt(const RecordSource<CH, PLAIN> &src, in
 	return make_float2(r.x*inv, r.y*inv);
 }
 
+// One workgroup = 8 wavefront steps x all 64 hops of a stream.  Reads are coalesced along the bin index (8 lanes
+// per row); the 512 records are transposed through LDS so that the stores to the skewed array are contiguous 1-KiB
+// rows (the scattered 16-byte stores of the first version ran at 1.3 TB/s and dominated the whole pipeline).
 template <int CH, bool PLAIN>
 __global__ __launch_bounds__(256) void kPredictB(DevBatch d, int sBase, int hopBase) {
 	constexpr int NF = 9 + 3*CH, NCH = (NF + 3)/4;
-	const int t = blockIdx.x*blockDim.x + threadIdx.x;
-	const int kq = blockIdx.y, s = blockIdx.z, sg = sBase + s;
+	extern __shared__ __attribute__((aligned(16))) unsigned char smemRaw[];
+	float4 *tile = reinterpret_cast<float4 *>(smemRaw); // [(st*NCH + j)*65 + k]
+	const int s = blockIdx.y, sg = sBase + s;
+	const int T0 = blockIdx.x*8;
 	const int M = d.M, L = d.L;
 	const int nh = d.nHops[s];
-	if (t >= M + d.lag*(d.T - 1)) return;
-	float4 *rec = d.REC + ((size_t)s*d.recSteps + t)*(size_t)d.recPitch + 4*kq;
-	// which of the 4 lanes of this thread's 64-byte lines carry a record
-	bool validAny = false;
+	if (nh == 0 || T0 >= M + d.lag*(nh - 1)) return; // nothing of this stream's wavefront in these steps
+	const int st = threadIdx.x & 7, r = threadIdx.x >> 3;
+	const int t = T0 + st;
 #pragma unroll
-	for (int i = 0; i < 4; ++i) {
-		const int k = 4*kq + i, b = t - d.lag*k;
-		validAny = validAny || (k < nh && b >= 0 && b < M);
-	}
-	if (!validAny) return;
-#pragma unroll
-	for (int i = 0; i < 4; ++i) {
-		const int k = 4*kq + i;
+	for (int half = 0; half < 2; ++half) {
+		const int k = r + 32*half;
 		const int b = t - d.lag*k;
 		float f[NCH*4];
 #pragma unroll
@@ -858,9 +856,17 @@ __global__ __launch_bounds__(256) void kPredictB(DevBatch d, int sBase, int hopB
 				f[11 + 3*c] = sqrtf(e[c]);
 			}
 		}
-		// one 16-byte store per chunk; the four lanes (i = 0..3) of a thread complete full 64-byte lines
 #pragma unroll
-		for (int j = 0; j < NCH; ++j) rec[j*64 + i] = make_float4(f[4*j], f[4*j + 1], f[4*j + 2], f[4*j + 3]);
+		for (int j = 0; j < NCH; ++j) tile[(st*NCH + j)*65 + k] = make_float4(f[4*j], f[4*j + 1], f[4*j + 2], f[4*j + 3]);
+	}
+	__syncthreads();
+	float4 *rec = d.REC + ((size_t)s*d.recSteps + T0)*(size_t)d.recPitch;
+#pragma unroll
+	for (int n = 0; n < 2*NCH; ++n) { // 8*NCH*64 float4 per tile / 256 threads
+		const int idx = threadIdx.x + 256*n;
+		const int row = idx >> 6, k = idx & 63; // row = st*NCH + j
+		const int stw = row/NCH, j = row - stw*NCH;
+		rec[(size_t)stw*d.recPitch + j*64 + k] = tile[row*65 + k];
 	}
 }
 
@@ -896,6 +902,7 @@ __global__ __launch_bounds__(64) void kChain(DevBatch d, int sBase, int hopBase)
 	const int s = blockIdx.x, sg = sBase + s, k = threadIdx.x;
 	const int nh = d.nHops[s];
 	if (nh == 0) return;
+	__builtin_amdgcn_s_setprio(3); // serial path of the whole pipeline: win issue arbitration against co-resident bulk waves
 	const int M = d.M, L = d.L, lag = d.lag;
 	const bool active = k < nh;
 	const float4 *rec = d.REC + (size_t)s*d.recSteps*(size_t)d.recPitch + k;
@@ -1075,7 +1082,7 @@ __global__ __launch_bounds__(256) void kEmit(DevBatch d, IoArgs io, int sBase, i
 // State that outlives a tile: Band.input / Band.prevInput (= input of the last hop that analysed a new
 // spectrum, signalsmith-stretch.h:806-811), Prediction.energy of the last hop (:707), pitch-estimate state.
 // ------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void kCarryState(DevBatch d, int sBase, int hopBase) {
+__global__ __launch_bounds__(256) void kCarryFeed(DevBatch d, int sBase, int hopBase) { // everything that does not depend on the recurrence
 	const int s = blockIdx.z, sg = sBase + s, c = blockIdx.y;
 	const int b = blockIdx.x*blockDim.x + threadIdx.x;
 	const int nh = d.nHops[s];
@@ -1091,7 +1098,6 @@ __global__ __launch_bounds__(256) void kCarryState(DevBatch d, int sBase, int ho
 		const bool plain = !(hl.flags & (HOP_MAPPED | HOP_FORMANTS));
 		d.stEnergy[stateRow(d, sg, c) + b] = plain ? cnorm(inputRow(d, hl, s, sg, c)[b]) : d.E[rowOf(d, s, nh - 1, c) + b];
 	}
-	d.stOut[stateRow(d, sg, c) + b] = d.OUT[rowOf(d, s, nh - 1, c) + b]; // Band.output after the tile's last hop
 	if (b == 0 && c == 0) {
 		float w = d.stFreq[2*sg], wt = d.stFreq[2*sg + 1];
 		bool any = false;
@@ -1104,6 +1110,15 @@ __global__ __launch_bounds__(256) void kCarryState(DevBatch d, int sBase, int ho
 		}
 		if (any) { d.stFreq[2*sg] = w; d.stFreq[2*sg + 1] = wt; }
 	}
+}
+
+// Band.output after the tile's last hop (signalsmith-stretch.h:788-800 leave it in the Band array): runs behind the recurrence
+__global__ __launch_bounds__(256) void kCarryOut(DevBatch d, int sBase) {
+	const int s = blockIdx.z, sg = sBase + s, c = blockIdx.y;
+	const int b = blockIdx.x*blockDim.x + threadIdx.x;
+	const int nh = d.nHops[s];
+	if (nh == 0 || b >= d.M) return;
+	d.stOut[stateRow(d, sg, c) + b] = d.OUT[rowOf(d, s, nh - 1, c) + b];
 }
 
 // Input history for the next call: the last B+I samples of (history ++ this call's input)  (copyInput, :215-229,:418)
@@ -1221,12 +1236,14 @@ void launchFeedFormant(const DevBatch &d, int sBase, int nStreams, int hopBase, 
 }
 template <int CH>
 static void launchPredictT(const DevBatch &d, int sBase, int nStreams, int hopBase, int tileHops, bool plain, hipStream_t st) {
-	const dim3 grid(divUp(d.M + d.lag*(d.T - 1), 256), divUp(tileHops, 4), nStreams);
+	const dim3 grid(divUp(d.M + d.lag*(d.T - 1), 8), nStreams);
+	const size_t lds = (size_t)8*((9 + 3*CH + 3)/4)*65*sizeof(float4);
+	(void)tileHops;
 	if (plain) {
-		hipLaunchKernelGGL((kPredictB<CH, true>), grid, dim3(256), 0, st, d, sBase, hopBase);
+		hipLaunchKernelGGL((kPredictB<CH, true>), grid, dim3(256), lds, st, d, sBase, hopBase);
 	} else {
 		hipLaunchKernelGGL(kPredictA, dim3(divUp(d.M, 256), tileHops, nStreams), dim3(256), 0, st, d, sBase, hopBase);
-		hipLaunchKernelGGL((kPredictB<CH, false>), grid, dim3(256), 0, st, d, sBase, hopBase);
+		hipLaunchKernelGGL((kPredictB<CH, false>), grid, dim3(256), lds, st, d, sBase, hopBase);
 	}
 }
 void launchPredict(const DevBatch &d, int sBase, int nStreams, int hopBase, int tileHops, bool plain, hipStream_t st) {
@@ -1269,8 +1286,11 @@ void launchSynth(const DevBatch &d, int sBase, int nStreams, int hopBase, int ti
 void launchEmit(const DevBatch &d, const IoArgs &io, int sBase, int nStreams, int tileIndex, int maxSpan, hipStream_t st) {
 	hipLaunchKernelGGL(kEmit, dim3(divUp(maxSpan + d.carryLen, 256), d.C, nStreams), dim3(256), 0, st, d, io, sBase, tileIndex);
 }
-void launchCarryState(const DevBatch &d, int sBase, int nStreams, int hopBase, hipStream_t st) {
-	hipLaunchKernelGGL(kCarryState, dim3(divUp(d.M, 256), d.C, nStreams), dim3(256), 0, st, d, sBase, hopBase);
+void launchCarryFeed(const DevBatch &d, int sBase, int nStreams, int hopBase, hipStream_t st) {
+	hipLaunchKernelGGL(kCarryFeed, dim3(divUp(d.M, 256), d.C, nStreams), dim3(256), 0, st, d, sBase, hopBase);
+}
+void launchCarryOut(const DevBatch &d, int sBase, int nStreams, hipStream_t st) {
+	hipLaunchKernelGGL(kCarryOut, dim3(divUp(d.M, 256), d.C, nStreams), dim3(256), 0, st, d, sBase);
 }
 void launchHistory(const DevBatch &d, const IoArgs &io, hipStream_t st) {
 	hipLaunchKernelGGL(kHistory, dim3(divUp(d.histLen, 256), d.C, d.S), dim3(256), 0, st, d, io);

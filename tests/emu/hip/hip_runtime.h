@@ -58,6 +58,9 @@ static inline hipError_t hipSetDevice(int) { return 0; }
 static inline hipError_t hipGetDeviceCount(int *n) { *n = 1; return 0; }
 static inline hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) { *s = (hipStream_t)1; return 0; }
 static inline hipError_t hipStreamSynchronize(hipStream_t) { return 0; }
+static inline hipError_t hipDeviceGetStreamPriorityRange(int *lo, int *hi) { *lo = 0; *hi = 0; return 0; }
+static inline hipError_t hipStreamCreateWithPriority(hipStream_t *s, unsigned, int) { *s = (hipStream_t)1; return 0; }
+#define __builtin_amdgcn_s_setprio(x) ((void)0)
 static inline hipError_t hipStreamDestroy(hipStream_t) { return 0; }
 static inline hipError_t hipMalloc(void **p, size_t n) { *p = std::calloc(n ? n : 1, 1); return *p ? 0 : 2; }
 static inline hipError_t hipFree(void *p) { std::free(p); return 0; }
@@ -66,6 +69,9 @@ static inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMem
 static inline hipError_t hipMemset(void *d, int v, size_t n) { std::memset(d, v, n); return 0; }
 static inline hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t) { std::memset(d, v, n); return 0; }
 static inline hipError_t hipEventCreate(hipEvent_t *e) { *e = nullptr; return 0; }
+#define hipEventDisableTiming 2
+static inline hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned) { *e = nullptr; return 0; }
+static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return 0; }
 static inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return 0; }
 static inline hipError_t hipEventSynchronize(hipEvent_t) { return 0; }
 static inline hipError_t hipEventElapsedTime(float *ms, hipEvent_t, hipEvent_t) { *ms = 0; return 0; }

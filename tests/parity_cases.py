@@ -5,8 +5,10 @@ Every case drives the product through its C ABI (python ctypes mirror of the ref
 TOLERANCE (stated here once).  The whole path is fp32 and the phase recurrence is chaotic (a 1e-7
 relative perturbation of the INPUT changes the reference's own output by 1e-5..1e-2 within 16 hops, more for noise
 and for pitch-mapped material where peak decisions flip).  So the bound is conditioning-aware, as App. D.2 prescribes:
-over every horizon h in HORIZONS (hops), rel-RMS(product, checker) <= max(FLOOR, SELF_FACTOR * max over 3 seeds of rel-RMS(checker on the
-input perturbed by 1e-7 relative, checker)).  FLOOR = 1e-4 covers the fp32 rounding differences of a different FFT
+over every horizon h in HORIZONS (hops), rel-RMS(product, checker) <= max(FLOOR, SELF_FACTOR * max over 3 seeds of
+rel-RMS(checker on the input perturbed by PERTURBATION = 1e-6 relative, checker)).  1e-6 (~8 ulp) is the measured
+rel-RMS difference between our FFT and the reference's on the identity path (test_full_batch_identity: 1.6e-6), i.e.
+the input-equivalent size of "same algorithm, different fp32 rounding".  FLOOR = 1e-4 covers the fp32 rounding differences of a different FFT
 factorisation / FMA contraction when the self-sensitivity is tiny; cases with no phase-vocoder feedback (1.0x
 identity, ring bookkeeping) use TOL_EXACT = 2e-6 instead."""
 import numpy as np
@@ -16,7 +18,8 @@ import scenarios
 
 TOL_EXACT = 2e-6
 FLOOR = 1e-4
-SELF_FACTOR = 10.0
+SELF_FACTOR = 5.0
+PERTURBATION = 1e-6  # ~8 ulp: the size of the rounding difference between two fp32 FFT implementations of this length
 HORIZONS = (6, 12, 24, 48, 1 << 30)
 SELF_SEEDS = (1, 2, 3)
 
@@ -31,7 +34,7 @@ def make(kind, lib, ref, channels, cfg, setup=None, seed=0):
 
 def perturbed(x, seed=1):
     u = np.random.default_rng(seed).uniform(-1, 1, x.shape)
-    return (x*(1 + 1e-7*u)).astype(np.float32)
+    return (x*(1 + PERTURBATION*u)).astype(np.float32)
 
 
 def assert_parity(y, o, o_self, interval, label):
