@@ -596,6 +596,7 @@ void Batch::process(const float *in, long long inSS, long long inCS, const int *
 	// hundred waves, instruction-issue bound), `stSynth` synthesis + emission.  Two workspaces alternate, so the bulk
 	// kernels of the next tile fill the machine while the recurrence of the current one is in flight.
 	const bool serial = profiling || !overlap;
+	const bool noFuse = std::getenv("SMST_NO_FUSE") != nullptr;
 	hipStream_t sF = st, sC = serial ? st : stChain, sS = serial ? st : stSynth;
 	if (!serial) {
 		SMST_HIP(hipEventRecord(evStart, st));
@@ -611,6 +612,8 @@ void Batch::process(const float *in, long long inSS, long long inCS, const int *
 			const int hopBase = t*T;
 			const int tileHops = std::min(T, std::max(1, maxHops - hopBase));
 			const int slot = q & 1;
+			const bool plain = !(th[1] || th[2]);
+			const bool fused = (C <= 2) && !noFuse; // mono/stereo: records stay in LDS (kVocoder)
 			const TileBuffers &w = slots[slot];
 			DevBatch dd = d;
 			dd.Xcur = w.Xcur; dd.Xprev = w.Xprev; dd.P = w.P; dd.OUT = w.OUT; dd.REC = w.REC; dd.dump = w.dump; dd.E = w.E;
@@ -622,22 +625,36 @@ void Batch::process(const float *in, long long inSS, long long inCS, const int *
 				SMST_HIP(hipStreamWaitEvent(sF, evChain[slot], 0));
 				SMST_HIP(hipStreamWaitEvent(sF, evSynth[slot], 0));
 			}
+			if (!serial && fused && !plain && q >= 1) SMST_HIP(hipStreamWaitEvent(sF, evChain[slot ^ 1], 0)); // pass A reads the carried state
 			if (th[0]) {
 				if (th[3]) timed(timings.analyseMs, [&] { launchAnalyse(dd, io, sBase, ns, hopBase, tileHops, sF); if (profiling) ++timings.analyseLaunches; });
 				if (th[1] || th[2]) timed(timings.feedMs, [&] {
 					launchFeedMap(dd, sBase, ns, hopBase, tileHops, sF);
 					if (th[2]) launchFeedFormant(dd, sBase, ns, hopBase, tileHops, sF);
 				});
-				timed(timings.predictMs, [&] { launchPredict(dd, sBase, ns, hopBase, tileHops, !(th[1] || th[2]), sF); if (profiling) ++timings.predictLaunches; });
-				timed(timings.otherMs, [&] { launchCarryFeed(dd, sBase, ns, hopBase, sF); });
+				timed(timings.predictMs, [&] {
+					if (fused) launchPredictFused(dd, sBase, ns, hopBase, tileHops, plain, sF);
+					else launchPredict(dd, sBase, ns, hopBase, tileHops, plain, sF);
+					if (profiling) ++timings.predictLaunches;
+				});
+				// the carried feed-forward state (Band.input/.prevInput, Prediction.energy) may only move on once every
+				// reader of the OLD state has run: in the fused path the producers inside kVocoder still read it
+				if (!fused) timed(timings.otherMs, [&] { launchCarryFeed(dd, sBase, ns, hopBase, sF); });
 			}
 			if (!serial) {
 				SMST_HIP(hipEventRecord(evFeed[slot], sF));
 				SMST_HIP(hipStreamWaitEvent(sC, evFeed[slot], 0));
 			}
 			if (th[0]) {
-				timed(timings.chainMs, [&] { launchChain(dd, sBase, ns, hopBase, sC); if (profiling) ++timings.chainLaunches; });
-				timed(timings.otherMs, [&] { launchCarryOut(dd, sBase, ns, sC); });
+				timed(timings.chainMs, [&] {
+					if (fused) launchVocoder(dd, sBase, ns, hopBase, plain, sC);
+					else launchChain(dd, sBase, ns, hopBase, sC);
+					if (profiling) ++timings.chainLaunches;
+				});
+				timed(timings.otherMs, [&] {
+					if (fused) launchCarryFeed(dd, sBase, ns, hopBase, sC);
+					launchCarryOut(dd, sBase, ns, sC);
+				});
 			}
 			if (!serial) {
 				SMST_HIP(hipEventRecord(evChain[slot], sC));

@@ -673,11 +673,20 @@ __device__ __forceinline__ LerpIndex lerpIndex(float x) { // :559-562
 	return r;
 }
 __device__ __forceinline__ float2 bandAt(const float2 *row, int idx, int M) { // getBand, :548-551
-	return (idx < 0 || idx >= M) ? make_float2(0.f, 0.f) : row[idx];
+	// branch-free: always load (clamped index), then zero outside [0, M) -- keeps every load of a record in one
+	// basic block so the compiler can issue them back to back (memory-level parallelism of the record producers)
+	const int ci = min(max(idx, 0), M - 1);
+	const float2 v = row[ci];
+	return (ci == idx) ? v : make_float2(0.f, 0.f);
 }
 __device__ __forceinline__ float2 lerpBand(const float2 *row, LerpIndex li, int M) { // getFractional, :553-557
 	float2 low = bandAt(row, li.lo, M), high = bandAt(row, li.lo + 1, M);
 	return make_float2(low.x + (high.x - low.x)*li.fr, low.y + (high.y - low.y)*li.fr);
+}
+__device__ __forceinline__ float2 rotAt(const DevBatch &d, int idx, bool rotate) { // hop rotation of bin idx, 1 outside / when off
+	const int ci = min(max(idx, 0), d.M - 1);
+	const float2 v = d.rot[ci];
+	return (rotate && ci == idx) ? v : make_float2(1.f, 0.f);
 }
 
 // pass A: P and E in row layout [s][k][c][M]
@@ -718,14 +727,6 @@ __global__ __launch_bounds__(256) void kPredictA(DevBatch d, int sBase, int hopB
 // (:791-800, lock twist P_c conj(P_m) formed in the recurrence kernel).  Floats: 0-7 A,B,Cc,Dc; 8 m; 9+3c.. per channel.  Records live in a SKEWED layout
 // REC[s][t][chunk][lane k] (float4 chunks, t = b + lag*k) so that step t of the wavefront is one contiguous block.
 
-// Fractional read that skips the upper tap when the index is an integer (always the case without a pitch map).
-__device__ __forceinline__ float2 lerpBandFast(const float2 *row, LerpIndex li, int M) {
-	float2 low = bandAt(row, li.lo, M);
-	if (li.fr == 0.0f) return low;
-	float2 high = bandAt(row, li.lo + 1, M);
-	return make_float2(low.x + (high.x - low.x)*li.fr, low.y + (high.y - low.y)*li.fr);
-}
-
 // PLAIN = no hop of the tile has a pitch map or formant processing: then Prediction.input is the input spectrum
 // itself and Prediction.energy its squared magnitude (signalsmith-stretch.h:676-685,:708-710), so pass A is skipped.
 template <int CH, bool PLAIN>
@@ -751,33 +752,109 @@ struct RecordSource {
 template <int CH, bool PLAIN>
 __device__ __forceinline__ float2 twistAt(const RecordSource<CH, PLAIN> &src, int mc, int bx, bool rotate, const float2 *in,
                                           const float2 *pv, const float *EprevRow, const float2 *inPrevHop, float tfDown, float stepMul) {
+	// bx may be one past the last bin for the callers' masked-out cases: every access below clamps
 	const DevBatch &d = src.d;
 	const int M = src.M;
-	const float2 mp = src.mapAt(bx);
-	const LerpIndex li = lerpIndex(mp.x);
-	const bool loIn = li.lo >= 0 && li.lo < M, hiIn = li.lo + 1 >= 0 && li.lo + 1 < M;
-	const float2 rotLo = (rotate && loIn) ? d.rot[li.lo] : make_float2(1.f, 0.f);
-	float2 Q = cmul(bandAt(pv, li.lo, M), rotLo);
-	if (li.fr != 0.0f) {
-		const float2 rotHi = (rotate && hiIn) ? d.rot[li.lo + 1] : make_float2(1.f, 0.f);
-		float2 pvHi = cmul(bandAt(pv, li.lo + 1, M), rotHi);
-		Q = make_float2(Q.x + (pvHi.x - Q.x)*li.fr, Q.y + (pvHi.y - Q.y)*li.fr);
+	const int bc = min(bx, M - 1);
+	const float2 mp = src.mapAt(bc);
+	const float2 rotB = rotAt(d, bc, rotate);
+	float2 Q;
+	if (PLAIN) { // identity map: the previous-input tap sits exactly on bin bc (fraction 0), and shares its rotation
+		Q = cmul(pv[bc], rotB);
+	} else {
+		const LerpIndex li = lerpIndex(mp.x);
+		const float2 qLo = cmul(bandAt(pv, li.lo, M), rotAt(d, li.lo, rotate));
+		const float2 qHi = cmul(bandAt(pv, li.lo + 1, M), rotAt(d, li.lo + 1, rotate));
+		Q = make_float2(qLo.x + (qHi.x - qLo.x)*li.fr, qLo.y + (qHi.y - qLo.y)*li.fr);
 	}
-	const float2 rotB = rotate ? d.rot[bx] : make_float2(1.f, 0.f);
-	const float2 Px = src.P(mc, bx);
+	const float2 Px = src.P(mc, bc);
 	const float2 TW = cmul(rotB, cmulc(Px, Q));
-	const float eNow = src.E(mc, bx, Px);
-	const float ePrev = (PLAIN && inPrevHop) ? cnorm(inPrevHop[bx]) : EprevRow[bx];
+	const float eNow = src.E(mc, bc, Px);
+	const float ePrev = (PLAIN && inPrevHop) ? cnorm(inPrevHop[bc]) : EprevRow[bc];
 	const float den = fmaxf(ePrev, eNow) + 1e-15f; // :716
-	const float2 down = cmulc(Px, lerpBandFast(in, lerpIndex(mp.x - stepMul*tfDown), M));
+	const float2 down = cmulc(Px, lerpBand(in, lerpIndex(mp.x - stepMul*tfDown), M));
 	const float2 r = cmulc(TW, down);
 	const float inv = 1.0f/den;
 	return make_float2(r.x*inv, r.y*inv);
 }
 
+// Fills one record.  Per-channel fields: {P.x, P.y, sqrt(E)} and, with LOCK, the channel-lock twist P_c conj(P_m).
+// SPEC (mono/stereo): the four twists are evaluated for EVERY channel and the maximum-energy channel's set is
+// selected afterwards, so no load address depends on loaded data (one memory round trip per record instead of two).
+template <int CH, bool PLAIN, bool LOCK, bool SPEC, int NFLOATS>
+__device__ __forceinline__ void computeRecord(const DevBatch &d, const HopDesc &hd, const HopDesc &hp, int s, int sg, int k, int b, float (&f)[NFLOATS]) {
+	constexpr int PC = LOCK ? 5 : 3;
+	const int M = d.M, L = d.L;
+	const bool rotate = hd.flags & HOP_NEW_SPECTRUM, randomTf = hd.flags & HOP_RANDOM_TF;
+	const RecordSource<CH, PLAIN> src(d, hd, s, k, sg);
+	float2 p[CH];
+	float e[CH];
+#pragma unroll
+	for (int c = 0; c < CH; ++c) {
+		p[c] = src.P(c, b);
+		e[c] = src.E(c, b, p[c]);
+	}
+	int mc = 0; // maximum-energy channel, first maximum wins (:729-737)
+	float eMax = e[0];
+#pragma unroll
+	for (int c = 1; c < CH; ++c) {
+		if (e[c] > eMax) { mc = c; eMax = e[c]; }
+	}
+	float2 Pm = p[0];
+#pragma unroll
+	for (int c = 1; c < CH; ++c) if (c == mc) Pm = p[c];
+	const float2 mp = src.mapAt(b);
+	float tfUp = hd.timeFactor, tfDn = hd.timeFactor;
+	if (randomTf) { // uniform(4 - tf, tf): one draw per bin and direction (:640,:749,:769)
+		const float lo = 4.0f - hd.timeFactor, span = hd.timeFactor - lo;
+		tfUp = lo + span*hashUniform(hd.seed, b, 0);
+		tfDn = lo + span*hashUniform(hd.seed, b, 1);
+	}
+	auto twists = [&](int cm, float2 Pcm, float2 &A, float2 &B, float2 &Cc, float2 &Dc) {
+		const float2 *in = src.inRow(cm);
+		const float2 *pv = prevRow(d, hd, s, k, sg, cm);
+		// Prediction.energy of the previous hop: the carried state for the tile's first hop, else hop k-1's
+		const float *EprevRow = (k == 0) ? d.stEnergy + stateRow(d, sg, cm) : (PLAIN ? nullptr : d.E + rowOf(d, s, k - 1, cm));
+		const float2 *inPrevHop = (PLAIN && k > 0) ? inputRow(d, hp, s, sg, cm) : nullptr;
+		const float2 zero = make_float2(0.f, 0.f);
+		A = cmulc(Pcm, lerpBand(in, lerpIndex(mp.x - tfUp), M));
+		B = cmulc(Pcm, lerpBand(in, lerpIndex(mp.x - L*tfUp), M));
+		Cc = twistAt<CH, PLAIN>(src, cm, b + 1, rotate, in, pv, EprevRow, inPrevHop, tfDn, 1.0f);
+		Dc = twistAt<CH, PLAIN>(src, cm, b + L, rotate, in, pv, EprevRow, inPrevHop, tfDn, float(L));
+		if (!(b > 0)) A = zero;      // :748
+		if (!(b >= L)) B = zero;     // :756
+		if (!(b < M - 1)) Cc = zero; // :765
+		if (!(b < M - L)) Dc = zero; // :776
+	};
+	float2 A, B, Cc, Dc;
+	if (SPEC) {
+		twists(0, p[0], A, B, Cc, Dc);
+#pragma unroll
+		for (int c = 1; c < CH; ++c) {
+			float2 a2, b2, c2, d2;
+			twists(c, p[c], a2, b2, c2, d2);
+			if (c == mc) { A = a2; B = b2; Cc = c2; Dc = d2; }
+		}
+	} else {
+		twists(mc, Pm, A, B, Cc, Dc);
+	}
+	f[0] = A.x; f[1] = A.y; f[2] = B.x; f[3] = B.y; f[4] = Cc.x; f[5] = Cc.y; f[6] = Dc.x; f[7] = Dc.y;
+	f[8] = __int_as_float(mc);
+#pragma unroll
+	for (int c = 0; c < CH; ++c) {
+		f[9 + PC*c] = p[c].x; f[10 + PC*c] = p[c].y;
+		f[11 + PC*c] = sqrtf(e[c]);
+		if (LOCK) {
+			float2 lock = cmulc(p[c], Pm);
+			f[12 + PC*c] = lock.x; f[13 + PC*c] = lock.y;
+		}
+	}
+}
+
 // One workgroup = 8 wavefront steps x all 64 hops of a stream.  Reads are coalesced along the bin index (8 lanes
 // per row); the 512 records are transposed through LDS so that the stores to the skewed array are contiguous 1-KiB
 // rows (the scattered 16-byte stores of the first version ran at 1.3 TB/s and dominated the whole pipeline).
+// (Used for more than 2 channels; mono/stereo use the fused kVocoder below, which never writes records to HBM.)
 template <int CH, bool PLAIN>
 __global__ __launch_bounds__(256) void kPredictB(DevBatch d, int sBase, int hopBase) {
 	constexpr int NF = 9 + 3*CH, NCH = (NF + 3)/4;
@@ -785,7 +862,7 @@ __global__ __launch_bounds__(256) void kPredictB(DevBatch d, int sBase, int hopB
 	float4 *tile = reinterpret_cast<float4 *>(smemRaw); // [(st*NCH + j)*65 + k]
 	const int s = blockIdx.y, sg = sBase + s;
 	const int T0 = blockIdx.x*8;
-	const int M = d.M, L = d.L;
+	const int M = d.M;
 	const int nh = d.nHops[s];
 	if (nh == 0 || T0 >= M + d.lag*(nh - 1)) return; // nothing of this stream's wavefront in these steps
 	const int st = threadIdx.x & 7, r = threadIdx.x >> 3;
@@ -799,62 +876,8 @@ __global__ __launch_bounds__(256) void kPredictB(DevBatch d, int sBase, int hopB
 		for (int j = 0; j < NCH*4; ++j) f[j] = 0.0f;
 		if (k < nh && b >= 0 && b < M) {
 			const HopDesc hd = d.hops[(size_t)sg*d.hopStride + hopBase + k];
-			const bool rotate = hd.flags & HOP_NEW_SPECTRUM, randomTf = hd.flags & HOP_RANDOM_TF;
-			const RecordSource<CH, PLAIN> src(d, hd, s, k, sg);
-			float2 p[CH];
-			float e[CH];
-#pragma unroll
-			for (int c = 0; c < CH; ++c) {
-				p[c] = src.P(c, b);
-				e[c] = src.E(c, b, p[c]);
-			}
-			int mc = 0; // maximum-energy channel, first maximum wins (:729-737)
-			float eMax = e[0];
-#pragma unroll
-			for (int c = 1; c < CH; ++c) {
-				if (e[c] > eMax) { mc = c; eMax = e[c]; }
-			}
-			float2 Pm = p[0];
-#pragma unroll
-			for (int c = 1; c < CH; ++c) if (c == mc) Pm = p[c];
-			const float2 *in = src.inRow(mc);
-			const float2 *pv = prevRow(d, hd, s, k, sg, mc);
-			// Prediction.energy of the previous hop: the carried state for the tile's first hop, else hop k-1's
-			const float *EprevRow = (k == 0) ? d.stEnergy + stateRow(d, sg, mc) : (PLAIN ? nullptr : d.E + rowOf(d, s, k - 1, mc));
-			const float2 *inPrevHop = nullptr;
-			if (PLAIN && k > 0) {
-				const HopDesc hp = d.hops[(size_t)sg*d.hopStride + hopBase + k - 1];
-				inPrevHop = inputRow(d, hp, s, sg, mc);
-			}
-			const float2 mp = src.mapAt(b);
-			float tfUp = hd.timeFactor, tfDn = hd.timeFactor;
-			if (randomTf) { // uniform(4 - tf, tf): one draw per bin and direction (:640,:749,:769)
-				const float lo = 4.0f - hd.timeFactor, span = hd.timeFactor - lo;
-				tfUp = lo + span*hashUniform(hd.seed, b, 0);
-				tfDn = lo + span*hashUniform(hd.seed, b, 1);
-			}
-			if (b > 0) {
-				float2 A = cmulc(Pm, lerpBandFast(in, lerpIndex(mp.x - tfUp), M));
-				f[0] = A.x; f[1] = A.y;
-			}
-			if (b >= L) {
-				float2 B = cmulc(Pm, lerpBandFast(in, lerpIndex(mp.x - L*tfUp), M));
-				f[2] = B.x; f[3] = B.y;
-			}
-			if (b < M - 1) {
-				float2 Cc = twistAt<CH, PLAIN>(src, mc, b + 1, rotate, in, pv, EprevRow, inPrevHop, tfDn, 1.0f);
-				f[4] = Cc.x; f[5] = Cc.y;
-			}
-			if (b < M - L) {
-				float2 Dc = twistAt<CH, PLAIN>(src, mc, b + L, rotate, in, pv, EprevRow, inPrevHop, tfDn, float(L));
-				f[6] = Dc.x; f[7] = Dc.y;
-			}
-			f[8] = __int_as_float(mc);
-#pragma unroll
-			for (int c = 0; c < CH; ++c) {
-				f[9 + 3*c] = p[c].x; f[10 + 3*c] = p[c].y;
-				f[11 + 3*c] = sqrtf(e[c]);
-			}
+			const HopDesc hp = d.hops[(size_t)sg*d.hopStride + hopBase + (k > 0 ? k - 1 : 0)];
+			computeRecord<CH, PLAIN, false, false>(d, hd, hp, s, sg, k, b, f);
 		}
 #pragma unroll
 		for (int j = 0; j < NCH; ++j) tile[(st*NCH + j)*65 + k] = make_float4(f[4*j], f[4*j + 1], f[4*j + 2], f[4*j + 3]);
@@ -998,6 +1021,163 @@ __global__ __launch_bounds__(64) void kChain(DevBatch d, int sBase, int hopBase)
 				__builtin_amdgcn_wave_barrier();
 				__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 			}
+		}
+	}
+}
+
+// ------------------------------------------------------------------------------------------------------
+// K3 fused (mono / stereo): the recurrence and its coefficients in ONE kernel, so the records never touch HBM.
+// One workgroup of 8 waves per stream: wave 0 is the CONSUMER (the skewed wavefront of kChain, one lane per hop);
+// waves 1-7 are PRODUCERS that compute the records (same arithmetic as kPredictB, 8 rows x 8 steps per wave-pass,
+// reads coalesced along the bin index) into an LDS ring of 3 blocks x 8 steps.  Hand-off is by two LDS words per
+// slot (units produced, blocks consumed); LDS operations of a wave execute in order, so a counter update issued
+// after the data writes is seen after them.  The consumer raises its own issue priority: it is the serial path.
+// ------------------------------------------------------------------------------------------------------
+constexpr int kVocBlockSteps = 8, kVocBlocks = 3, kVocWaves = 16;
+
+__device__ __forceinline__ int ldsPeek(volatile int *p) { return *p; }
+
+template <int CH, bool PLAIN>
+__global__ __launch_bounds__(64*kVocWaves) __attribute__((amdgpu_waves_per_eu(4, 4))) void kVocoder(DevBatch d, int sBase, int hopBase) {
+	constexpr int NF = 9 + 5*CH, NCH = (NF + 3)/4, BS = kVocBlockSteps, NB = kVocBlocks, NP = kVocWaves - kVocWaves/4;
+	extern __shared__ __attribute__((aligned(16))) unsigned char smemRaw[];
+	const int R = d.ringSlots, Rm = R - 1;
+	float4 *recs = reinterpret_cast<float4 *>(smemRaw);                 // [(slot*BS + st)*NCH + j][64 lanes]
+	float2 *lds = reinterpret_cast<float2 *>(recs + NB*BS*NCH*64);      // ring [CH][R][64], then stage [CH][128]
+	const int stageBase = CH*R*64;
+	volatile int *sync = reinterpret_cast<volatile int *>(lds + stageBase + CH*128); // [0..NB) produced, [NB] consumed
+	HopDesc *hopsLds = reinterpret_cast<HopDesc *>(const_cast<int *>(sync) + 16);         // the tile's 64 hop descriptors
+
+	const int s = blockIdx.x, sg = sBase + s;
+	const int nh = d.nHops[s];
+	if (nh == 0) return;
+	const int wave = threadIdx.x >> 6, k = threadIdx.x & 63;
+	const int M = d.M, L = d.L, lag = d.lag;
+	const int steps = M + lag*(nh - 1);
+	const int chunks = (steps + 63) >> 6;
+	const int totalBlocks = chunks*(64/BS);
+	const float2 *stOut = d.stOut + stateRow(d, sg, 0);
+
+	// prologue (all waves): clear the ring, stage bins [0,128) of the carried Band.output, clear the hand-off words
+	for (int i = threadIdx.x; i < CH*R*64; i += blockDim.x) lds[i] = make_float2(0.f, 0.f);
+	for (int i = threadIdx.x; i < CH*128; i += blockDim.x) {
+		const int c = i >> 7, bb = i & 127;
+		lds[stageBase + i] = (bb < M) ? stOut[(size_t)c*M + bb] : make_float2(0.f, 0.f);
+	}
+	if (threadIdx.x <= NB) sync[threadIdx.x] = 0;
+	if (threadIdx.x < 64) hopsLds[threadIdx.x] = d.hops[(size_t)sg*d.hopStride + hopBase + threadIdx.x];
+	__syncthreads();
+
+	if (wave > 0) {
+		// ---------------- producers ----------------
+		// A workgroup's waves are dealt to the CU's 4 SIMDs cyclically, so waves 4, 8, 12 would share the consumer's
+		// SIMD and steal its issue slots: they retire at once and the consumer owns its SIMD (12 producers on 3 SIMDs).
+		if ((wave & 3) == 0) return;
+		const int pIndex = wave - 1 - (wave >> 2); // 0..NP-1 over the remaining waves
+		const int r = k & 7, st = k >> 3; // 8 adjacent lanes = 8 rows of one step: their LDS record writes are contiguous
+		for (int u = pIndex; u < totalBlocks*8; u += NP) {
+			const int n = u >> 3, it = u & 7;
+			const int slot = n%NB;
+			while (n - ldsPeek(&sync[NB]) >= NB) __builtin_amdgcn_s_sleep(2); // slot still being read
+			asm volatile("" ::: "memory");
+			const int row = 8*it + r;
+			const int t = BS*n + st;
+			const int b = t - lag*row;
+			float f[NCH*4];
+#pragma unroll
+			for (int j = 0; j < NCH*4; ++j) f[j] = 0.0f;
+			if (row < nh && b >= 0 && b < M && d.debugMode != 1) computeRecord<CH, PLAIN, true, false>(d, hopsLds[row], hopsLds[row > 0 ? row - 1 : 0], s, sg, row, b, f);
+#pragma unroll
+			for (int j = 0; j < NCH; ++j) recs[((slot*BS + st)*NCH + j)*64 + row] = make_float4(f[4*j], f[4*j + 1], f[4*j + 2], f[4*j + 3]);
+			asm volatile("" ::: "memory");
+			if (k == 0) atomicAdd(const_cast<int *>(&sync[slot]), 1); // LDS ops of a wave are in order: data first, then the count
+		}
+		return;
+	}
+
+	// ---------------- consumer (wave 0) ----------------
+	__builtin_amdgcn_s_setprio(3);
+	const bool active = k < nh;
+	const int kLag = lag*k;
+	float2 *OUT = d.OUT + rowOf(d, s, active ? k : 0, 0);
+	float2 *dump = d.dump + (size_t)s*CH*64 + k;
+	float2 pf[CH];
+	float2 own1[CH];
+#pragma unroll
+	for (int c = 0; c < CH; ++c) { pf[c] = make_float2(0.f, 0.f); own1[c] = make_float2(0.f, 0.f); }
+
+	for (int ch = 0; ch < chunks; ++ch) {
+		const int tb = ch << 6;
+		if (ch > 0) {
+#pragma unroll
+			for (int c = 0; c < CH; ++c) lds[stageBase + c*128 + ((tb + 64 + k) & 127)] = pf[c];
+		}
+		{
+			const int bb = tb + 128 + k;
+			const int bc = (bb < M) ? bb : M - 1;
+#pragma unroll
+			for (int c = 0; c < CH; ++c) {
+				float2 v = stOut[(size_t)c*M + bc];
+				pf[c] = (bb < M) ? v : make_float2(0.f, 0.f);
+			}
+		}
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+		for (int blk = 0; blk < 64/BS; ++blk) {
+			const int n = ch*(64/BS) + blk;
+			const int slot = n%NB;
+			const int need = 8*(n/NB + 1);
+			while (ldsPeek(&sync[slot]) < need) __builtin_amdgcn_s_sleep(1);
+			asm volatile("" ::: "memory");
+			const float4 *blockRecs = recs + (size_t)slot*BS*NCH*64 + k;
+#pragma unroll
+			for (int stp = 0; stp < BS; ++stp) {
+				if (d.debugMode == 2) break; // experiment: consumer only acknowledges blocks
+				const int t = tb + blk*BS + stp;
+				float f[NCH*4];
+#pragma unroll
+				for (int j = 0; j < NCH; ++j) {
+					const float4 v = blockRecs[(stp*NCH + j)*64];
+					f[4*j] = v.x; f[4*j + 1] = v.y; f[4*j + 2] = v.z; f[4*j + 3] = v.w;
+				}
+				const int b = t - kLag;
+				const bool valid = active && b >= 0 && b < M;
+				int mc = __float_as_int(f[8]);
+				mc = (mc < 0) ? 0 : ((mc > CH - 1) ? CH - 1 : mc);
+				float2 o1 = own1[0], pm = make_float2(f[9], f[10]);
+				float sm = f[11];
+#pragma unroll
+				for (int c = 1; c < CH; ++c) {
+					if (c == mc) { o1 = own1[c]; pm = make_float2(f[9 + 5*c], f[10 + 5*c]); sm = f[11 + 5*c]; }
+				}
+				const int ringRow = mc*R;
+				const float2 oL = lds[(ringRow + ((b - L) & Rm))*64 + k];
+				const int a1 = (k == 0) ? stageBase + mc*128 + ((b + 1) & 127) : (ringRow + ((b + 1) & Rm))*64 + k - 1;
+				const int aL = (k == 0) ? stageBase + mc*128 + ((b + L) & 127) : (ringRow + ((b + L) & Rm))*64 + k - 1;
+				const float2 p1 = lds[a1];
+				const float2 pL = lds[aL];
+				float2 phi = cmul(oL, make_float2(f[2], f[3]));
+				phi = cadd(phi, cmul(p1, make_float2(f[4], f[5])));
+				phi = cadd(phi, cmul(pL, make_float2(f[6], f[7])));
+				phi = cadd(phi, cmul(o1, make_float2(f[0], f[1])));
+				const float2 om = makeOutput(phi, pm, sm); // :788
+#pragma unroll
+				for (int c = 0; c < CH; ++c) {
+					float2 oc = makeOutput(cmul(om, make_float2(f[12 + 5*c], f[13 + 5*c])), make_float2(f[9 + 5*c], f[10 + 5*c]), f[11 + 5*c]); // :791-800
+					if (c == mc) oc = om;
+					if (!valid) oc = make_float2(0.f, 0.f);
+					own1[c] = oc;
+					lds[(c*R + (b & Rm))*64 + k] = oc;
+					float2 *dst = valid ? OUT + ((size_t)c*d.Mp + b) : dump + c*64;
+					*dst = oc;
+				}
+				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+				__builtin_amdgcn_wave_barrier();
+				__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+			}
+			asm volatile("" ::: "memory");
+			if (k == 0) sync[NB] = n + 1; // this block's slot may be refilled
 		}
 	}
 }
@@ -1238,13 +1418,28 @@ template <int CH>
 static void launchPredictT(const DevBatch &d, int sBase, int nStreams, int hopBase, int tileHops, bool plain, hipStream_t st) {
 	const dim3 grid(divUp(d.M + d.lag*(d.T - 1), 8), nStreams);
 	const size_t lds = (size_t)8*((9 + 3*CH + 3)/4)*65*sizeof(float4);
-	(void)tileHops;
 	if (plain) {
 		hipLaunchKernelGGL((kPredictB<CH, true>), grid, dim3(256), lds, st, d, sBase, hopBase);
 	} else {
 		hipLaunchKernelGGL(kPredictA, dim3(divUp(d.M, 256), tileHops, nStreams), dim3(256), 0, st, d, sBase, hopBase);
 		hipLaunchKernelGGL((kPredictB<CH, false>), grid, dim3(256), lds, st, d, sBase, hopBase);
 	}
+}
+// mono / stereo: pass A (only with a pitch map or formants) on the feed-forward stream ...
+void launchPredictFused(const DevBatch &d, int sBase, int nStreams, int hopBase, int tileHops, bool plain, hipStream_t st) {
+	if (!plain) hipLaunchKernelGGL(kPredictA, dim3(divUp(d.M, 256), tileHops, nStreams), dim3(256), 0, st, d, sBase, hopBase);
+}
+// ... and the fused producer/consumer recurrence
+template <int CH>
+static void launchVocoderT(const DevBatch &d, int sBase, int nStreams, int hopBase, bool plain, hipStream_t st) {
+	constexpr int NCH = (9 + 5*CH + 3)/4;
+	const size_t lds = (size_t)kVocBlocks*kVocBlockSteps*NCH*64*sizeof(float4) + ((size_t)CH*d.ringSlots*64 + (size_t)CH*128)*sizeof(float2) + 64 + 64*sizeof(HopDesc);
+	if (plain) hipLaunchKernelGGL((kVocoder<CH, true>), dim3(nStreams), dim3(64*kVocWaves), lds, st, d, sBase, hopBase);
+	else hipLaunchKernelGGL((kVocoder<CH, false>), dim3(nStreams), dim3(64*kVocWaves), lds, st, d, sBase, hopBase);
+}
+void launchVocoder(const DevBatch &d, int sBase, int nStreams, int hopBase, bool plain, hipStream_t st) {
+	if (d.C == 1) launchVocoderT<1>(d, sBase, nStreams, hopBase, plain, st);
+	else launchVocoderT<2>(d, sBase, nStreams, hopBase, plain, st);
 }
 void launchPredict(const DevBatch &d, int sBase, int nStreams, int hopBase, int tileHops, bool plain, hipStream_t st) {
 	switch (d.C) {
