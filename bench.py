@@ -29,9 +29,9 @@ def algorithmic_bytes_per_channel_hop(B, I, M, r):
     return 4*(I/r) + 4*I + 2*12*M + (2*8*M if r == 1 else 0) + 2*4*(B - I)
 
 
-def make_inputs(torch, S, C, n, device, first_stream=0):
+def make_inputs(torch, S, C, n, device, first_stream=0, sr=SR):
     """Synthetic streams of SURVEY.md 8(d): type = s mod 3 (sine pair / chirp / uniform noise), generated on the GPU."""
-    t = torch.arange(n, device=device, dtype=torch.float64)/SR
+    t = torch.arange(n, device=device, dtype=torch.float64)/sr
     x = torch.empty((S, C, n), dtype=torch.float32, device=device)
     gen = torch.Generator(device=device)
     for s in range(S):
@@ -41,7 +41,7 @@ def make_inputs(torch, S, C, n, device, first_stream=0):
                 f1 = 110*2**((sg % 37)/12)
                 v = 0.4*torch.sin(2*torch.pi*f1*t + 0.5*c) + 0.2*torch.sin(2*torch.pi*3.17*f1*t)
             elif sg % 3 == 1:
-                k = (0.4*SR - 50)/(n/SR)
+                k = (0.4*sr - 50)/(n/sr)
                 v = 0.5*torch.sin(2*torch.pi*(50*t + 0.5*k*t*t) + 0.5*c)
             else:
                 gen.manual_seed(1_000_003*sg + c)
@@ -82,7 +82,26 @@ def main():
     ap.add_argument("--seconds", type=float, default=10.0, help="seconds of input per stream per step")
     ap.add_argument("--stretch", type=float, default=1.5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--config", default="2", choices=["2", "3", "4", "4b", "5"],
+                    help="BASELINE.json config (default 2 = the one the headline metric is quoted on; the others are "
+                         "reported in DESIGN.md, they are not the bench line)")
     args = ap.parse_args()
+    preset, C, sr_cfg = "default", 2, SR
+    setup = None
+    per_stream = None
+    if args.config == "3":
+        args.streams, args.stretch = 1024, 1.0
+        setup = lambda b: b.setTransposeSemitones(12, 8000/48000)  # noqa: E731
+    elif args.config in ("4", "4b"):
+        args.streams, args.stretch = 512, 0.75
+        def setup(b):
+            if args.config == "4b":
+                b.setTransposeSemitones(4, 8000/48000)
+            b.setFormantFactor(1, True)
+            b.setFormantBase(200/48000)
+    elif args.config == "5":
+        args.streams, args.seconds, preset, C, sr_cfg = 1024, 2.0, "cheaper", 8, 96000
+        per_stream = True
 
     import torch
     import torch.distributed as dist
@@ -98,12 +117,23 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     pkg = importlib.import_module("signalsmith-stretch_amd")
-    S, C = args.streams, 2
-    n_in = int(args.seconds*SR)
+    S = args.streams
+    n_in = int(args.seconds*sr_cfg)
     n_out = int(round(n_in*args.stretch))
-    batch = pkg.StretchBatch(S, C, preset="default", sample_rate=SR, device=local_rank, seed=rank)
-    x = make_inputs(torch, S, C, n_in, device, first_stream=rank*S)
-    y = torch.empty((S, C, n_out), dtype=torch.float32, device=device)
+    batch = pkg.StretchBatch(S, C, preset=preset, sample_rate=sr_cfg, device=local_rank, seed=rank)
+    if setup:
+        setup(batch)
+    if per_stream:  # config 5: per-stream random stretch 0.75-1.5x and +-12 st
+        import numpy as np
+        g = np.random.Generator(np.random.PCG64(5))
+        stretches = g.uniform(0.75, 1.5, 8192)[rank*S:(rank + 1)*S]
+        semis = g.uniform(-12, 12, 8192)[rank*S:(rank + 1)*S]
+        for i in range(S):
+            batch.setTransposeSemitones(float(semis[i]), 0.0, stream=i)
+        n_out = [int(round(n_in*float(v))) for v in stretches]
+    x = make_inputs(torch, S, C, n_in, device, first_stream=rank*S, sr=sr_cfg)
+    n_out_max = max(n_out) if per_stream else n_out
+    y = torch.empty((S, C, n_out_max), dtype=torch.float32, device=device)
     torch.cuda.synchronize()
 
     def barrier():
@@ -128,10 +158,11 @@ def main():
         elapsed = float(tt.item())
     ok = bool(torch.isfinite(y).all().item()) and float(y.abs().max().item()) > 0.01
 
-    samples_per_step = world*S*C*(n_in + n_out)
+    total_out = sum(n_out) if per_stream else S*n_out
+    samples_per_step = world*C*(S*n_in + total_out)
     value = samples_per_step*args.steps/elapsed/1e6
     B, I, M = batch.blockSamples(), batch.intervalSamples(), batch.bands()
-    hops_per_stream = -(-n_out//I)
+    hops_per_stream = -(-(total_out//S)//I)
     bytes_per_chop = algorithmic_bytes_per_channel_hop(B, I, M, args.stretch)
 
     roofline = None
@@ -173,11 +204,14 @@ def main():
             "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed/args.steps*1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[1]: %d stereo streams per GPU, 48 kHz, presetDefault, %.2fx stretch, fp32, "
-                                   "%.0f s input per stream per step, device-resident I/O" % (S, args.stretch, args.seconds),
+            "config": {"workload": ("BASELINE configs[1]: %d stereo streams per GPU, 48 kHz, presetDefault, %.2fx stretch, fp32, "
+                                    "%.0f s input per stream per step, device-resident I/O" % (S, args.stretch, args.seconds))
+                       if args.config == "2" else "BASELINE config %s (not the headline): %d streams x %d ch per GPU, %d Hz, preset %s, %.0f s per step"
+                       % (args.config, S, C, sr_cfg, preset, args.seconds),
                        "streams_total": world*S, "channels": C, "block": B, "interval": I, "fft": batch.fftSamples(),
                        "hops_per_stream_per_step": hops_per_stream, "sharding": "streams/%d, no collective" % world},
             "realtime_x": world*S*args.seconds*args.steps/elapsed,
+            "channels": C,
             "output_finite_nonzero": ok,
             "roofline": roofline, "cpu_baseline": cpu,
         }

@@ -45,7 +45,8 @@ struct DevBatch {
 	float *E;
 	float2 *map;    // [subS][T][M]
 	float *ratio;   // [subS][T][M]
-	float *esum;    // [subS][T][M]
+	float *energyT, *smoothT; // [subS][M][64 hops]: feed scratch, hop index fastest
+	float2 *peaksT;           // [subS][M/2 + 2][64 hops]
 	float *est;     // [subS][T][2]
 	float *frames;  // [subS][T][C][B]
 	const int *nHops;      // [subS] hops of this tile
@@ -62,8 +63,7 @@ struct IoArgs {
 
 void launchEnergy(const DevBatch &d, const IoArgs &io, int sBase, int nStreams, float *energyOut, hipStream_t st);
 void launchAnalyse(const DevBatch &d, const IoArgs &io, int sBase, int nStreams, int hopBase, int tileHops, hipStream_t st);
-void launchFeedMap(const DevBatch &d, int sBase, int nStreams, int hopBase, int tileHops, hipStream_t st);
-void launchFeedFormant(const DevBatch &d, int sBase, int nStreams, int hopBase, int tileHops, hipStream_t st);
+void launchFeed(const DevBatch &d, int sBase, int nStreams, int hopBase, hipStream_t st);
 void launchPredict(const DevBatch &d, int sBase, int nStreams, int hopBase, int tileHops, bool plain, hipStream_t st);
 void launchChain(const DevBatch &d, int sBase, int nStreams, int hopBase, hipStream_t st);
 void launchPredictFused(const DevBatch &d, int sBase, int nStreams, int hopBase, int tileHops, bool plain, hipStream_t st);

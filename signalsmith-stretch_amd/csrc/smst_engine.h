@@ -86,7 +86,7 @@ private:
 	hipStream_t stChain = nullptr;  // the bin recurrence (few waves, latency-bound): overlaps with the bulk kernels
 	hipStream_t stSynth = nullptr;  // synthesis + emission of the previous tile
 	hipEvent_t evStart = nullptr, evFeed[2] = {nullptr, nullptr}, evChain[2] = {nullptr, nullptr}, evSynth[2] = {nullptr, nullptr};
-	struct TileBuffers { float2 *Xcur, *Xprev, *P, *OUT, *dump, *map; float4 *REC; float *E, *ratio, *esum, *est, *frames; } slots[2]{};
+	struct TileBuffers { float2 *Xcur, *Xprev, *P, *OUT, *dump, *map, *peaksT; float4 *REC; float *E, *ratio, *energyT, *smoothT, *est, *frames; } slots[2]{};
 	bool overlap = true;
 	int subS = 0;
 	size_t wsBytes = 0;

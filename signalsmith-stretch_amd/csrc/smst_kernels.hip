@@ -456,199 +456,257 @@ __device__ __forceinline__ float mapFreqDev(const DevBatch &d, const StreamParam
 }
 
 // ------------------------------------------------------------------------------------------------------
-// K2b-d: channel-summed energy, 4-pass one-pole smoothing, peak centroids, output map.
-// One 64-thread workgroup per (hop, stream).  The recurrences over the bin index are evaluated serially by
-// lane 0 in the reference's own order (signalsmith-stretch.h:818-848, :859-880, :882-917) so every rounding
-// matches; the parallel axis is the (stream, hop) grid.  Also emits the channel-summed energy (formant metric,
-// :974-980) and the raw pitch estimate (:929-960) when formants are on.
+// K2b-e: channel-summed energy, 4-pass one-pole smoothing, peak centroids, output map, formant envelope and ratio
+// (signalsmith-stretch.h:818-848, :859-880, :882-917, :929-966, :972-1036).  All of these are recurrences over the
+// bin index; the reference's rounding is kept by evaluating them serially IN THE REFERENCE'S ORDER -- the
+// parallel axis is (stream, hop): one wave per stream, lane k = hop k of the tile, scratch arrays laid out
+// [bin][64 hops] so that every serial step of the wave is one coalesced 256-byte access.
+//   kFeedEnergy : energyT[s][b][k] = sum_c |input_c[b]|^2           (parallel, LDS-transposed)
+//   kFeedSerial : everything else, lanes = hops
 // ------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void kFeedMap(DevBatch d, int sBase, int hopBase) {
+__global__ __launch_bounds__(256) void kFeedEnergy(DevBatch d, int sBase, int hopBase) {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smemRaw[];
-	float *energy = reinterpret_cast<float *>(smemRaw); // [M]
-	float *smoothed = energy + d.M;                      // [M]
-	float2 *peaks = reinterpret_cast<float2 *>(smoothed + d.M); // [M/2 + 2] {input, output}
-	int *nPeaksShared = reinterpret_cast<int *>(peaks + d.M/2 + 2);
-
-	const int k = blockIdx.x, s = blockIdx.y, sg = sBase + s;
-	const HopDesc hd = d.hops[(size_t)sg*d.hopStride + hopBase + k];
-	if (!(hd.flags & HOP_ACTIVE)) return;
-	const bool mapped = hd.flags & HOP_MAPPED, formants = hd.flags & HOP_FORMANTS;
-	if (!mapped && !formants) return;
+	float *tile = reinterpret_cast<float *>(smemRaw); // [64 hops][65]
+	const int s = blockIdx.y, sg = sBase + s;
+	const int b0 = blockIdx.x*64;
+	const int nh = d.nHops[s];
+	if (nh == 0) return;
 	const int M = d.M, C = d.C;
-	const float Nf = float(d.N);
-
-	for (int b = threadIdx.x; b < M; b += blockDim.x) {
+	const int lane = threadIdx.x & 63, rq = threadIdx.x >> 6;
+	for (int k = rq; k < 64; k += 4) {
 		float e = 0;
-		for (int c = 0; c < C; ++c) e += cnorm(inputRow(d, hd, s, sg, c)[b]);
-		energy[b] = e;
-		smoothed[b] = e;
-		if (formants) d.esum[((size_t)s*d.T + k)*M + b] = e;
+		const int b = b0 + lane;
+		if (k < nh && b < M) {
+			const HopDesc hd = d.hops[(size_t)sg*d.hopStride + hopBase + k];
+			if (hd.flags & (HOP_MAPPED | HOP_FORMANTS)) {
+				for (int c = 0; c < C; ++c) e += cnorm(inputRow(d, hd, s, sg, c)[b]);
+			}
+		}
+		tile[k*65 + lane] = e;
 	}
 	__syncthreads();
-	const StreamParams prm = d.params[sg];
+	float *eT = d.energyT + (size_t)s*M*64;
+	for (int bq = rq; bq < 64; bq += 4) {
+		const int b = b0 + bq;
+		if (b < M) eT[(size_t)b*64 + lane] = tile[lane*65 + bq];
+	}
+}
 
-	if (threadIdx.x == 0) {
-		if (formants && prm.formantBaseFreq <= 0) { // estimateFrequency() raw part, :929-960
-			int p0 = 0, p1 = 0, p2 = 0;
-			for (int b = 1; b < M - 1; ++b) {
-				float e = energy[b];
-				if (e < energy[b - 1] || e <= energy[b + 1]) continue;
-				if (e > energy[p0]) {
-					if (e > energy[p1]) {
-						if (e > energy[p2]) { p0 = p1; p1 = p2; p2 = b; }
-						else { p0 = p1; p1 = b; }
-					} else {
-						p0 = b;
-					}
+// One serial pass over the M bins of a [bin][64]-strided column, software-pipelined: the 16 loads of a chunk are
+// independent of the recurrence and are issued together, the recurrence then runs on registers.  step(e, x) -> e.
+template <bool DOWN, typename F>
+__device__ __forceinline__ float serialPass(const float *src, float *dst, int M, float e, F step) {
+	constexpr int U = 16;
+	for (int c0 = 0; c0 < M; c0 += U) {
+		float x[U];
+#pragma unroll
+		for (int i = 0; i < U; ++i) {
+			const int b = DOWN ? (M - 1 - c0 - i) : (c0 + i);
+			x[i] = (b >= 0 && b < M) ? src[(size_t)b*64] : 0.0f;
+		}
+#pragma unroll
+		for (int i = 0; i < U; ++i) {
+			const int b = DOWN ? (M - 1 - c0 - i) : (c0 + i);
+			if (b >= 0 && b < M) {
+				e = step(e, x[i]);
+				dst[(size_t)b*64] = e;
+			}
+		}
+	}
+	return e;
+}
+
+__global__ __launch_bounds__(64) void kFeedSerial(DevBatch d, int sBase, int hopBase) {
+	const int s = blockIdx.x, sg = sBase + s, k = threadIdx.x;
+	const int nh = d.nHops[s];
+	if (nh == 0) return;
+	const int M = d.M;
+	const float Nf = float(d.N);
+	const HopDesc hd = d.hops[(size_t)sg*d.hopStride + hopBase + (k < nh ? k : 0)];
+	const bool active = k < nh;
+	const bool mapped = active && (hd.flags & HOP_MAPPED), formants = active && (hd.flags & HOP_FORMANTS);
+	const StreamParams prm = d.params[sg];
+	const float *eT = d.energyT + (size_t)s*M*64 + k;
+	float *sT = d.smoothT + (size_t)s*M*64 + k;
+	float2 *pk = d.peaksT + (size_t)s*(M/2 + 2)*64 + k;
+
+	if (__any(mapped)) {
+		// smoothEnergy: (down, up) x 2 with the state carried through, :837-847 (first pass reads the energy)
+		const float smoothingBins = Nf/float(d.I);
+		const float slew = 1/(1 + smoothingBins*0.5f);
+		float e = 0;
+		auto pole = [slew](float acc, float x) { return acc + (x - acc)*slew; };
+		e = serialPass<true>(eT, sT, M, e, pole);
+		e = serialPass<false>(sT, sT, M, e, pole);
+		e = serialPass<true>(sT, sT, M, e, pole);
+		e = serialPass<false>(sT, sT, M, e, pole);
+		// findPeaks, :859-880: maximal runs with energy > smoothed, centroid, mapped centre
+		int nPeaks = 0;
+		bool inRun = false;
+		float bandSum = 0, energySum = 0;
+		for (int c0 = 0; c0 <= M; c0 += 16) {
+			float en16[16], sm16[16];
+#pragma unroll
+			for (int i = 0; i < 16; ++i) {
+				const int b = c0 + i;
+				en16[i] = (b < M) ? eT[(size_t)b*64] : 0.0f;
+				sm16[i] = (b < M) ? sT[(size_t)b*64] : 0.0f;
+			}
+#pragma unroll
+			for (int i = 0; i < 16; ++i) {
+				const int b = c0 + i;
+				if (b > M) break;
+				const float en = en16[i];
+				const bool above = (b < M) && en > sm16[i];
+				if (above) {
+					if (!inRun) { bandSum = 0; energySum = 0; inRun = true; }
+					bandSum += b*en;
+					energySum += en;
+				} else if (inRun) {
+					inRun = false;
+					const float avgBand = bandSum/energySum;
+					const float avgFreq = (avgBand + 0.5f)/Nf;
+					if (mapped) pk[(size_t)nPeaks*64] = make_float2(avgBand, mapFreqDev(d, prm, sg, avgFreq)*Nf - 0.5f);
+					++nPeaks;
 				}
 			}
+		}
+		// updateOutputMap, :882-917: segment rules reproduce the reference's write order (top segment written last)
+		if (mapped) {
+			float2 *mapRow = d.map + ((size_t)s*d.T + k)*M;
+			const float2 first = nPeaks > 0 ? pk[0] : make_float2(0.f, 0.f);
+			const float2 lastP = nPeaks > 0 ? pk[(size_t)(nPeaks - 1)*64] : make_float2(0.f, 0.f);
+			const int topStart = max(0, (int)lastP.y), bottomEnd = min(M, (int)ceilf(first.y));
+			int p = 1;
+			float2 prev = first, next = nPeaks > 1 ? pk[64] : first;
+			for (int b = 0; b < M; ++b) {
+				float2 mp = make_float2(float(b), 1.0f);
+				if (nPeaks > 0) {
+					if (b >= topStart) {
+						mp = make_float2(b + (lastP.x - lastP.y), 1.0f);
+					} else if (b < bottomEnd) {
+						mp = make_float2(b + (first.x - first.y), 1.0f);
+					} else if (nPeaks >= 2) {
+						// largest p in [1, nPeaks) with ceil(peaks[p-1].out) <= b
+						while (p + 1 < nPeaks && max(0, (int)ceilf(next.y)) <= b) {
+							++p;
+							prev = next;
+							next = pk[(size_t)p*64];
+						}
+						if (b < min(M, (int)ceilf(next.y))) {
+							float rangeScale = 1/(next.y - prev.y);
+							float outOffset = prev.x - prev.y;
+							float outScale = next.x - next.y - prev.x + prev.y;
+							float gradScale = outScale*rangeScale;
+							float r = (b - prev.y)*rangeScale;
+							float h = r*r*(3 - 2*r);
+							float outB = b + outOffset + h*outScale;
+							float gradH = 6*r*(1 - r);
+							mp = make_float2(outB, 1 + gradH*gradScale);
+						} // else: not covered by any segment (non-monotonic map only): identity, see DESIGN.md
+					}
+				}
+				mapRow[b] = mp;
+			}
+		}
+	}
+
+	if (__any(formants)) {
+		// updateFormants, :972-1036.  The metric is the channel-summed energy (:974-980).
+		const bool autoBase = formants && prm.formantBaseFreq <= 0;
+		float pw = 0, ww = 0;
+		if (__any(autoBase)) { // estimateFrequency() raw part, :929-960
+			int p0 = 0, p1 = 0, p2 = 0;
+			float e0 = eT[0], e1 = eT[0], e2 = eT[0]; // metric at p0, p1, p2
+			float em = eT[0], ec = eT[64];             // metric at b-1, b
+			for (int b = 1; b < M - 1; ++b) {
+				const float en = eT[(size_t)(b + 1)*64];
+				const float e = ec;
+				if (!(e < em || e <= en)) {
+					if (e > e0) {
+						if (e > e1) {
+							if (e > e2) { p0 = p1; e0 = e1; p1 = p2; e1 = e2; p2 = b; e2 = e; }
+							else { p0 = p1; e0 = e1; p1 = b; e1 = e; }
+						} else {
+							p0 = b; e0 = e;
+						}
+					}
+				}
+				em = ec;
+				ec = en;
+			}
 			int peakEstimate = p2;
-			if (energy[p1] > energy[p2]*0.1f) {
+			if (e1 > e2*0.1f) {
 				int diff = abs(peakEstimate - p1);
 				if (diff > peakEstimate/8 && diff < peakEstimate*7/8) peakEstimate = peakEstimate%diff;
-				if (energy[p0] > energy[p2]*0.01f) {
+				if (e0 > e2*0.01f) {
 					int diff2 = abs(peakEstimate - p0);
 					if (diff2 > peakEstimate/8 && diff2 < peakEstimate*7/8) peakEstimate = peakEstimate%diff2;
 				}
 			}
-			float weight = energy[p2];
-			d.est[((size_t)s*d.T + k)*2] = peakEstimate*weight;
-			d.est[((size_t)s*d.T + k)*2 + 1] = weight;
-		}
-		int nPeaks = 0;
-		if (mapped) {
-			// smoothEnergy steps 1,2: (down, up) x 2 with the state carried through, :837-847
-			const float smoothingBins = Nf/float(d.I);
-			const float slew = 1/(1 + smoothingBins*0.5f);
-			float e = 0;
-			for (int rep = 0; rep < 2; ++rep) {
-				for (int b = M - 1; b >= 0; --b) { e += (smoothed[b] - e)*slew; smoothed[b] = e; }
-				for (int b = 0; b < M; ++b) { e += (smoothed[b] - e)*slew; smoothed[b] = e; }
-			}
-			// findPeaks, :859-880
-			int start = 0;
-			while (start < M) {
-				if (energy[start] > smoothed[start]) {
-					int end = start;
-					float bandSum = 0, energySum = 0;
-					while (end < M && energy[end] > smoothed[end]) {
-						bandSum += end*energy[end];
-						energySum += energy[end];
-						++end;
-					}
-					float avgBand = bandSum/energySum;
-					float avgFreq = (avgBand + 0.5f)/Nf;
-					peaks[nPeaks++] = make_float2(avgBand, mapFreqDev(d, prm, sg, avgFreq)*Nf - 0.5f);
-					start = end;
-				}
-				++start;
+			pw = peakEstimate*e2;
+			ww = e2;
+			if (autoBase) {
+				d.est[((size_t)s*d.T + k)*2] = pw;
+				d.est[((size_t)s*d.T + k)*2 + 1] = ww;
 			}
 		}
-		*nPeaksShared = nPeaks;
-	}
-	__syncthreads();
-	if (!mapped) return; // the map stays the identity (handled by the readers)
-
-	// updateOutputMap, :882-917 -- per output bin, parallel; segment rules reproduce the reference's write order
-	const int nPeaks = *nPeaksShared;
-	float2 *mapRow = d.map + ((size_t)s*d.T + k)*M;
-	for (int b = threadIdx.x; b < M; b += blockDim.x) {
-		float2 mp = make_float2(float(b), 1.0f);
-		if (nPeaks > 0) {
-			const float2 first = peaks[0], lastP = peaks[nPeaks - 1];
-			// (with one peak every bin is below ceil(out) or at/above trunc(out), so the search branch needs >= 2)
-			if (b >= max(0, (int)lastP.y)) { // top segment is written last, :913-916
-				mp = make_float2(b + (lastP.x - lastP.y), 1.0f);
-			} else if (b < min(M, (int)ceilf(first.y))) { // :889-892
-				mp = make_float2(b + (first.x - first.y), 1.0f);
-			} else if (nPeaks >= 2) {
-				// find p in [1, nPeaks) with ceil(peaks[p-1].out) <= b < ceil(peaks[p].out); later p wins on ties
-				int lo = 1, hi = nPeaks - 1;
-				while (lo < hi) { // largest p with ceil(peaks[p-1].out) <= b
-					int mid = (lo + hi + 1) >> 1;
-					if (max(0, (int)ceilf(peaks[mid - 1].y)) <= b) lo = mid; else hi = mid - 1;
-				}
-				const float2 prev = peaks[lo - 1], next = peaks[lo];
-				if (b < min(M, (int)ceilf(next.y))) {
-					float rangeScale = 1/(next.y - prev.y);
-					float outOffset = prev.x - prev.y;
-					float outScale = next.x - next.y - prev.x + prev.y;
-					float gradScale = outScale*rangeScale;
-					float r = (b - prev.y)*rangeScale;
-					float h = r*r*(3 - 2*r);
-					float outB = b + outOffset + h*outScale;
-					float gradH = 6*r*(1 - r);
-					mp = make_float2(outB, 1 + gradH*gradScale);
-				} // else: not covered by any segment (non-monotonic map only): identity, see DESIGN.md
-			}
-		}
-		mapRow[b] = mp;
-	}
-}
-
-// ------------------------------------------------------------------------------------------------------
-// K2e: formant envelope and per-bin energy ratio (signalsmith-stretch.h:972-1036).
-// One 64-thread workgroup per (hop, stream); the max-decay / min-grow passes are serial in the bin index
-// and evaluated by lane 0 in the reference's order.
-// ------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void kFeedFormant(DevBatch d, int sBase, int hopBase) {
-	extern __shared__ __attribute__((aligned(16))) unsigned char smemRaw[];
-	float *metric = reinterpret_cast<float *>(smemRaw); // [M + 2]
-
-	const int k = blockIdx.x, s = blockIdx.y, sg = sBase + s;
-	const HopDesc hd = d.hops[(size_t)sg*d.hopStride + hopBase + k];
-	if (!(hd.flags & HOP_ACTIVE) || !(hd.flags & HOP_FORMANTS)) return;
-	const int M = d.M;
-	const float Nf = float(d.N);
-	const StreamParams prm = d.params[sg];
-	const float *esum = d.esum + ((size_t)s*d.T + k)*M;
-	for (int b = threadIdx.x; b < M + 2; b += blockDim.x) metric[b] = (b < M) ? esum[b] : 0.0f;
-	__syncthreads();
-
-	if (threadIdx.x == 0) {
 		float freqEstimate = prm.formantBaseFreq*Nf - 0.5f; // freqToBand, :982
-		if (prm.formantBaseFreq <= 0) { // smoothed estimate: replay the recurrence of :962-965 over the tile's hops
+		if (__any(autoBase)) { // :962-965 -- the estimate is smoothed from hop to hop: replay the hops of the tile in order
 			float w = d.stFreq[2*sg], wt = d.stFreq[2*sg + 1];
-			for (int j = 0; j <= k; ++j) {
-				const HopDesc hj = d.hops[(size_t)sg*d.hopStride + hopBase + j];
-				if (!(hj.flags & HOP_ACTIVE) || !(hj.flags & HOP_FORMANTS)) continue;
-				float pw = d.est[((size_t)s*d.T + j)*2], ww = d.est[((size_t)s*d.T + j)*2 + 1];
-				w += (pw - w)*0.25f;
-				wt += (ww - wt)*0.25f;
+			float mine = 0;
+			for (int j = 0; j < 64; ++j) {
+				const float pwj = __shfl(pw, j), wwj = __shfl(ww, j);
+				const int on = __shfl((int)autoBase, j);
+				if (on) {
+					w += (pwj - w)*0.25f;
+					wt += (wwj - wt)*0.25f;
+				}
+				if (j == k) mine = w/(wt + 1e-30f);
 			}
-			freqEstimate = w/(wt + 1e-30f);
+			if (autoBase) freqEstimate = mine;
 		}
 		float decay = 1 - 1/(freqEstimate*0.5f + 1);
 		float e = 0;
-		for (int rep = 0; rep < 2; ++rep) {
-			for (int b = M - 1; b >= 0; --b) { e = fmaxf(metric[b], e*decay); metric[b] = e; }
-			for (int b = 0; b < M; ++b) { e = fmaxf(metric[b], e*decay); metric[b] = e; }
+		// max-decay passes (first one reads the metric), then min-grow passes, state carried throughout
+		{
+			const float dk = decay;
+			auto maxDecay = [dk](float acc, float x) { return fmaxf(x, acc*dk); };
+			e = serialPass<true>(eT, sT, M, e, maxDecay);
+			e = serialPass<false>(sT, sT, M, e, maxDecay);
+			e = serialPass<true>(sT, sT, M, e, maxDecay);
+			e = serialPass<false>(sT, sT, M, e, maxDecay);
 		}
 		decay = 1/decay;
-		for (int rep = 0; rep < 2; ++rep) {
-			for (int b = M - 1; b >= 0; --b) { e = fminf(metric[b], e*decay); metric[b] = e; }
-			for (int b = 0; b < M; ++b) { e = fminf(metric[b], e*decay); metric[b] = e; }
+		{
+			const float dk = decay;
+			auto minGrow = [dk](float acc, float x) { return fminf(x, acc*dk); };
+			for (int rep = 0; rep < 2; ++rep) {
+				e = serialPass<true>(sT, sT, M, e, minGrow);
+				e = serialPass<false>(sT, sT, M, e, minGrow);
+			}
 		}
-	}
-	__syncthreads();
-	float *ratio = d.ratio + ((size_t)s*d.T + k)*M;
-	for (int b = threadIdx.x; b < M; b += blockDim.x) {
-		float inputF = (b + 0.5f)/Nf;
-		float outputF = prm.formantCompensation ? mapFreqDev(d, prm, sg, inputF) : inputF;
-		// invMapFormant, :920-925
-		if (outputF*prm.invFormantMultiplier > prm.freqTonalityLimit) outputF = outputF + (1 - prm.formantMultiplier)*prm.freqTonalityLimit;
-		else outputF = outputF*prm.invFormantMultiplier;
-		float inputE = metric[b];
-		float band = outputF*Nf - 0.5f;
-		float targetE = 0;
-		if (!(band < 0)) {
-			band = fminf(band, float(M));
-			int fl = (int)floorf(band);
-			float fr = band - fl;
-			float low = metric[fl], high = metric[fl + 1];
-			targetE = low + (high - low)*fr;
+		if (formants) {
+			float *ratio = d.ratio + ((size_t)s*d.T + k)*M;
+			for (int b = 0; b < M; ++b) {
+				float inputF = (b + 0.5f)/Nf;
+				float outputF = prm.formantCompensation ? mapFreqDev(d, prm, sg, inputF) : inputF;
+				// invMapFormant, :920-925
+				if (outputF*prm.invFormantMultiplier > prm.freqTonalityLimit) outputF = outputF + (1 - prm.formantMultiplier)*prm.freqTonalityLimit;
+				else outputF = outputF*prm.invFormantMultiplier;
+				const float inputE = sT[(size_t)b*64];
+				float band = outputF*Nf - 0.5f;
+				float targetE = 0;
+				if (!(band < 0)) { // getFormant, :1009-1016 (entries M and M+1 of the metric are zero)
+					band = fminf(band, float(M));
+					const int fl = (int)floorf(band);
+					const float fr = band - fl;
+					const float low = (fl < M) ? sT[(size_t)fl*64] : 0.0f, high = (fl + 1 < M) ? sT[(size_t)(fl + 1)*64] : 0.0f;
+					targetE = low + (high - low)*fr;
+				}
+				ratio[b] = targetE/(inputE + 1e-30f);
+			}
 		}
-		ratio[b] = targetE/(inputE + 1e-30f);
 	}
 }
 
@@ -1406,13 +1464,9 @@ void launchAnalyse(const DevBatch &d, const IoArgs &io, int sBase, int nStreams,
 	size_t lds = 2*(size_t)d.M*sizeof(float2);
 	hipLaunchKernelGGL(kAnalyse, grid, dim3(256), lds, st, d, io, sBase, hopBase);
 }
-void launchFeedMap(const DevBatch &d, int sBase, int nStreams, int hopBase, int tileHops, hipStream_t st) {
-	size_t lds = 2*(size_t)d.M*sizeof(float) + ((size_t)d.M/2 + 2)*sizeof(float2) + 16;
-	hipLaunchKernelGGL(kFeedMap, dim3(tileHops, nStreams), dim3(64), lds, st, d, sBase, hopBase);
-}
-void launchFeedFormant(const DevBatch &d, int sBase, int nStreams, int hopBase, int tileHops, hipStream_t st) {
-	size_t lds = ((size_t)d.M + 2)*sizeof(float);
-	hipLaunchKernelGGL(kFeedFormant, dim3(tileHops, nStreams), dim3(64), lds, st, d, sBase, hopBase);
+void launchFeed(const DevBatch &d, int sBase, int nStreams, int hopBase, hipStream_t st) {
+	hipLaunchKernelGGL(kFeedEnergy, dim3(divUp(d.M, 64), nStreams), dim3(256), 64*65*sizeof(float), st, d, sBase, hopBase);
+	hipLaunchKernelGGL(kFeedSerial, dim3(nStreams), dim3(64), 0, st, d, sBase, hopBase);
 }
 template <int CH>
 static void launchPredictT(const DevBatch &d, int sBase, int nStreams, int hopBase, int tileHops, bool plain, hipStream_t st) {

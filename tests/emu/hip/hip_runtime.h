@@ -62,6 +62,14 @@ static inline hipError_t hipDeviceGetStreamPriorityRange(int *lo, int *hi) { *lo
 static inline hipError_t hipStreamCreateWithPriority(hipStream_t *s, unsigned, int) { *s = (hipStream_t)1; return 0; }
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
 #define __builtin_amdgcn_s_sleep(x) emuSyncThreads()
+// wave-level votes/shuffles are only used by single-wave kernels whose lanes all reach them; the emulator runs lanes one at a
+// time, so these are provided by tests/emu/hip_emu.cpp with a gather-then-yield protocol
+bool emuAny(bool v);
+float emuShflF(float v, int lane);
+int emuShflI(int v, int lane);
+#define __any(v) emuAny(v)
+static inline float __shfl(float v, int lane) { return emuShflF(v, lane); }
+static inline int __shfl(int v, int lane) { return emuShflI(v, lane); }
 static inline int atomicAdd(int *p, int v) { int o = *p; *p = o + v; return o; }
 static inline hipError_t hipStreamDestroy(hipStream_t) { return 0; }
 static inline hipError_t hipMalloc(void **p, size_t n) { *p = std::calloc(n ? n : 1, 1); return *p ? 0 : 2; }

@@ -65,3 +65,39 @@ void emuLaunch(dim3 grid, dim3 block, size_t ldsBytes, const std::function<void(
 		}
 	}
 }
+
+// ---- wave-level collectives for 64-thread (single wave) kernels: every lane deposits its value, yields once so that
+// all lanes of the block have deposited, then reads.  Two alternating banks keep back-to-back collectives apart.
+namespace {
+float shflBankF[2][1024];
+int shflBankI[2][1024];
+bool anyBank[2][1024];
+int collectiveSeq[1024];
+}
+static int laneIndex() { return (int)(threadIdx.x + blockDim.x*(threadIdx.y + blockDim.y*threadIdx.z)); }
+bool emuAny(bool v) {
+	const int me = laneIndex(), bank = collectiveSeq[me]++ & 1;
+	anyBank[bank][me] = v;
+	emuSyncThreads();
+	bool r = false;
+	const int n = (int)(blockDim.x*blockDim.y*blockDim.z);
+	for (int i = 0; i < n; ++i) r = r || anyBank[bank][i];
+	emuSyncThreads();
+	return r;
+}
+float emuShflF(float v, int lane) {
+	const int me = laneIndex(), bank = collectiveSeq[me]++ & 1;
+	shflBankF[bank][me] = v;
+	emuSyncThreads();
+	float r = shflBankF[bank][lane];
+	emuSyncThreads();
+	return r;
+}
+int emuShflI(int v, int lane) {
+	const int me = laneIndex(), bank = collectiveSeq[me]++ & 1;
+	shflBankI[bank][me] = v;
+	emuSyncThreads();
+	int r = shflBankI[bank][lane];
+	emuSyncThreads();
+	return r;
+}
