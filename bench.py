@@ -183,10 +183,12 @@ def main():
         tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get(dom)
+                traffic = json.load(open(tpath)).get({"analyse": "kAnalyseFast", "predict": "kPredictB", "chain": "kVocoder" if C <= 2 else "kChain",
+                                                      "synth": "kSynthFast", "emit": "kEmit"}[dom])
             except Exception:
                 traffic = None
-        roofline = dict(bound="hbm", kernel={"analyse": "kAnalyse", "predict": "kPredict", "chain": "kChain", "synth": "kSynth", "emit": "kEmit"}[dom],
+        names = {"analyse": "kAnalyseFast", "predict": "kPredictB", "chain": "kVocoder" if C <= 2 else "kChain", "synth": "kSynthFast", "emit": "kEmit"}
+        roofline = dict(bound="hbm", kernel=names[dom],
                         achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved/HBM_PEAK_GBS, traffic=traffic,
                         avg_launch_ms=avg_ms, launches_per_step=launch_count[dom],
                         algorithmic_bytes_per_channel_hop=bytes_per_chop, channel_hops_per_launch=chops_per_launch,
