@@ -251,7 +251,7 @@ void Batch::allocateWorkspace() {
 	// Per (stream, hop, channel): 4 complex rows + 1 float row of M bins + one B-sample frame, plus the skewed records.
 	// Sub-batch the streams so the tile workspace stays under a budget (default 48 GiB of the 288 GB HBM).
 	double budgetGiB = 24; // per workspace; there are two
-	if (const char *env = std::getenv("SMST_WORKSPACE_GIB")) budgetGiB = std::max(0.25, atof(env));
+	if (const char *env = std::getenv("SMST_WORKSPACE_GIB")) budgetGiB = std::max(0.0005, atof(env));
 	const size_t recChunks = (9 + 3*(size_t)C + 3)/4;
 	d.recSteps = ((M + d.lag*(d.T - 1) + 63)/64)*64 + 8;
 	d.recPitch = int(recChunks*64 + 16);

@@ -1091,13 +1091,13 @@ __global__ __launch_bounds__(64) void kChain(DevBatch d, int sBase, int hopBase)
 // slot (units produced, blocks consumed); LDS operations of a wave execute in order, so a counter update issued
 // after the data writes is seen after them.  The consumer raises its own issue priority: it is the serial path.
 // ------------------------------------------------------------------------------------------------------
-constexpr int kVocBlockSteps = 8, kVocBlocks = 3, kVocWaves = 16;
+constexpr int kVocBlockSteps = 8, kVocBlocks = 4, kVocWaves = 16;
 
 __device__ __forceinline__ int ldsPeek(volatile int *p) { return *p; }
 
 template <int CH, bool PLAIN>
 __global__ __launch_bounds__(64*kVocWaves) __attribute__((amdgpu_waves_per_eu(4, 4))) void kVocoder(DevBatch d, int sBase, int hopBase) {
-	constexpr int NF = 9 + 5*CH, NCH = (NF + 3)/4, BS = kVocBlockSteps, NB = kVocBlocks, NP = kVocWaves - kVocWaves/4;
+	constexpr int NF = 9 + 3*CH, NCH = (NF + 3)/4, BS = kVocBlockSteps, NB = kVocBlocks, NP = kVocWaves - kVocWaves/4;
 	extern __shared__ __attribute__((aligned(16))) unsigned char smemRaw[];
 	const int R = d.ringSlots, Rm = R - 1;
 	float4 *recs = reinterpret_cast<float4 *>(smemRaw);                 // [(slot*BS + st)*NCH + j][64 lanes]
@@ -1144,7 +1144,7 @@ __global__ __launch_bounds__(64*kVocWaves) __attribute__((amdgpu_waves_per_eu(4,
 			float f[NCH*4];
 #pragma unroll
 			for (int j = 0; j < NCH*4; ++j) f[j] = 0.0f;
-			if (row < nh && b >= 0 && b < M && d.debugMode != 1) computeRecord<CH, PLAIN, true, false>(d, hopsLds[row], hopsLds[row > 0 ? row - 1 : 0], s, sg, row, b, f);
+			if (row < nh && b >= 0 && b < M && d.debugMode != 1) computeRecord<CH, PLAIN, false, false>(d, hopsLds[row], hopsLds[row > 0 ? row - 1 : 0], s, sg, row, b, f);
 #pragma unroll
 			for (int j = 0; j < NCH; ++j) recs[((slot*BS + st)*NCH + j)*64 + row] = make_float4(f[4*j], f[4*j + 1], f[4*j + 2], f[4*j + 3]);
 			asm volatile("" ::: "memory");
@@ -1207,7 +1207,7 @@ __global__ __launch_bounds__(64*kVocWaves) __attribute__((amdgpu_waves_per_eu(4,
 				float sm = f[11];
 #pragma unroll
 				for (int c = 1; c < CH; ++c) {
-					if (c == mc) { o1 = own1[c]; pm = make_float2(f[9 + 5*c], f[10 + 5*c]); sm = f[11 + 5*c]; }
+					if (c == mc) { o1 = own1[c]; pm = make_float2(f[9 + 3*c], f[10 + 3*c]); sm = f[11 + 3*c]; }
 				}
 				const int ringRow = mc*R;
 				const float2 oL = lds[(ringRow + ((b - L) & Rm))*64 + k];
@@ -1222,7 +1222,8 @@ __global__ __launch_bounds__(64*kVocWaves) __attribute__((amdgpu_waves_per_eu(4,
 				const float2 om = makeOutput(phi, pm, sm); // :788
 #pragma unroll
 				for (int c = 0; c < CH; ++c) {
-					float2 oc = makeOutput(cmul(om, make_float2(f[12 + 5*c], f[13 + 5*c])), make_float2(f[9 + 5*c], f[10 + 5*c]), f[11 + 5*c]); // :791-800
+					const float2 pc = make_float2(f[9 + 3*c], f[10 + 3*c]);
+					float2 oc = makeOutput(cmul(om, cmulc(pc, pm)), pc, f[11 + 3*c]); // channel lock, :791-800
 					if (c == mc) oc = om;
 					if (!valid) oc = make_float2(0.f, 0.f);
 					own1[c] = oc;
@@ -1486,7 +1487,7 @@ void launchPredictFused(const DevBatch &d, int sBase, int nStreams, int hopBase,
 // ... and the fused producer/consumer recurrence
 template <int CH>
 static void launchVocoderT(const DevBatch &d, int sBase, int nStreams, int hopBase, bool plain, hipStream_t st) {
-	constexpr int NCH = (9 + 5*CH + 3)/4;
+	constexpr int NCH = (9 + 3*CH + 3)/4;
 	const size_t lds = (size_t)kVocBlocks*kVocBlockSteps*NCH*64*sizeof(float4) + ((size_t)CH*d.ringSlots*64 + (size_t)CH*128)*sizeof(float2) + 64 + 64*sizeof(HopDesc);
 	if (plain) hipLaunchKernelGGL((kVocoder<CH, true>), dim3(nStreams), dim3(64*kVocWaves), lds, st, d, sBase, hopBase);
 	else hipLaunchKernelGGL((kVocoder<CH, false>), dim3(nStreams), dim3(64*kVocWaves), lds, st, d, sBase, hopBase);

@@ -197,3 +197,57 @@ def case_random_time_factor(lib, ref):
     a, b = g.process(x, 9000), r.process(x, 9000)
     ra, rb = np.sqrt(np.mean(a[:, 2000:]**2)), np.sqrt(np.mean(b[:, 2000:]**2))
     assert abs(ra/rb - 1) < 0.1
+
+
+def case_sub_batches(lib, ref, monkeypatch):
+    """A tiny workspace budget forces the engine to process the streams in several sub-batches (and several tiles
+    each): results must not depend on it."""
+    pkg = package()
+    C, sr, S, n = 2, 48000, 5, 128*70
+    xs = np.stack([synth_input(s, C, n, sr) for s in range(S)])
+    nout = int(n*1.25)
+    b = pkg.StretchBatch(S, C, block=512, interval=128, lib=lib)
+    whole = b.process(xs, nout)
+    b.close()
+    full = None
+    monkeypatch.setenv("SMST_WORKSPACE_GIB", "0.009")  # ~9 MiB per workspace: 2 streams per sub-batch at this geometry
+    b = pkg.StretchBatch(S, C, block=512, interval=128, lib=lib)
+    assert b.workspaceBytes() <= 2*9.7e6
+    split = b.process(xs, nout)
+    b.close()
+    assert np.array_equal(whole, split)
+
+
+def case_cmd_main_flow(lib, ref, sr=44100, seconds=1.5, time_factor=1.0, semitones=0.0, channels=1):
+    """BASELINE config 1: the call sequence of the reference's CLI (cmd/main.cpp:44-82) -- presetDefault,
+    setTransposeSemitones(st, 8000/sr), setFormantSemitones(0), setFormantBase(100/sr), outputSeek, process, flush --
+    on a mono 44.1 kHz stream at 1.0x / 0 st, product vs checker; at 1.0x the result is also the input itself."""
+    n = int(sr*seconds)
+    x = synth_input(0, channels, n, sr)
+
+    def play(o, xx):
+        cfg = dict(preset="default", sample_rate=float(sr))
+        del cfg
+        o.setTransposeSemitones(semitones, 8000.0/sr)   # cmd/main.cpp:46 (defaults :22-28)
+        o.setFormantSemitones(0.0, False)                # :47
+        o.setFormantBase(100.0/sr)                       # :48
+        out_len = int(round(n*time_factor))              # :36
+        seek_len = o.outputSeekLength(1/time_factor)     # :58
+        o.outputSeek(xx[:, :seek_len])                   # :59
+        output_index = out_len - o.intervalSamples()     # :62
+        output_pos = output_index + o.outputLatency()    # :65
+        input_pos = int(round(output_pos/time_factor))   # :67
+        input_index = input_pos + o.inputLatency()       # :69
+        padded = np.zeros((channels, max(input_index, n)), np.float32)  # inWav.resize(inputIndex), :73
+        padded[:, :n] = xx
+        a = o.process(padded[:, seek_len:input_index], output_index)    # :77-78
+        b = o.flush(out_len - output_index)                              # :81-82
+        return np.concatenate([a, b], axis=1)
+    y, o = check_scenario(lib, ref, dict(preset="default", sample_rate=float(sr)), x, play, "cmd/main.cpp flow")
+    if time_factor == 1.0 and semitones == 0.0:
+        # the input itself, apart from the pre-roll fold-back in the first interval (reference: 7e-3 there) and the
+        # flush fade in the last one
+        head = 1323 if sr == 44100 else 1440
+        tail = 2*head
+        assert rel_rms(y[:, head:-tail], x[:, head:y.shape[1] - tail]) < 5e-6
+        assert rel_rms(o[:, head:-tail], x[:, head:o.shape[1] - tail]) < 5e-6

@@ -38,3 +38,11 @@ def test_batch_ragged(emu, ref):
 
 def test_random_time_factor(emu, ref):
     pc.case_random_time_factor(emu, ref)
+
+
+def test_sub_batches(emu, ref, monkeypatch):
+    pc.case_sub_batches(emu, ref, monkeypatch)
+
+
+def test_cmd_main_flow_config1(emu, ref):
+    pc.case_cmd_main_flow(emu, ref)

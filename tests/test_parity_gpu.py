@@ -176,3 +176,13 @@ def test_host_and_device_memory_agree(hip):
     b.synchronize()
     assert np.array_equal(yh, yd.cpu().numpy())
     b.close()
+
+
+def test_sub_batches(hip, ref, monkeypatch):
+    pc.case_sub_batches(hip, ref, monkeypatch)
+
+
+def test_cmd_main_flow_config1(hip, ref):
+    """BASELINE config 1 (1 mono stream, 44.1 kHz, presetDefault, 1.0x / 0 st via the cmd/main.cpp call sequence)."""
+    pc.case_cmd_main_flow(hip, ref)
+    pc.case_cmd_main_flow(hip, ref, sr=48000, seconds=2.0, time_factor=1.3, semitones=3.0, channels=2)
