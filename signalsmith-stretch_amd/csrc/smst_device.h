@@ -68,6 +68,7 @@ void launchPredict(const DevBatch &d, int sBase, int nStreams, int hopBase, int 
 void launchChain(const DevBatch &d, int sBase, int nStreams, int hopBase, hipStream_t st);
 void launchPredictFused(const DevBatch &d, int sBase, int nStreams, int hopBase, int tileHops, bool plain, hipStream_t st);
 void launchVocoder(const DevBatch &d, int sBase, int nStreams, int hopBase, bool plain, hipStream_t st);
+bool fusedSupported(const DevBatch &d);
 void launchSynth(const DevBatch &d, int sBase, int nStreams, int hopBase, int tileHops, hipStream_t st);
 void launchEmit(const DevBatch &d, const IoArgs &io, int sBase, int nStreams, int tileIndex, int maxSpan, hipStream_t st);
 void launchCarryFeed(const DevBatch &d, int sBase, int nStreams, int hopBase, hipStream_t st);

@@ -615,7 +615,7 @@ void Batch::process(const float *in, long long inSS, long long inCS, const int *
 			const int tileHops = std::min(T, std::max(1, maxHops - hopBase));
 			const int slot = q & 1;
 			const bool plain = !(th[1] || th[2]);
-			const bool fused = (C <= 2) && !noFuse; // mono/stereo: records stay in LDS (kVocoder)
+			const bool fused = fusedSupported(d) && !noFuse; // mono/stereo: records stay in LDS (kVocoder)
 			const TileBuffers &w = slots[slot];
 			DevBatch dd = d;
 			dd.Xcur = w.Xcur; dd.Xprev = w.Xprev; dd.P = w.P; dd.OUT = w.OUT; dd.REC = w.REC; dd.dump = w.dump; dd.E = w.E;

@@ -1085,42 +1085,52 @@ __global__ __launch_bounds__(64) void kChain(DevBatch d, int sBase, int hopBase)
 
 // ------------------------------------------------------------------------------------------------------
 // K3 fused (mono / stereo): the recurrence and its coefficients in ONE kernel, so the records never touch HBM.
-// One workgroup of 8 waves per stream: wave 0 is the CONSUMER (the skewed wavefront of kChain, one lane per hop);
-// waves 1-7 are PRODUCERS that compute the records (same arithmetic as kPredictB, 8 rows x 8 steps per wave-pass,
-// reads coalesced along the bin index) into an LDS ring of 3 blocks x 8 steps.  Hand-off is by two LDS words per
-// slot (units produced, blocks consumed); LDS operations of a wave execute in order, so a counter update issued
-// after the data writes is seen after them.  The consumer raises its own issue priority: it is the serial path.
+// One workgroup of 16 waves per stream: wave 0 is the CONSUMER (the skewed wavefront, one lane per hop); 12 of
+// the other waves are PRODUCERS that compute the records (same arithmetic as kPredictB, 8 rows x 8 steps per
+// wave-pass, branch-free loads) into an LDS ring of 3 blocks x 8 steps; waves 4, 8, 12 would share the
+// consumer's SIMD and retire at once.  Hand-off is by LDS counters (units produced per slot, blocks consumed); LDS
+// operations of a wave execute in order, so a counter update issued after the data writes is seen after them.
+//
+// The consumer keeps the serial path in registers: each lane holds its last 8 outputs per channel (h[t & 7]), so
+//   own taps      out[b-1], out[b-L]                    = h[(i+7)&7], h[(i+8-L)&7]
+//   previous hop  out_{k-1}[b+1], out_{k-1}[b+L]        = the SAME two registers of lane k-1 (it runs lag = L+1 bins
+//                                                         ahead), fetched with one DPP wave_shr:1 each
+// and only lane 0 (whose "previous hop" is the carried Band.output) reads them from the staged LDS copy, one step
+// ahead.  No LDS round trip and no memory load sits on the recurrence.
 // ------------------------------------------------------------------------------------------------------
-constexpr int kVocBlockSteps = 8, kVocBlocks = 4, kVocWaves = 16;
+constexpr int kVocBlockSteps = 8, kVocBlocks = 3, kVocWaves = 16;
 
 __device__ __forceinline__ int ldsPeek(volatile int *p) { return *p; }
+__device__ __forceinline__ float2 fromLaneBelow(float2 v) { // lane k receives lane k-1's value (lane 0: zero)
+	return make_float2(__int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v.x), 0x138, 0xf, 0xf, false)),
+	                   __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v.y), 0x138, 0xf, 0xf, false)));
+}
 
-template <int CH, bool PLAIN>
-__global__ __launch_bounds__(64*kVocWaves) __attribute__((amdgpu_waves_per_eu(4, 4))) void kVocoder(DevBatch d, int sBase, int hopBase) {
+template <int CH, bool PLAIN, int L>
+__global__ __launch_bounds__(64*kVocWaves) void kVocoder(DevBatch d, int sBase, int hopBase) {
 	constexpr int NF = 9 + 3*CH, NCH = (NF + 3)/4, BS = kVocBlockSteps, NB = kVocBlocks, NP = kVocWaves - kVocWaves/4;
+	constexpr int lag = L + 1;
+	static_assert(BS == 8 && L >= 1 && L <= 7, "history registers are indexed by step & 7");
 	extern __shared__ __attribute__((aligned(16))) unsigned char smemRaw[];
-	const int R = d.ringSlots, Rm = R - 1;
 	float4 *recs = reinterpret_cast<float4 *>(smemRaw);                 // [(slot*BS + st)*NCH + j][64 lanes]
-	float2 *lds = reinterpret_cast<float2 *>(recs + NB*BS*NCH*64);      // ring [CH][R][64], then stage [CH][128]
-	const int stageBase = CH*R*64;
-	volatile int *sync = reinterpret_cast<volatile int *>(lds + stageBase + CH*128); // [0..NB) produced, [NB] consumed
-	HopDesc *hopsLds = reinterpret_cast<HopDesc *>(const_cast<int *>(sync) + 16);         // the tile's 64 hop descriptors
+	float2 *stage = reinterpret_cast<float2 *>(recs + NB*BS*NCH*64);    // [CH][128]: carried Band.output, 128-bin window
+	volatile int *sync = reinterpret_cast<volatile int *>(stage + CH*128); // [0..NB) units produced, [NB] blocks consumed
+	HopDesc *hopsLds = reinterpret_cast<HopDesc *>(const_cast<int *>(sync) + 16); // the tile's 64 hop descriptors
 
 	const int s = blockIdx.x, sg = sBase + s;
 	const int nh = d.nHops[s];
 	if (nh == 0) return;
 	const int wave = threadIdx.x >> 6, k = threadIdx.x & 63;
-	const int M = d.M, L = d.L, lag = d.lag;
+	const int M = d.M;
 	const int steps = M + lag*(nh - 1);
 	const int chunks = (steps + 63) >> 6;
 	const int totalBlocks = chunks*(64/BS);
 	const float2 *stOut = d.stOut + stateRow(d, sg, 0);
 
-	// prologue (all waves): clear the ring, stage bins [0,128) of the carried Band.output, clear the hand-off words
-	for (int i = threadIdx.x; i < CH*R*64; i += blockDim.x) lds[i] = make_float2(0.f, 0.f);
+	// prologue (all waves): stage bins [0,128) of the carried Band.output, clear the hand-off words, cache the hop table
 	for (int i = threadIdx.x; i < CH*128; i += blockDim.x) {
 		const int c = i >> 7, bb = i & 127;
-		lds[stageBase + i] = (bb < M) ? stOut[(size_t)c*M + bb] : make_float2(0.f, 0.f);
+		stage[i] = (bb < M) ? stOut[(size_t)c*M + bb] : make_float2(0.f, 0.f);
 	}
 	if (threadIdx.x <= NB) sync[threadIdx.x] = 0;
 	if (threadIdx.x < 64) hopsLds[threadIdx.x] = d.hops[(size_t)sg*d.hopStride + hopBase + threadIdx.x];
@@ -1128,9 +1138,7 @@ __global__ __launch_bounds__(64*kVocWaves) __attribute__((amdgpu_waves_per_eu(4,
 
 	if (wave > 0) {
 		// ---------------- producers ----------------
-		// A workgroup's waves are dealt to the CU's 4 SIMDs cyclically, so waves 4, 8, 12 would share the consumer's
-		// SIMD and steal its issue slots: they retire at once and the consumer owns its SIMD (12 producers on 3 SIMDs).
-		if ((wave & 3) == 0) return;
+		if ((wave & 3) == 0) return; // would share the consumer's SIMD
 		const int pIndex = wave - 1 - (wave >> 2); // 0..NP-1 over the remaining waves
 		const int r = k & 7, st = k >> 3; // 8 adjacent lanes = 8 rows of one step: their LDS record writes are contiguous
 		for (int u = pIndex; u < totalBlocks*8; u += NP) {
@@ -1160,15 +1168,22 @@ __global__ __launch_bounds__(64*kVocWaves) __attribute__((amdgpu_waves_per_eu(4,
 	float2 *OUT = d.OUT + rowOf(d, s, active ? k : 0, 0);
 	float2 *dump = d.dump + (size_t)s*CH*64 + k;
 	float2 pf[CH];
-	float2 own1[CH];
+	float2 h[8][CH];   // this lane's outputs of the last 8 steps
+	float2 sv1[CH], svL[CH]; // lane 0: carried outputs at bins b+1 and b+L of the NEXT step, read one step ahead
 #pragma unroll
-	for (int c = 0; c < CH; ++c) { pf[c] = make_float2(0.f, 0.f); own1[c] = make_float2(0.f, 0.f); }
+	for (int c = 0; c < CH; ++c) {
+		pf[c] = make_float2(0.f, 0.f);
+#pragma unroll
+		for (int i = 0; i < 8; ++i) h[i][c] = make_float2(0.f, 0.f);
+		sv1[c] = stage[c*128 + ((1 - kLag) & 127)];
+		svL[c] = stage[c*128 + ((L - kLag) & 127)];
+	}
 
 	for (int ch = 0; ch < chunks; ++ch) {
 		const int tb = ch << 6;
 		if (ch > 0) {
 #pragma unroll
-			for (int c = 0; c < CH; ++c) lds[stageBase + c*128 + ((tb + 64 + k) & 127)] = pf[c];
+			for (int c = 0; c < CH; ++c) stage[c*128 + ((tb + 64 + k) & 127)] = pf[c];
 		}
 		{
 			const int bb = tb + 128 + k;
@@ -1189,32 +1204,43 @@ __global__ __launch_bounds__(64*kVocWaves) __attribute__((amdgpu_waves_per_eu(4,
 			while (ldsPeek(&sync[slot]) < need) __builtin_amdgcn_s_sleep(1);
 			asm volatile("" ::: "memory");
 			const float4 *blockRecs = recs + (size_t)slot*BS*NCH*64 + k;
+			float4 q[NCH];
 #pragma unroll
-			for (int stp = 0; stp < BS; ++stp) {
+			for (int j = 0; j < NCH; ++j) q[j] = blockRecs[j*64];
+#pragma unroll
+			for (int i = 0; i < BS; ++i) {
 				if (d.debugMode == 2) break; // experiment: consumer only acknowledges blocks
-				const int t = tb + blk*BS + stp;
+				const int t = tb + blk*BS + i;
 				float f[NCH*4];
 #pragma unroll
-				for (int j = 0; j < NCH; ++j) {
-					const float4 v = blockRecs[(stp*NCH + j)*64];
-					f[4*j] = v.x; f[4*j + 1] = v.y; f[4*j + 2] = v.z; f[4*j + 3] = v.w;
+				for (int j = 0; j < NCH; ++j) { f[4*j] = q[j].x; f[4*j + 1] = q[j].y; f[4*j + 2] = q[j].z; f[4*j + 3] = q[j].w; }
+				if (i + 1 < BS) {
+#pragma unroll
+					for (int j = 0; j < NCH; ++j) q[j] = blockRecs[((i + 1)*NCH + j)*64];
 				}
 				const int b = t - kLag;
 				const bool valid = active && b >= 0 && b < M;
 				int mc = __float_as_int(f[8]);
 				mc = (mc < 0) ? 0 : ((mc > CH - 1) ? CH - 1 : mc);
-				float2 o1 = own1[0], pm = make_float2(f[9], f[10]);
+				// taps: own history, and lane k-1's history (lane 0: the staged carried state)
+				float2 o1 = h[(i + 7) & 7][0], oL = h[(i + 8 - L) & 7][0];
+				float2 p1 = fromLaneBelow(oL), pL = fromLaneBelow(o1);
+				if (k == 0) { p1 = sv1[0]; pL = svL[0]; }
+				float2 pm = make_float2(f[9], f[10]);
 				float sm = f[11];
 #pragma unroll
 				for (int c = 1; c < CH; ++c) {
-					if (c == mc) { o1 = own1[c]; pm = make_float2(f[9 + 3*c], f[10 + 3*c]); sm = f[11 + 3*c]; }
+					const float2 o1c = h[(i + 7) & 7][c], oLc = h[(i + 8 - L) & 7][c];
+					float2 p1c = fromLaneBelow(oLc), pLc = fromLaneBelow(o1c);
+					if (k == 0) { p1c = sv1[c]; pLc = svL[c]; }
+					if (c == mc) { o1 = o1c; oL = oLc; p1 = p1c; pL = pLc; pm = make_float2(f[9 + 3*c], f[10 + 3*c]); sm = f[11 + 3*c]; }
 				}
-				const int ringRow = mc*R;
-				const float2 oL = lds[(ringRow + ((b - L) & Rm))*64 + k];
-				const int a1 = (k == 0) ? stageBase + mc*128 + ((b + 1) & 127) : (ringRow + ((b + 1) & Rm))*64 + k - 1;
-				const int aL = (k == 0) ? stageBase + mc*128 + ((b + L) & 127) : (ringRow + ((b + L) & Rm))*64 + k - 1;
-				const float2 p1 = lds[a1];
-				const float2 pL = lds[aL];
+				// next step's staged values (only lane 0 uses them): bins (b+1)+1 and (b+1)+L
+#pragma unroll
+				for (int c = 0; c < CH; ++c) {
+					sv1[c] = stage[c*128 + ((b + 2) & 127)];
+					svL[c] = stage[c*128 + ((b + 1 + L) & 127)];
+				}
 				float2 phi = cmul(oL, make_float2(f[2], f[3]));
 				phi = cadd(phi, cmul(p1, make_float2(f[4], f[5])));
 				phi = cadd(phi, cmul(pL, make_float2(f[6], f[7])));
@@ -1226,14 +1252,10 @@ __global__ __launch_bounds__(64*kVocWaves) __attribute__((amdgpu_waves_per_eu(4,
 					float2 oc = makeOutput(cmul(om, cmulc(pc, pm)), pc, f[11 + 3*c]); // channel lock, :791-800
 					if (c == mc) oc = om;
 					if (!valid) oc = make_float2(0.f, 0.f);
-					own1[c] = oc;
-					lds[(c*R + (b & Rm))*64 + k] = oc;
+					h[i][c] = oc;
 					float2 *dst = valid ? OUT + ((size_t)c*d.Mp + b) : dump + c*64;
 					*dst = oc;
 				}
-				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-				__builtin_amdgcn_wave_barrier();
-				__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 			}
 			asm volatile("" ::: "memory");
 			if (k == 0) sync[NB] = n + 1; // this block's slot may be refilled
@@ -1485,13 +1507,25 @@ void launchPredictFused(const DevBatch &d, int sBase, int nStreams, int hopBase,
 	if (!plain) hipLaunchKernelGGL(kPredictA, dim3(divUp(d.M, 256), tileHops, nStreams), dim3(256), 0, st, d, sBase, hopBase);
 }
 // ... and the fused producer/consumer recurrence
+template <int CH, int L>
+static void launchVocoderTL(const DevBatch &d, int sBase, int nStreams, int hopBase, bool plain, hipStream_t st) {
+	constexpr int NCH = (9 + 3*CH + 3)/4;
+	const size_t lds = (size_t)kVocBlocks*kVocBlockSteps*NCH*64*sizeof(float4) + (size_t)CH*128*sizeof(float2) + 64 + 64*sizeof(HopDesc);
+	if (plain) hipLaunchKernelGGL((kVocoder<CH, true, L>), dim3(nStreams), dim3(64*kVocWaves), lds, st, d, sBase, hopBase);
+	else hipLaunchKernelGGL((kVocoder<CH, false, L>), dim3(nStreams), dim3(64*kVocWaves), lds, st, d, sBase, hopBase);
+}
 template <int CH>
 static void launchVocoderT(const DevBatch &d, int sBase, int nStreams, int hopBase, bool plain, hipStream_t st) {
-	constexpr int NCH = (9 + 3*CH + 3)/4;
-	const size_t lds = (size_t)kVocBlocks*kVocBlockSteps*NCH*64*sizeof(float4) + ((size_t)CH*d.ringSlots*64 + (size_t)CH*128)*sizeof(float2) + 64 + 64*sizeof(HopDesc);
-	if (plain) hipLaunchKernelGGL((kVocoder<CH, true>), dim3(nStreams), dim3(64*kVocWaves), lds, st, d, sBase, hopBase);
-	else hipLaunchKernelGGL((kVocoder<CH, false>), dim3(nStreams), dim3(64*kVocWaves), lds, st, d, sBase, hopBase);
+	switch (d.L) { // longVerticalStep = round(fftSamples/interval): 4 (presetDefault @48k), 5 (@44.1k), 3 (presetCheaper)
+	case 3: launchVocoderTL<CH, 3>(d, sBase, nStreams, hopBase, plain, st); break;
+	case 4: launchVocoderTL<CH, 4>(d, sBase, nStreams, hopBase, plain, st); break;
+	case 5: launchVocoderTL<CH, 5>(d, sBase, nStreams, hopBase, plain, st); break;
+	case 2: launchVocoderTL<CH, 2>(d, sBase, nStreams, hopBase, plain, st); break;
+	case 6: launchVocoderTL<CH, 6>(d, sBase, nStreams, hopBase, plain, st); break;
+	default: launchVocoderTL<CH, 7>(d, sBase, nStreams, hopBase, plain, st); break; // only reached with L == 7 (see fusedSupported)
+	}
 }
+bool fusedSupported(const DevBatch &d) { return d.C <= 2 && d.L >= 2 && d.L <= 7 && d.lag == d.L + 1; }
 void launchVocoder(const DevBatch &d, int sBase, int nStreams, int hopBase, bool plain, hipStream_t st) {
 	if (d.C == 1) launchVocoderT<1>(d, sBase, nStreams, hopBase, plain, st);
 	else launchVocoderT<2>(d, sBase, nStreams, hopBase, plain, st);

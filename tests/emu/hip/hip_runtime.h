@@ -70,6 +70,8 @@ int emuShflI(int v, int lane);
 #define __any(v) emuAny(v)
 static inline float __shfl(float v, int lane) { return emuShflF(v, lane); }
 static inline int __shfl(int v, int lane) { return emuShflI(v, lane); }
+int emuDppShr1(int old, int v);
+static inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int, int, bool) { (void)ctrl; return emuDppShr1(old, src); }
 static inline int atomicAdd(int *p, int v) { int o = *p; *p = o + v; return o; }
 static inline hipError_t hipStreamDestroy(hipStream_t) { return 0; }
 static inline hipError_t hipMalloc(void **p, size_t n) { *p = std::calloc(n ? n : 1, 1); return *p ? 0 : 2; }

@@ -101,3 +101,15 @@ int emuShflI(int v, int lane) {
 	emuSyncThreads();
 	return r;
 }
+
+// DPP wave_shr:1 (the only control the product uses): lane i of a 64-lane wave receives lane i-1's value, lane 0 keeps
+// `old`.  Lanes of a wave run consecutively in index order between yields, so lane i-1 has always executed the same
+// call instance already: a per-lane ring indexed by the call counter needs no yield (at most 512 calls per lane happen
+// between two yields of the recurrence wave).
+namespace { int dppRing[1024][1024]; unsigned dppSeq[1024]; }
+int emuDppShr1(int old, int v) {
+	const int me = laneIndex();
+	const unsigned seq = dppSeq[me]++ & 1023u;
+	dppRing[me][seq] = v;
+	return (me & 63) ? dppRing[me - 1][seq] : old;
+}
