@@ -962,13 +962,13 @@ __global__ __launch_bounds__(256) void kPredictB(DevBatch d, int sBase, int hopB
 // on the serial path.
 // ------------------------------------------------------------------------------------------------------
 __device__ __forceinline__ float2 makeOutput(float2 phase, float2 input, float sqrtEnergy) { // :596-603
-	float n = cnorm(phase);
-	if (n <= 1e-15f) {
-		phase = input;
-		n = cnorm(input) + 1e-15f;
-	}
-	float g = sqrtEnergy*__builtin_amdgcn_rsqf(n);
-	return cscale(phase, g);
+	// branch-free: the fallback (prediction too weak -> use the input's phase) is a select, not a divergent branch
+	const float n = cnorm(phase);
+	const bool weak = n <= 1e-15f;
+	const float nIn = cnorm(input) + 1e-15f;
+	const float2 ph = weak ? input : phase;
+	const float g = sqrtEnergy*__builtin_amdgcn_rsqf(weak ? nIn : n);
+	return cscale(ph, g);
 }
 
 template <int CH>
@@ -1102,8 +1102,8 @@ constexpr int kVocBlockSteps = 8, kVocBlocks = 3, kVocWaves = 16;
 
 __device__ __forceinline__ int ldsPeek(volatile int *p) { return *p; }
 __device__ __forceinline__ float2 fromLaneBelow(float2 v) { // lane k receives lane k-1's value (lane 0: zero)
-	return make_float2(__int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v.x), 0x138, 0xf, 0xf, false)),
-	                   __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v.y), 0x138, 0xf, 0xf, false)));
+	return make_float2(__int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v.x), 0x138, 0xf, 0xf, true)),
+	                   __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v.y), 0x138, 0xf, 0xf, true)));
 }
 
 template <int CH, bool PLAIN, int L>
@@ -1204,20 +1204,20 @@ __global__ __launch_bounds__(64*kVocWaves) void kVocoder(DevBatch d, int sBase, 
 			while (ldsPeek(&sync[slot]) < need) __builtin_amdgcn_s_sleep(1);
 			asm volatile("" ::: "memory");
 			const float4 *blockRecs = recs + (size_t)slot*BS*NCH*64 + k;
-			float4 q[NCH];
+			float4 q[2][NCH]; // two register sets alternate, so the next step's record loads never overwrite live values
 #pragma unroll
-			for (int j = 0; j < NCH; ++j) q[j] = blockRecs[j*64];
+			for (int j = 0; j < NCH; ++j) q[0][j] = blockRecs[j*64];
 #pragma unroll
 			for (int i = 0; i < BS; ++i) {
 				if (d.debugMode == 2) break; // experiment: consumer only acknowledges blocks
 				const int t = tb + blk*BS + i;
-				float f[NCH*4];
-#pragma unroll
-				for (int j = 0; j < NCH; ++j) { f[4*j] = q[j].x; f[4*j + 1] = q[j].y; f[4*j + 2] = q[j].z; f[4*j + 3] = q[j].w; }
 				if (i + 1 < BS) {
 #pragma unroll
-					for (int j = 0; j < NCH; ++j) q[j] = blockRecs[((i + 1)*NCH + j)*64];
+					for (int j = 0; j < NCH; ++j) q[(i + 1) & 1][j] = blockRecs[((i + 1)*NCH + j)*64];
 				}
+				float f[NCH*4];
+#pragma unroll
+				for (int j = 0; j < NCH; ++j) { f[4*j] = q[i & 1][j].x; f[4*j + 1] = q[i & 1][j].y; f[4*j + 2] = q[i & 1][j].z; f[4*j + 3] = q[i & 1][j].w; }
 				const int b = t - kLag;
 				const bool valid = active && b >= 0 && b < M;
 				int mc = __float_as_int(f[8]);
@@ -1246,15 +1246,25 @@ __global__ __launch_bounds__(64*kVocWaves) void kVocoder(DevBatch d, int sBase, 
 				phi = cadd(phi, cmul(pL, make_float2(f[6], f[7])));
 				phi = cadd(phi, cmul(o1, make_float2(f[0], f[1])));
 				const float2 om = makeOutput(phi, pm, sm); // :788
+				if (CH == 2) { // one locked channel: evaluate the lock once, for whichever channel is not the maximum
+					const float2 pother = mc ? make_float2(f[9], f[10]) : make_float2(f[12], f[13]);
+					const float sother = mc ? f[11] : f[14];
+					float2 olock = makeOutput(cmul(om, cmulc(pother, pm)), pother, sother); // channel lock, :791-800
+					float2 oc0 = mc ? olock : om, oc1 = mc ? om : olock;
+					if (!valid) { oc0 = make_float2(0.f, 0.f); oc1 = oc0; }
+					h[i][0] = oc0;
+					h[i][CH - 1] = oc1;
+					float2 *dst = valid ? OUT + b : dump;
+					dst[0] = oc0;
+					dst[valid ? (size_t)d.Mp : (size_t)64] = oc1;
+				} else {
 #pragma unroll
-				for (int c = 0; c < CH; ++c) {
-					const float2 pc = make_float2(f[9 + 3*c], f[10 + 3*c]);
-					float2 oc = makeOutput(cmul(om, cmulc(pc, pm)), pc, f[11 + 3*c]); // channel lock, :791-800
-					if (c == mc) oc = om;
-					if (!valid) oc = make_float2(0.f, 0.f);
-					h[i][c] = oc;
-					float2 *dst = valid ? OUT + ((size_t)c*d.Mp + b) : dump + c*64;
-					*dst = oc;
+					for (int c = 0; c < CH; ++c) {
+						float2 oc = valid ? om : make_float2(0.f, 0.f);
+						h[i][c] = oc;
+						float2 *dst = valid ? OUT + ((size_t)c*d.Mp + b) : dump + c*64;
+						*dst = oc;
+					}
 				}
 			}
 			asm volatile("" ::: "memory");
