@@ -1140,7 +1140,7 @@ __global__ __launch_bounds__(64*kVocWaves) void kVocoder(DevBatch d, int sBase, 
 		// ---------------- producers ----------------
 		if ((wave & 3) == 0) return; // would share the consumer's SIMD
 		const int pIndex = wave - 1 - (wave >> 2); // 0..NP-1 over the remaining waves
-		const int r = k & 7, st = k >> 3; // 8 adjacent lanes = 8 rows of one step: their LDS record writes are contiguous
+		const int st = k & 7, r = k >> 3; // 8 adjacent lanes = 8 consecutive bins of one row: 64-byte contiguous global loads
 		for (int u = pIndex; u < totalBlocks*8; u += NP) {
 			const int n = u >> 3, it = u & 7;
 			const int slot = n%NB;
@@ -1154,7 +1154,8 @@ __global__ __launch_bounds__(64*kVocWaves) void kVocoder(DevBatch d, int sBase, 
 			for (int j = 0; j < NCH*4; ++j) f[j] = 0.0f;
 			if (row < nh && b >= 0 && b < M && d.debugMode != 1) computeRecord<CH, PLAIN, false, false>(d, hopsLds[row], hopsLds[row > 0 ? row - 1 : 0], s, sg, row, b, f);
 #pragma unroll
-			for (int j = 0; j < NCH; ++j) recs[((slot*BS + st)*NCH + j)*64 + row] = make_float4(f[4*j], f[4*j + 1], f[4*j + 2], f[4*j + 3]);
+			// lane rotation by 2*st spreads the 8 lanes of a row (same row, 8 steps = 8 LDS rows a multiple of 256 B apart) over 8 bank groups
+			for (int j = 0; j < NCH; ++j) recs[((slot*BS + st)*NCH + j)*64 + ((row + 2*st) & 63)] = make_float4(f[4*j], f[4*j + 1], f[4*j + 2], f[4*j + 3]);
 			asm volatile("" ::: "memory");
 			if (k == 0) atomicAdd(const_cast<int *>(&sync[slot]), 1); // LDS ops of a wave are in order: data first, then the count
 		}
@@ -1203,17 +1204,17 @@ __global__ __launch_bounds__(64*kVocWaves) void kVocoder(DevBatch d, int sBase, 
 			const int need = 8*(n/NB + 1);
 			while (ldsPeek(&sync[slot]) < need) __builtin_amdgcn_s_sleep(1);
 			asm volatile("" ::: "memory");
-			const float4 *blockRecs = recs + (size_t)slot*BS*NCH*64 + k;
+			const float4 *blockRecs = recs + (size_t)slot*BS*NCH*64;
 			float4 q[2][NCH]; // two register sets alternate, so the next step's record loads never overwrite live values
 #pragma unroll
-			for (int j = 0; j < NCH; ++j) q[0][j] = blockRecs[j*64];
+			for (int j = 0; j < NCH; ++j) q[0][j] = blockRecs[j*64 + k];
 #pragma unroll
 			for (int i = 0; i < BS; ++i) {
 				if (d.debugMode == 2) break; // experiment: consumer only acknowledges blocks
 				const int t = tb + blk*BS + i;
 				if (i + 1 < BS) {
 #pragma unroll
-					for (int j = 0; j < NCH; ++j) q[(i + 1) & 1][j] = blockRecs[((i + 1)*NCH + j)*64];
+					for (int j = 0; j < NCH; ++j) q[(i + 1) & 1][j] = blockRecs[((i + 1)*NCH + j)*64 + ((k + 2*(i + 1)) & 63)];
 				}
 				float f[NCH*4];
 #pragma unroll

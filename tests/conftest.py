@@ -47,14 +47,19 @@ def synth_input(stream, channels, n, sr):
 
 @pytest.fixture(scope="session")
 def ref():
-    """The checker: oracle/_ref = unmodified reference header + L1 restatement (prebuilt .so travels to the GPU box)."""
+    """The checker: oracle/_ref = unmodified reference header + L1 restatement (prebuilt .so travels to the GPU box).
+    Where neither the prebuilt library nor the reference tree exists, fall back to the plain C++ port
+    (oracle/stretch_port.cpp, pinned against oracle/_ref and the WASM golden vectors by test_oracle_golden.py); cases
+    that need members the port does not restate skip themselves."""
     import ref_oracle
     if not ref_oracle.available():
         if os.path.exists("/root/reference/signalsmith-stretch.h"):
             subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "ref"], check=True, capture_output=True)
-        if not ref_oracle.available():
-            pytest.skip("oracle/_ref/libsmst_ref.so not built (needs /root/reference at build time)")
-    return ref_oracle
+    if ref_oracle.available():
+        return ref_oracle
+    import types
+    import port_oracle
+    return types.SimpleNamespace(RefStretch=port_oracle.PortStretch, available=lambda: True, is_port=True)
 
 
 @pytest.fixture(scope="session")
