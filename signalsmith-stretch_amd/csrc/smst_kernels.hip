@@ -1107,7 +1107,7 @@ __device__ __forceinline__ float2 fromLaneBelow(float2 v) { // lane k receives l
 }
 
 template <int CH, bool PLAIN, int L>
-__global__ __launch_bounds__(64*kVocWaves) void kVocoder(DevBatch d, int sBase, int hopBase) {
+__global__ __launch_bounds__(64*kVocWaves) __attribute__((amdgpu_waves_per_eu(5, 5))) void kVocoder(DevBatch d, int sBase, int hopBase) {
 	constexpr int NF = 9 + 3*CH, NCH = (NF + 3)/4, BS = kVocBlockSteps, NB = kVocBlocks, NP = kVocWaves - kVocWaves/4;
 	constexpr int lag = L + 1;
 	static_assert(BS == 8 && L >= 1 && L <= 7, "history registers are indexed by step & 7");
@@ -1116,6 +1116,8 @@ __global__ __launch_bounds__(64*kVocWaves) void kVocoder(DevBatch d, int sBase, 
 	float2 *stage = reinterpret_cast<float2 *>(recs + NB*BS*NCH*64);    // [CH][128]: carried Band.output, 128-bin window
 	volatile int *sync = reinterpret_cast<volatile int *>(stage + CH*128); // [0..NB) units produced, [NB] blocks consumed
 	HopDesc *hopsLds = reinterpret_cast<HopDesc *>(const_cast<int *>(sync) + 16); // the tile's 64 hop descriptors
+	float2 *outRing = reinterpret_cast<float2 *>(hopsLds + 64);                    // [2 blocks][BS][CH][64]: results on their way to HBM
+	// sync words: [0..NB) units produced per slot, [NB] blocks consumed, [NB+1] result blocks ready, [NB+2] result blocks written
 
 	const int s = blockIdx.x, sg = sBase + s;
 	const int nh = d.nHops[s];
@@ -1132,12 +1134,43 @@ __global__ __launch_bounds__(64*kVocWaves) void kVocoder(DevBatch d, int sBase, 
 		const int c = i >> 7, bb = i & 127;
 		stage[i] = (bb < M) ? stOut[(size_t)c*M + bb] : make_float2(0.f, 0.f);
 	}
-	if (threadIdx.x <= NB) sync[threadIdx.x] = 0;
+	if (threadIdx.x <= NB + 2) sync[threadIdx.x] = 0;
 	if (threadIdx.x < 64) hopsLds[threadIdx.x] = d.hops[(size_t)sg*d.hopStride + hopBase + threadIdx.x];
 	__syncthreads();
 
 	if (wave > 0) {
 		// ---------------- producers ----------------
+		if (wave == 4) {
+			// ---------------- writer ----------------
+			// Drains the consumer's results to HBM 8 steps at a time.  Per lane and step the consumer would issue one
+			// 8-byte store per channel into 64 different cache lines (128 partial-line transactions per step, competing
+			// with the producers' loads); here 4 lanes cover one row's 8 bins with 16-byte stores, 16 rows per instruction.
+			// Bins outside [0, M) of an active row land in the rows' padding (row pitch M + 32).
+			const int g = k >> 2, part = k & 3;
+			for (int n = 0; n < totalBlocks; ++n) {
+				while (ldsPeek(&sync[NB + 1]) <= n) __builtin_amdgcn_s_sleep(2);
+				asm volatile("" ::: "memory");
+				const float2 *blockOut = outRing + (size_t)(n & 1)*BS*CH*64;
+#pragma unroll
+				for (int pass = 0; pass < 4; ++pass) {
+					const int row = 16*pass + g;
+					const int b0 = BS*n - lag*row;
+					const bool ok = row < nh && b0 + BS - 1 >= 0 && b0 < M;
+#pragma unroll
+					for (int c = 0; c < CH; ++c) {
+						const float2 v0 = blockOut[((2*part)*CH + c)*64 + row], v1 = blockOut[((2*part + 1)*CH + c)*64 + row];
+						if (ok) {
+							float2 *dst = d.OUT + rowOf(d, s, row, c) + b0 + 2*part;
+							dst[0] = v0;
+							dst[1] = v1;
+						}
+					}
+				}
+				asm volatile("" ::: "memory");
+				if (k == 0) sync[NB + 2] = n + 1;
+			}
+			return;
+		}
 		if ((wave & 3) == 0) return; // would share the consumer's SIMD
 		const int pIndex = wave - 1 - (wave >> 2); // 0..NP-1 over the remaining waves
 		const int st = k & 7, r = k >> 3; // 8 adjacent lanes = 8 consecutive bins of one row: 64-byte contiguous global loads
@@ -1166,8 +1199,6 @@ __global__ __launch_bounds__(64*kVocWaves) void kVocoder(DevBatch d, int sBase, 
 	__builtin_amdgcn_s_setprio(3);
 	const bool active = k < nh;
 	const int kLag = lag*k;
-	float2 *OUT = d.OUT + rowOf(d, s, active ? k : 0, 0);
-	float2 *dump = d.dump + (size_t)s*CH*64 + k;
 	float2 pf[CH];
 	float2 h[8][CH];   // this lane's outputs of the last 8 steps
 	float2 sv1[CH], svL[CH]; // lane 0: carried outputs at bins b+1 and b+L of the NEXT step, read one step ahead
@@ -1205,6 +1236,9 @@ __global__ __launch_bounds__(64*kVocWaves) void kVocoder(DevBatch d, int sBase, 
 			while (ldsPeek(&sync[slot]) < need) __builtin_amdgcn_s_sleep(1);
 			asm volatile("" ::: "memory");
 			const float4 *blockRecs = recs + (size_t)slot*BS*NCH*64;
+			while (n - ldsPeek(&sync[NB + 2]) >= 2) __builtin_amdgcn_s_sleep(1); // the writer still owns this result slot
+			asm volatile("" ::: "memory");
+			float2 *blockOut = outRing + (size_t)(n & 1)*BS*CH*64 + k;
 			float4 q[2][NCH]; // two register sets alternate, so the next step's record loads never overwrite live values
 #pragma unroll
 			for (int j = 0; j < NCH; ++j) q[0][j] = blockRecs[j*64 + k];
@@ -1255,21 +1289,19 @@ __global__ __launch_bounds__(64*kVocWaves) void kVocoder(DevBatch d, int sBase, 
 					if (!valid) { oc0 = make_float2(0.f, 0.f); oc1 = oc0; }
 					h[i][0] = oc0;
 					h[i][CH - 1] = oc1;
-					float2 *dst = valid ? OUT + b : dump;
-					dst[0] = oc0;
-					dst[valid ? (size_t)d.Mp : (size_t)64] = oc1;
+					blockOut[(i*CH)*64] = oc0;
+					blockOut[(i*CH + CH - 1)*64] = oc1;
 				} else {
 #pragma unroll
 					for (int c = 0; c < CH; ++c) {
 						float2 oc = valid ? om : make_float2(0.f, 0.f);
 						h[i][c] = oc;
-						float2 *dst = valid ? OUT + ((size_t)c*d.Mp + b) : dump + c*64;
-						*dst = oc;
+						blockOut[(i*CH + c)*64] = oc;
 					}
 				}
 			}
 			asm volatile("" ::: "memory");
-			if (k == 0) sync[NB] = n + 1; // this block's slot may be refilled
+			if (k == 0) { sync[NB] = n + 1; sync[NB + 1] = n + 1; } // record slot may be refilled; results may be written out
 		}
 	}
 }
@@ -1521,7 +1553,7 @@ void launchPredictFused(const DevBatch &d, int sBase, int nStreams, int hopBase,
 template <int CH, int L>
 static void launchVocoderTL(const DevBatch &d, int sBase, int nStreams, int hopBase, bool plain, hipStream_t st) {
 	constexpr int NCH = (9 + 3*CH + 3)/4;
-	const size_t lds = (size_t)kVocBlocks*kVocBlockSteps*NCH*64*sizeof(float4) + (size_t)CH*128*sizeof(float2) + 64 + 64*sizeof(HopDesc);
+	const size_t lds = (size_t)kVocBlocks*kVocBlockSteps*NCH*64*sizeof(float4) + (size_t)CH*128*sizeof(float2) + 64 + 64*sizeof(HopDesc) + (size_t)2*kVocBlockSteps*CH*64*sizeof(float2);
 	if (plain) hipLaunchKernelGGL((kVocoder<CH, true, L>), dim3(nStreams), dim3(64*kVocWaves), lds, st, d, sBase, hopBase);
 	else hipLaunchKernelGGL((kVocoder<CH, false, L>), dim3(nStreams), dim3(64*kVocWaves), lds, st, d, sBase, hopBase);
 }
