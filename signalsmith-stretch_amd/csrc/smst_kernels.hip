@@ -738,7 +738,15 @@ __device__ __forceinline__ float2 bandAt(const float2 *row, int idx, int M) { //
 	return (ci == idx) ? v : make_float2(0.f, 0.f);
 }
 __device__ __forceinline__ float2 lerpBand(const float2 *row, LerpIndex li, int M) { // getFractional, :553-557
-	float2 low = bandAt(row, li.lo, M), high = bandAt(row, li.lo + 1, M);
+	// both taps with ONE 16-byte load (they are adjacent bins): half the memory transactions of two 8-byte loads.
+	// The pair is read at a clamped position and the taps outside [0, M) are zeroed afterwards (branch-free).
+	const int ci = min(max(li.lo, 0), M - 2);
+	const float4 v = *reinterpret_cast<const float4 *>(row + ci); // 8-byte aligned; gfx9 global loads need dword alignment only
+	const int delta = li.lo - ci; // 0 in range; -1: low tap is bin -1; +1: low tap is bin M-1; otherwise both taps are outside
+	float2 low = make_float2(v.x, v.y), high = make_float2(v.z, v.w);
+	if (delta == -1) { high = low; low = make_float2(0.f, 0.f); }
+	else if (delta == 1) { low = high; high = make_float2(0.f, 0.f); }
+	else if (delta != 0) { low = make_float2(0.f, 0.f); high = low; }
 	return make_float2(low.x + (high.x - low.x)*li.fr, low.y + (high.y - low.y)*li.fr);
 }
 __device__ __forceinline__ float2 rotAt(const DevBatch &d, int idx, bool rotate) { // hop rotation of bin idx, 1 outside / when off
