@@ -1116,7 +1116,7 @@ __device__ __forceinline__ float2 fromLaneBelow(float2 v) { // lane k receives l
 
 template <int CH, bool PLAIN, int L>
 __global__ __launch_bounds__(64*kVocWaves) __attribute__((amdgpu_waves_per_eu(5, 5))) void kVocoder(DevBatch d, int sBase, int hopBase) {
-	constexpr int NF = 9 + 3*CH, NCH = (NF + 3)/4, BS = kVocBlockSteps, NB = kVocBlocks, NP = kVocWaves - kVocWaves/4;
+	constexpr int NF = 9 + 3*CH, NCH = (NF + 3)/4, BS = kVocBlockSteps, NB = kVocBlocks, NP = kVocWaves - 2;
 	constexpr int lag = L + 1;
 	static_assert(BS == 8 && L >= 1 && L <= 7, "history registers are indexed by step & 7");
 	extern __shared__ __attribute__((aligned(16))) unsigned char smemRaw[];
@@ -1179,8 +1179,7 @@ __global__ __launch_bounds__(64*kVocWaves) __attribute__((amdgpu_waves_per_eu(5,
 			}
 			return;
 		}
-		if ((wave & 3) == 0) return; // would share the consumer's SIMD
-		const int pIndex = wave - 1 - (wave >> 2); // 0..NP-1 over the remaining waves
+		const int pIndex = wave - 1 - (wave > 4); // 0..NP-1 over the producer waves (every wave but the consumer and the writer)
 		const int st = k & 7, r = k >> 3; // 8 adjacent lanes = 8 consecutive bins of one row: 64-byte contiguous global loads
 		for (int u = pIndex; u < totalBlocks*8; u += NP) {
 			const int n = u >> 3, it = u & 7;
