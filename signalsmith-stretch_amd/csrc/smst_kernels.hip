@@ -496,22 +496,31 @@ __global__ __launch_bounds__(256) void kFeedEnergy(DevBatch d, int sBase, int ho
 // independent of the recurrence and are issued together, the recurrence then runs on registers.  step(e, x) -> e.
 template <bool DOWN, typename F>
 __device__ __forceinline__ float serialPass(const float *src, float *dst, int M, float e, F step) {
+	// double-buffered: chunk c+1 is fetched before chunk c is reduced, so no memory round trip sits between chunks
+	// (src may equal dst: the in-place passes only ever overwrite elements that were already fetched)
 	constexpr int U = 16;
-	for (int c0 = 0; c0 < M; c0 += U) {
-		float x[U];
+	float cur[U], nxt[U];
+	auto fetch = [&](float (&x)[U], int c0) {
 #pragma unroll
 		for (int i = 0; i < U; ++i) {
 			const int b = DOWN ? (M - 1 - c0 - i) : (c0 + i);
-			x[i] = (b >= 0 && b < M) ? src[(size_t)b*64] : 0.0f;
+			const int bc = min(max(b, 0), M - 1);
+			x[i] = src[(size_t)bc*64];
 		}
+	};
+	fetch(cur, 0);
+	for (int c0 = 0; c0 < M; c0 += U) {
+		fetch(nxt, c0 + U); // clamped: past the end it re-reads the last element, which is never used
 #pragma unroll
 		for (int i = 0; i < U; ++i) {
 			const int b = DOWN ? (M - 1 - c0 - i) : (c0 + i);
 			if (b >= 0 && b < M) {
-				e = step(e, x[i]);
+				e = step(e, cur[i]);
 				dst[(size_t)b*64] = e;
 			}
 		}
+#pragma unroll
+		for (int i = 0; i < U; ++i) cur[i] = nxt[i];
 	}
 	return e;
 }
