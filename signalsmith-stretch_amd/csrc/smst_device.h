@@ -17,6 +17,7 @@ struct DevBatch {
 	int mapTableLen;
 	int histCur, carryCur;        // which half of the double buffers is current
 	int debugMode;                // SMST_DEBUG_MODE experiments (0 = product behaviour)
+	int noStage;                  // SMST_NO_STAGE: producers of the fused kernel gather from HBM even where staging applies
 	FftPlan plan;
 	// constant tables
 	const float2 *twH;     // e^{-2 pi i j / H}
@@ -67,7 +68,7 @@ void launchFeed(const DevBatch &d, int sBase, int nStreams, int hopBase, hipStre
 void launchPredict(const DevBatch &d, int sBase, int nStreams, int hopBase, int tileHops, bool plain, hipStream_t st);
 void launchChain(const DevBatch &d, int sBase, int nStreams, int hopBase, hipStream_t st);
 void launchPredictFused(const DevBatch &d, int sBase, int nStreams, int hopBase, int tileHops, bool plain, hipStream_t st);
-void launchVocoder(const DevBatch &d, int sBase, int nStreams, int hopBase, bool plain, hipStream_t st);
+void launchVocoder(const DevBatch &d, int sBase, int nStreams, int hopBase, bool plain, bool bounded, hipStream_t st); // bounded: no random time factors in the tile
 bool fusedSupported(const DevBatch &d);
 void launchSynth(const DevBatch &d, int sBase, int nStreams, int hopBase, int tileHops, hipStream_t st);
 void launchEmit(const DevBatch &d, const IoArgs &io, int sBase, int nStreams, int tileIndex, int maxSpan, hipStream_t st);

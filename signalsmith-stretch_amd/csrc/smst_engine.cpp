@@ -126,6 +126,7 @@ Batch::Batch(int streams, int channels, int block, int interval, bool splitCompu
 	d.mapTableLen = 0;
 	d.debugMode = 0;
 	if (const char *env = std::getenv("SMST_DEBUG_MODE")) d.debugMode = atoi(env);
+	d.noStage = std::getenv("SMST_NO_STAGE") != nullptr;
 
 	// constant tables
 	std::vector<float2> tw(M), half(M), rot(M);
@@ -535,7 +536,7 @@ void Batch::process(const float *in, long long inSS, long long inCS, const int *
 	// tileInfo layout: [sub][tile][2][subS] (nHops, lastNewHop)
 	std::vector<int> tileInfo((size_t)nSub*nTiles*2*subS, 0);
 	std::vector<int> maxSpan((size_t)nSub*nTiles, 0);
-	std::vector<unsigned char> tileHas((size_t)nSub*nTiles*4, 0); // any hops / any mapped / any formants / any new spectrum
+	std::vector<unsigned char> tileHas((size_t)nSub*nTiles*8, 0); // any hops / any mapped / any formants / any new spectrum / any random time factor
 	for (int s = 0; s < S; ++s) {
 		const auto &list = hopLists[s];
 		const int sub = s/subS, sl = s%subS;
@@ -557,11 +558,12 @@ void Batch::process(const float *in, long long inSS, long long inCS, const int *
 			int lastNewLocal = -1;
 			for (int h = h0; h < h1; ++h) {
 				if (list[h].flags & HOP_NEW_SPECTRUM) lastNewLocal = h - h0;
-				unsigned char *th = tileHas.data() + (size_t)(sub*nTiles + t)*4;
+				unsigned char *th = tileHas.data() + (size_t)(sub*nTiles + t)*8;
 				th[0] = 1;
 				if (list[h].flags & HOP_MAPPED) th[1] = 1;
 				if (list[h].flags & HOP_FORMANTS) th[2] = 1;
 				if (list[h].flags & HOP_NEW_SPECTRUM) th[3] = 1;
+				if (list[h].flags & HOP_RANDOM_TF) th[4] = 1;
 			}
 			info[subS + sl] = lastNewLocal;
 			maxSpan[(size_t)sub*nTiles + t] = std::max(maxSpan[(size_t)sub*nTiles + t], ed.nHi - ed.nLo);
@@ -610,7 +612,7 @@ void Batch::process(const float *in, long long inSS, long long inCS, const int *
 		const int sBase = sub*subS;
 		const int ns = std::min(subS, S - sBase);
 		for (int t = 0; t < nTiles; ++t, ++q) {
-			const unsigned char *th = tileHas.data() + (size_t)(sub*nTiles + t)*4;
+			const unsigned char *th = tileHas.data() + (size_t)(sub*nTiles + t)*8;
 			const int hopBase = t*T;
 			const int tileHops = std::min(T, std::max(1, maxHops - hopBase));
 			const int slot = q & 1;
@@ -646,7 +648,7 @@ void Batch::process(const float *in, long long inSS, long long inCS, const int *
 			}
 			if (th[0]) {
 				timed(timings.chainMs, [&] {
-					if (fused) launchVocoder(dd, sBase, ns, hopBase, plain, sC);
+					if (fused) launchVocoder(dd, sBase, ns, hopBase, plain, !th[4], sC);
 					else launchChain(dd, sBase, ns, hopBase, sC);
 					if (profiling) ++timings.chainLaunches;
 				});

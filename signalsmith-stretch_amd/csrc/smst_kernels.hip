@@ -1115,17 +1115,181 @@ __global__ __launch_bounds__(64) void kChain(DevBatch d, int sBase, int hopBase)
 // and only lane 0 (whose "previous hop" is the carried Band.output) reads them from the staged LDS copy, one step
 // ahead.  No LDS round trip and no memory load sits on the recurrence.
 // ------------------------------------------------------------------------------------------------------
-constexpr int kVocBlockSteps = 8, kVocBlocks = 3, kVocWaves = 16;
-
 __device__ __forceinline__ int ldsPeek(volatile int *p) { return *p; }
+
+// Staged producers (PLAIN tiles without random time factors, L <= 5).  Measured on the first version of this kernel
+// (profiles/r1_pmc_vocoder_ta.json): the texture-address unit was busy 76% of the kernel -- every record issued 14
+// narrow gathers (8 rows x 64 B each).  Here one producer wave owns 8 fixed rows; per 8-step block it fetches the
+// rows' windows once with 16-byte loads (IN: bins b0-2L..b0+7+L of every channel, PV and ROT: b0+1..b0+7+L, plus the
+// row above its first row for Prediction.energy of the previous hop), parks them in a private LDS buffer, and computes
+// its 64 records from LDS.  The loads of block n+1 are in flight while block n is computed.
+template <int CH, int L>
+struct StageGeom {
+	static constexpr int PIN = (8 + 3*L + 1)/2;  // 16-byte pieces (2 bins) of one IN window
+	static constexpr int PPV = (7 + L + 1)/2;    // pieces of one PV / ROT window
+	static constexpr int PV_OFF = CH*2*PIN, ROT_OFF = PV_OFF + CH*2*PPV, ROWLEN = ROT_OFF + 2*PPV; // float2 units
+	static constexpr int ROW_PIECES = CH*PIN + CH*PPV + PPV;
+	static constexpr int X_FIRST = L/2, X_PIECES = 3 + L - L/2 + 1; // extra row (hop above): window indices [L, 6+2L]
+	static constexpr int TOTAL = 8*ROW_PIECES + CH*X_PIECES;
+	static constexpr int LOADS = (TOTAL + 63)/64;
+	static constexpr int ROWS = 9; // local rows -1..7
+};
+
+template <int CH, int L, int NB, int NP>
+__device__ __forceinline__ void vocoderProduceStaged(const DevBatch &d, int s, int sg, int nh, int pIndex, int k, int totalBlocks,
+                                                     float4 *recs, volatile int *sync, const HopDesc *hopsLds, float2 *sbuf) {
+	using G = StageGeom<CH, L>;
+	constexpr int NF = 9 + 3*CH, NCH = (NF + 3)/4, BS = 8, lag = L + 1;
+	static_assert(NP%8 == 0, "one producer wave per group of 8 rows");
+	const int M = d.M;
+	const int it = pIndex & 7;
+	// ---- block-invariant description of this lane's pieces
+	const float2 *psrc[G::LOADS];
+	int pbin[G::LOADS], plds[G::LOADS];
+	bool pok[G::LOADS];
+#pragma unroll
+	for (int i = 0; i < G::LOADS; ++i) {
+		const int q = k + 64*i;
+		int rl, j;
+		if (q < 8*G::ROW_PIECES) { rl = q/G::ROW_PIECES; j = q%G::ROW_PIECES; }
+		else { const int x = q - 8*G::ROW_PIECES; rl = -1; j = (x/G::X_PIECES)*G::PIN + G::X_FIRST + x%G::X_PIECES; }
+		const int row = 8*it + rl;
+		const bool ok = q < G::TOTAL && row >= 0 && row < nh;
+		const HopDesc hd = hopsLds[ok ? row : 0];
+		const float2 *src;
+		int rel, off;
+		if (j < CH*G::PIN) { // IN
+			const int c = j/G::PIN, pp = j%G::PIN;
+			src = inputRow(d, hd, s, sg, 0) + (size_t)c*((hd.inSrc >= 0) ? d.Mp : d.M);
+			rel = -2*L + 2*pp;
+			off = c*2*G::PIN + 2*pp;
+		} else if (j < CH*G::PIN + CH*G::PPV) { // PV
+			const int jj = j - CH*G::PIN, c = jj/G::PPV, pp = jj%G::PPV;
+			src = prevRow(d, hd, s, row, sg, c);
+			rel = 1 + 2*pp;
+			off = G::PV_OFF + c*2*G::PPV + 2*pp;
+		} else { // ROT
+			const int pp = j - CH*G::PIN - CH*G::PPV;
+			src = d.rot;
+			rel = 1 + 2*pp;
+			off = G::ROT_OFF + 2*pp;
+		}
+		psrc[i] = ok ? src : d.rot;
+		pbin[i] = rel - lag*row;
+		plds[i] = (rl + 1)*G::ROWLEN + off;
+		pok[i] = ok;
+	}
+	float4 v[G::LOADS];
+	auto issue = [&](int n) {
+#pragma unroll
+		for (int i = 0; i < G::LOADS; ++i) {
+			const int sb = BS*n + pbin[i];
+			const int cb = min(max(sb, 0), M - 2);
+			v[i] = *reinterpret_cast<const float4 *>(psrc[i] + cb); // 8-byte aligned; dword alignment suffices on gfx9
+		}
+	};
+	auto park = [&](int n) {
+#pragma unroll
+		for (int i = 0; i < G::LOADS; ++i) {
+			const int sb = BS*n + pbin[i];
+			const int delta = sb - min(max(sb, 0), M - 2); // 0 in range; -1: first bin is -1; +1: first bin is M-1; else both outside
+			float2 lo = make_float2(v[i].x, v[i].y), hi = make_float2(v[i].z, v[i].w);
+			if (delta == -1) { hi = lo; lo = make_float2(0.f, 0.f); }
+			else if (delta == 1) { lo = hi; hi = make_float2(0.f, 0.f); }
+			else if (delta != 0) { lo = make_float2(0.f, 0.f); hi = lo; }
+			if (pok[i]) *reinterpret_cast<float4 *>(sbuf + plds[i]) = make_float4(lo.x, lo.y, hi.x, hi.y);
+		}
+	};
+	const int st = k & 7, r = k >> 3, row = 8*it + r;
+	const HopDesc hd = hopsLds[row < nh ? row : 0];
+	const bool rotate = hd.flags & HOP_NEW_SPECTRUM;
+	const float tf = hd.timeFactor;
+	const float2 *mine = sbuf + (r + 1)*G::ROWLEN, *above = sbuf + r*G::ROWLEN;
+	constexpr int NPB = NP/8;
+	int n = pIndex >> 3;
+	if (n < totalBlocks) issue(n);
+	for (; n < totalBlocks; n += NPB) {
+		park(n);
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+		if (n + NPB < totalBlocks) issue(n + NPB);
+		const int slot = n%NB;
+		while (n - ldsPeek(&sync[NB]) >= NB) __builtin_amdgcn_s_sleep(2); // slot still being read
+		asm volatile("" ::: "memory");
+		const int b0 = BS*n - lag*row, b = b0 + st;
+		float f[NCH*4];
+#pragma unroll
+		for (int j = 0; j < NCH*4; ++j) f[j] = 0.0f;
+		if (row < nh && b >= 0 && b < M && d.debugMode != 1) {
+			// same arithmetic as computeRecord<CH, true, false, false>, operands from the staged windows
+			auto IN = [&](int c, int x) { return mine[c*2*G::PIN + (x - b0 + 2*L)]; };
+			auto lerpIN = [&](int c, LerpIndex li) {
+				const float2 low = IN(c, li.lo), high = IN(c, li.lo + 1);
+				return make_float2(low.x + (high.x - low.x)*li.fr, low.y + (high.y - low.y)*li.fr);
+			};
+			float2 p[CH];
+			float e[CH];
+#pragma unroll
+			for (int c = 0; c < CH; ++c) { p[c] = IN(c, b); e[c] = cnorm(p[c]); }
+			int mc = 0;
+			float eMax = e[0];
+#pragma unroll
+			for (int c = 1; c < CH; ++c) if (e[c] > eMax) { mc = c; eMax = e[c]; }
+			float2 Pm = p[0];
+#pragma unroll
+			for (int c = 1; c < CH; ++c) if (c == mc) Pm = p[c];
+			const float fb = float(b);
+			float2 A = cmulc(Pm, lerpIN(mc, lerpIndex(fb - tf)));
+			float2 B = cmulc(Pm, lerpIN(mc, lerpIndex(fb - L*tf)));
+			auto twist = [&](int bx, float stepMul) {
+				const int bc = min(bx, M - 1);
+				const float2 rotB = rotate ? mine[G::ROT_OFF + (bx - b0 - 1)] : make_float2(1.f, 0.f);
+				const float2 Q = cmul(mine[G::PV_OFF + mc*2*G::PPV + (bx - b0 - 1)], rotB);
+				const float2 Px = IN(mc, bx);
+				const float2 TW = cmul(rotB, cmulc(Px, Q));
+				const float eNow = cnorm(Px);
+				// Prediction.energy of the previous hop: hop row-1's input (its window starts lag bins later), or the carried state
+				const float ePrev = (row > 0) ? cnorm(above[mc*2*G::PIN + (bx - b0 - lag + 2*L)]) : d.stEnergy[stateRow(d, sg, mc) + bc];
+				const float den = fmaxf(ePrev, eNow) + 1e-15f;
+				const float2 down = cmulc(Px, lerpIN(mc, lerpIndex(float(bc) - stepMul*tf)));
+				const float2 rr = cmulc(TW, down);
+				const float inv = 1.0f/den;
+				return make_float2(rr.x*inv, rr.y*inv);
+			};
+			float2 Cc = twist(b + 1, 1.0f), Dc = twist(b + L, float(L));
+			const float2 zero = make_float2(0.f, 0.f);
+			if (!(b > 0)) A = zero;
+			if (!(b >= L)) B = zero;
+			if (!(b < M - 1)) Cc = zero;
+			if (!(b < M - L)) Dc = zero;
+			f[0] = A.x; f[1] = A.y; f[2] = B.x; f[3] = B.y; f[4] = Cc.x; f[5] = Cc.y; f[6] = Dc.x; f[7] = Dc.y;
+			f[8] = __int_as_float(mc);
+#pragma unroll
+			for (int c = 0; c < CH; ++c) { f[9 + 3*c] = p[c].x; f[10 + 3*c] = p[c].y; f[11 + 3*c] = sqrtf(e[c]); }
+		}
+#pragma unroll
+		for (int j = 0; j < NCH; ++j) recs[((slot*BS + st)*NCH + j)*64 + ((row + 2*st) & 63)] = make_float4(f[4*j], f[4*j + 1], f[4*j + 2], f[4*j + 3]);
+		asm volatile("" ::: "memory");
+		if (k == 0) atomicAdd(const_cast<int *>(&sync[slot]), 1);
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier(); // every lane has read its operands before the next block's windows are parked
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+	}
+}
+
+constexpr int kVocBlockSteps = 8, kVocBlocks = 3, kVocBlocksStaged = 2, kVocWaves = 16, kVocStagedProducers = 8;
+
 __device__ __forceinline__ float2 fromLaneBelow(float2 v) { // lane k receives lane k-1's value (lane 0: zero)
 	return make_float2(__int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v.x), 0x138, 0xf, 0xf, true)),
 	                   __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v.y), 0x138, 0xf, 0xf, true)));
 }
 
-template <int CH, bool PLAIN, int L>
+template <int CH, bool PLAIN, int L, bool STAGED>
 __global__ __launch_bounds__(64*kVocWaves) __attribute__((amdgpu_waves_per_eu(5, 5))) void kVocoder(DevBatch d, int sBase, int hopBase) {
-	constexpr int NF = 9 + 3*CH, NCH = (NF + 3)/4, BS = kVocBlockSteps, NB = kVocBlocks, NP = kVocWaves - 2;
+	static_assert(!STAGED || (PLAIN && L <= 5), "staged producers: identity map, bounded windows");
+	constexpr int NF = 9 + 3*CH, NCH = (NF + 3)/4, BS = kVocBlockSteps, NB = STAGED ? kVocBlocksStaged : kVocBlocks;
+	constexpr int NP = STAGED ? kVocStagedProducers : kVocWaves - 2;
 	constexpr int lag = L + 1;
 	static_assert(BS == 8 && L >= 1 && L <= 7, "history registers are indexed by step & 7");
 	extern __shared__ __attribute__((aligned(16))) unsigned char smemRaw[];
@@ -1189,6 +1353,13 @@ __global__ __launch_bounds__(64*kVocWaves) __attribute__((amdgpu_waves_per_eu(5,
 			return;
 		}
 		const int pIndex = wave - 1 - (wave > 4); // 0..NP-1 over the producer waves (every wave but the consumer and the writer)
+		if (pIndex >= NP) return;
+		if constexpr (STAGED) {
+			using G = StageGeom<CH, L>;
+			float2 *sbuf = outRing + (size_t)2*BS*CH*64 + (size_t)pIndex*G::ROWS*G::ROWLEN;
+			vocoderProduceStaged<CH, L, NB, NP>(d, s, sg, nh, pIndex, k, totalBlocks, recs, sync, hopsLds, sbuf);
+			return;
+		}
 		const int st = k & 7, r = k >> 3; // 8 adjacent lanes = 8 consecutive bins of one row: 64-byte contiguous global loads
 		for (int u = pIndex; u < totalBlocks*8; u += NP) {
 			const int n = u >> 3, it = u & 7;
@@ -1567,27 +1738,36 @@ void launchPredictFused(const DevBatch &d, int sBase, int nStreams, int hopBase,
 }
 // ... and the fused producer/consumer recurrence
 template <int CH, int L>
-static void launchVocoderTL(const DevBatch &d, int sBase, int nStreams, int hopBase, bool plain, hipStream_t st) {
+static void launchVocoderTL(const DevBatch &d, int sBase, int nStreams, int hopBase, bool plain, bool bounded, hipStream_t st) {
 	constexpr int NCH = (9 + 3*CH + 3)/4;
-	const size_t lds = (size_t)kVocBlocks*kVocBlockSteps*NCH*64*sizeof(float4) + (size_t)CH*128*sizeof(float2) + 64 + 64*sizeof(HopDesc) + (size_t)2*kVocBlockSteps*CH*64*sizeof(float2);
-	if (plain) hipLaunchKernelGGL((kVocoder<CH, true, L>), dim3(nStreams), dim3(64*kVocWaves), lds, st, d, sBase, hopBase);
-	else hipLaunchKernelGGL((kVocoder<CH, false, L>), dim3(nStreams), dim3(64*kVocWaves), lds, st, d, sBase, hopBase);
+	const size_t fixed = (size_t)CH*128*sizeof(float2) + 64 + 64*sizeof(HopDesc) + (size_t)2*kVocBlockSteps*CH*64*sizeof(float2);
+	const size_t lds = (size_t)kVocBlocks*kVocBlockSteps*NCH*64*sizeof(float4) + fixed;
+	if constexpr (L <= 5) {
+		if (plain && bounded && !d.noStage) {
+			using G = StageGeom<CH, L>;
+			const size_t ldsStaged = (size_t)kVocBlocksStaged*kVocBlockSteps*NCH*64*sizeof(float4) + fixed + (size_t)kVocStagedProducers*G::ROWS*G::ROWLEN*sizeof(float2);
+			hipLaunchKernelGGL((kVocoder<CH, true, L, true>), dim3(nStreams), dim3(64*kVocWaves), ldsStaged, st, d, sBase, hopBase);
+			return;
+		}
+	}
+	if (plain) hipLaunchKernelGGL((kVocoder<CH, true, L, false>), dim3(nStreams), dim3(64*kVocWaves), lds, st, d, sBase, hopBase);
+	else hipLaunchKernelGGL((kVocoder<CH, false, L, false>), dim3(nStreams), dim3(64*kVocWaves), lds, st, d, sBase, hopBase);
 }
 template <int CH>
-static void launchVocoderT(const DevBatch &d, int sBase, int nStreams, int hopBase, bool plain, hipStream_t st) {
+static void launchVocoderT(const DevBatch &d, int sBase, int nStreams, int hopBase, bool plain, bool bounded, hipStream_t st) {
 	switch (d.L) { // longVerticalStep = round(fftSamples/interval): 4 (presetDefault @48k), 5 (@44.1k), 3 (presetCheaper)
-	case 3: launchVocoderTL<CH, 3>(d, sBase, nStreams, hopBase, plain, st); break;
-	case 4: launchVocoderTL<CH, 4>(d, sBase, nStreams, hopBase, plain, st); break;
-	case 5: launchVocoderTL<CH, 5>(d, sBase, nStreams, hopBase, plain, st); break;
-	case 2: launchVocoderTL<CH, 2>(d, sBase, nStreams, hopBase, plain, st); break;
-	case 6: launchVocoderTL<CH, 6>(d, sBase, nStreams, hopBase, plain, st); break;
-	default: launchVocoderTL<CH, 7>(d, sBase, nStreams, hopBase, plain, st); break; // only reached with L == 7 (see fusedSupported)
+	case 3: launchVocoderTL<CH, 3>(d, sBase, nStreams, hopBase, plain, bounded, st); break;
+	case 4: launchVocoderTL<CH, 4>(d, sBase, nStreams, hopBase, plain, bounded, st); break;
+	case 5: launchVocoderTL<CH, 5>(d, sBase, nStreams, hopBase, plain, bounded, st); break;
+	case 2: launchVocoderTL<CH, 2>(d, sBase, nStreams, hopBase, plain, bounded, st); break;
+	case 6: launchVocoderTL<CH, 6>(d, sBase, nStreams, hopBase, plain, bounded, st); break;
+	default: launchVocoderTL<CH, 7>(d, sBase, nStreams, hopBase, plain, bounded, st); break; // only reached with L == 7 (see fusedSupported)
 	}
 }
 bool fusedSupported(const DevBatch &d) { return d.C <= 2 && d.L >= 2 && d.L <= 7 && d.lag == d.L + 1; }
-void launchVocoder(const DevBatch &d, int sBase, int nStreams, int hopBase, bool plain, hipStream_t st) {
-	if (d.C == 1) launchVocoderT<1>(d, sBase, nStreams, hopBase, plain, st);
-	else launchVocoderT<2>(d, sBase, nStreams, hopBase, plain, st);
+void launchVocoder(const DevBatch &d, int sBase, int nStreams, int hopBase, bool plain, bool bounded, hipStream_t st) {
+	if (d.C == 1) launchVocoderT<1>(d, sBase, nStreams, hopBase, plain, bounded, st);
+	else launchVocoderT<2>(d, sBase, nStreams, hopBase, plain, bounded, st);
 }
 void launchPredict(const DevBatch &d, int sBase, int nStreams, int hopBase, int tileHops, bool plain, hipStream_t st) {
 	switch (d.C) {
