@@ -1115,7 +1115,12 @@ __global__ __launch_bounds__(64) void kChain(DevBatch d, int sBase, int hopBase)
 // and only lane 0 (whose "previous hop" is the carried Band.output) reads them from the staged LDS copy, one step
 // ahead.  No LDS round trip and no memory load sits on the recurrence.
 // ------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ int ldsPeek(volatile int *p) { return *p; }
+// Hand-off words in LDS: relaxed workgroup-scope atomics.  (A `volatile` access makes the backend drain EVERY
+// outstanding memory operation -- s_waitcnt vmcnt(0) -- around it, which serialised the producers' prefetch loads
+// behind each poll.)  Ordering against the data they guard comes from the in-order LDS pipe plus compiler barriers.
+__device__ __forceinline__ int ldsPeek(volatile int *p) { return __hip_atomic_load(const_cast<int *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void ldsPost(volatile int *p, int v) { __hip_atomic_store(const_cast<int *>(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void ldsCount(volatile int *p) { (void)__hip_atomic_fetch_add(const_cast<int *>(p), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
 // Staged producers (PLAIN tiles without random time factors, L <= 5).  Measured on the first version of this kernel
 // (profiles/r1_pmc_vocoder_ta.json): the texture-address unit was busy 76% of the kernel -- every record issued 14
@@ -1146,7 +1151,9 @@ __device__ __forceinline__ void vocoderProduceStaged(const DevBatch &d, int s, i
 	// ---- block-invariant description of this lane's pieces
 	const float2 *psrc[G::LOADS];
 	int pbin[G::LOADS], plds[G::LOADS];
-	bool pok[G::LOADS];
+	bool pok[G::LOADS], pen[G::LOADS]; // piece wanted / piece is carried Prediction.energy (row above the tile's first hop)
+	const float *carriedEnergy = d.stEnergy + stateRow(d, sg, 0); // [C][M]
+	const float *penergy = carriedEnergy;
 #pragma unroll
 	for (int i = 0; i < G::LOADS; ++i) {
 		const int q = k + 64*i;
@@ -1154,13 +1161,15 @@ __device__ __forceinline__ void vocoderProduceStaged(const DevBatch &d, int s, i
 		if (q < 8*G::ROW_PIECES) { rl = q/G::ROW_PIECES; j = q%G::ROW_PIECES; }
 		else { const int x = q - 8*G::ROW_PIECES; rl = -1; j = (x/G::X_PIECES)*G::PIN + G::X_FIRST + x%G::X_PIECES; }
 		const int row = 8*it + rl;
-		const bool ok = q < G::TOTAL && row >= 0 && row < nh;
-		const HopDesc hd = hopsLds[ok ? row : 0];
+		const bool energy = q < G::TOTAL && row == -1; // the hop above row 0 is the carried state: stage its energy as (E, 0)
+		const bool ok = q < G::TOTAL && row >= -1 && row < nh;
+		const HopDesc hd = hopsLds[row >= 0 && ok ? row : 0];
 		const float2 *src;
 		int rel, off;
 		if (j < CH*G::PIN) { // IN
 			const int c = j/G::PIN, pp = j%G::PIN;
-			src = inputRow(d, hd, s, sg, 0) + (size_t)c*((hd.inSrc >= 0) ? d.Mp : d.M);
+			src = energy ? d.rot : inputRow(d, hd, s, sg, 0) + (size_t)c*((hd.inSrc >= 0) ? d.Mp : d.M); // energy: dummy address for the wide load
+			if (energy) penergy = carriedEnergy + (size_t)c*M;
 			rel = -2*L + 2*pp;
 			off = c*2*G::PIN + 2*pp;
 		} else if (j < CH*G::PIN + CH*G::PPV) { // PV
@@ -1178,14 +1187,20 @@ __device__ __forceinline__ void vocoderProduceStaged(const DevBatch &d, int s, i
 		pbin[i] = rel - lag*row;
 		plds[i] = (rl + 1)*G::ROWLEN + off;
 		pok[i] = ok;
+		pen[i] = energy;
 	}
+	static_assert(64*(G::LOADS - 1) <= 8*G::ROW_PIECES, "pieces of the row above sit in the last load slot");
 	float4 v[G::LOADS];
+	float2 ve = make_float2(0.f, 0.f);
 	auto issue = [&](int n) {
 #pragma unroll
 		for (int i = 0; i < G::LOADS; ++i) {
 			const int sb = BS*n + pbin[i];
 			const int cb = min(max(sb, 0), M - 2);
 			v[i] = *reinterpret_cast<const float4 *>(psrc[i] + cb); // 8-byte aligned; dword alignment suffices on gfx9
+			// pieces of the carried energy (row above hop 0; only the last slot can hold them) are 2 floats: kept in their own
+			// registers until park(), so that no select waits for the loads here
+			if (i == G::LOADS - 1 && pen[i]) ve = *reinterpret_cast<const float2 *>(penergy + cb);
 		}
 	};
 	auto park = [&](int n) {
@@ -1193,11 +1208,13 @@ __device__ __forceinline__ void vocoderProduceStaged(const DevBatch &d, int s, i
 		for (int i = 0; i < G::LOADS; ++i) {
 			const int sb = BS*n + pbin[i];
 			const int delta = sb - min(max(sb, 0), M - 2); // 0 in range; -1: first bin is -1; +1: first bin is M-1; else both outside
-			float2 lo = make_float2(v[i].x, v[i].y), hi = make_float2(v[i].z, v[i].w);
-			if (delta == -1) { hi = lo; lo = make_float2(0.f, 0.f); }
-			else if (delta == 1) { lo = hi; hi = make_float2(0.f, 0.f); }
-			else if (delta != 0) { lo = make_float2(0.f, 0.f); hi = lo; }
-			if (pok[i]) *reinterpret_cast<float4 *>(sbuf + plds[i]) = make_float4(lo.x, lo.y, hi.x, hi.y);
+			// selects, not branches: lo = v.xy / v.zw / 0 for delta 0 / +1 / other; hi = v.zw / v.xy / 0 for delta 0 / -1 / other
+			const bool d0 = delta == 0, dp = delta == 1, dm = delta == -1;
+			const bool en = (i == G::LOADS - 1) && pen[i];
+			const float wx = en ? ve.x : v[i].x, wy = en ? 0.f : v[i].y, wz = en ? ve.y : v[i].z, ww = en ? 0.f : v[i].w;
+			float lx = dp ? wz : 0.f, ly = dp ? ww : 0.f, hx = dm ? wx : 0.f, hy = dm ? wy : 0.f;
+			if (d0) { lx = wx; ly = wy; hx = wz; hy = ww; }
+			if (pok[i]) *reinterpret_cast<float4 *>(sbuf + plds[i]) = make_float4(lx, ly, hx, hy);
 		}
 	};
 	const int st = k & 7, r = k >> 3, row = 8*it + r;
@@ -1250,7 +1267,8 @@ __device__ __forceinline__ void vocoderProduceStaged(const DevBatch &d, int s, i
 				const float2 TW = cmul(rotB, cmulc(Px, Q));
 				const float eNow = cnorm(Px);
 				// Prediction.energy of the previous hop: hop row-1's input (its window starts lag bins later), or the carried state
-				const float ePrev = (row > 0) ? cnorm(above[mc*2*G::PIN + (bx - b0 - lag + 2*L)]) : d.stEnergy[stateRow(d, sg, mc) + bc];
+				const float2 up = above[mc*2*G::PIN + (bx - b0 - lag + 2*L)];
+				const float ePrev = (row > 0) ? cnorm(up) : up.x;
 				const float den = fmaxf(ePrev, eNow) + 1e-15f;
 				const float2 down = cmulc(Px, lerpIN(mc, lerpIndex(float(bc) - stepMul*tf)));
 				const float2 rr = cmulc(TW, down);
@@ -1271,7 +1289,7 @@ __device__ __forceinline__ void vocoderProduceStaged(const DevBatch &d, int s, i
 #pragma unroll
 		for (int j = 0; j < NCH; ++j) recs[((slot*BS + st)*NCH + j)*64 + ((row + 2*st) & 63)] = make_float4(f[4*j], f[4*j + 1], f[4*j + 2], f[4*j + 3]);
 		asm volatile("" ::: "memory");
-		if (k == 0) atomicAdd(const_cast<int *>(&sync[slot]), 1);
+		if (k == 0) ldsCount(&sync[slot]);
 		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 		__builtin_amdgcn_wave_barrier(); // every lane has read its operands before the next block's windows are parked
 		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -1286,7 +1304,7 @@ __device__ __forceinline__ float2 fromLaneBelow(float2 v) { // lane k receives l
 }
 
 template <int CH, bool PLAIN, int L, bool STAGED>
-__global__ __launch_bounds__(64*kVocWaves) __attribute__((amdgpu_waves_per_eu(5, 5))) void kVocoder(DevBatch d, int sBase, int hopBase) {
+__global__ __launch_bounds__(64*kVocWaves) __attribute__((amdgpu_waves_per_eu(4, 4))) void kVocoder(DevBatch d, int sBase, int hopBase) {
 	static_assert(!STAGED || (PLAIN && L <= 5), "staged producers: identity map, bounded windows");
 	constexpr int NF = 9 + 3*CH, NCH = (NF + 3)/4, BS = kVocBlockSteps, NB = STAGED ? kVocBlocksStaged : kVocBlocks;
 	constexpr int NP = STAGED ? kVocStagedProducers : kVocWaves - 2;
@@ -1348,11 +1366,14 @@ __global__ __launch_bounds__(64*kVocWaves) __attribute__((amdgpu_waves_per_eu(5,
 					}
 				}
 				asm volatile("" ::: "memory");
-				if (k == 0) sync[NB + 2] = n + 1;
+				if (k == 0) ldsPost(&sync[NB + 2], n + 1);
 			}
 			return;
 		}
-		const int pIndex = wave - 1 - (wave > 4); // 0..NP-1 over the producer waves (every wave but the consumer and the writer)
+		// 0..NP-1 over the producer waves.  Waves land on SIMD (wave & 3); the staged kernel runs 8 producers: two on each
+		// of SIMDs 1-3 and two (waves 8, 12) sharing SIMD 0 with the consumer and the writer.
+		int pIndex = wave - 1 - (wave > 4);
+		if (STAGED) pIndex = (wave & 3) ? ((wave < 8) ? pIndex : NP) : ((wave == 8) ? 6 : ((wave == 12) ? 7 : NP));
 		if (pIndex >= NP) return;
 		if constexpr (STAGED) {
 			using G = StageGeom<CH, L>;
@@ -1377,7 +1398,7 @@ __global__ __launch_bounds__(64*kVocWaves) __attribute__((amdgpu_waves_per_eu(5,
 			// lane rotation by 2*st spreads the 8 lanes of a row (same row, 8 steps = 8 LDS rows a multiple of 256 B apart) over 8 bank groups
 			for (int j = 0; j < NCH; ++j) recs[((slot*BS + st)*NCH + j)*64 + ((row + 2*st) & 63)] = make_float4(f[4*j], f[4*j + 1], f[4*j + 2], f[4*j + 3]);
 			asm volatile("" ::: "memory");
-			if (k == 0) atomicAdd(const_cast<int *>(&sync[slot]), 1); // LDS ops of a wave are in order: data first, then the count
+			if (k == 0) ldsCount(&sync[slot]); // LDS ops of a wave are in order: data first, then the count
 		}
 		return;
 	}
@@ -1488,7 +1509,7 @@ __global__ __launch_bounds__(64*kVocWaves) __attribute__((amdgpu_waves_per_eu(5,
 				}
 			}
 			asm volatile("" ::: "memory");
-			if (k == 0) { sync[NB] = n + 1; sync[NB + 1] = n + 1; } // record slot may be refilled; results may be written out
+			if (k == 0) { ldsPost(&sync[NB], n + 1); ldsPost(&sync[NB + 1], n + 1); } // record slot may be refilled; results may be written out
 		}
 	}
 }

@@ -73,6 +73,10 @@ static inline int __shfl(int v, int lane) { return emuShflI(v, lane); }
 int emuDppShr1(int old, int v);
 static inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int, int, bool) { (void)ctrl; return emuDppShr1(old, src); }
 static inline int atomicAdd(int *p, int v) { int o = *p; *p = o + v; return o; }
+#define __HIP_MEMORY_SCOPE_WORKGROUP 2
+#define __hip_atomic_load(p, order, scope) (*(volatile int *)(p))
+#define __hip_atomic_store(p, v, order, scope) (*(volatile int *)(p) = (v))
+#define __hip_atomic_fetch_add(p, v, order, scope) atomicAdd((p), (v))
 static inline hipError_t hipStreamDestroy(hipStream_t) { return 0; }
 static inline hipError_t hipMalloc(void **p, size_t n) { *p = std::calloc(n ? n : 1, 1); return *p ? 0 : 2; }
 static inline hipError_t hipFree(void *p) { std::free(p); return 0; }
