@@ -232,7 +232,7 @@ __device__ __forceinline__ void dftLast(float2 (&v)[R3]) {
 // lds: H + H/16 float2.  All threads of the block must call this (it synchronises).
 template <int SIGN, int R3, typename Load, typename Store>
 __device__ __forceinline__ void fftFast(float2 *lds, const float2 *__restrict__ twA, const float2 *__restrict__ twB, Load load, Store store) {
-	constexpr int H = 256*R3, MA = 16*R3;
+	constexpr int MA = 16*R3;
 	const int t = threadIdx.x;
 	float2 v[16];
 	// stage A: radix 16, stride 1
@@ -1298,9 +1298,10 @@ __device__ __forceinline__ void vocoderProduceStaged(const DevBatch &d, int s, i
 
 constexpr int kVocBlockSteps = 8, kVocBlocks = 3, kVocBlocksStaged = 2, kVocWaves = 16, kVocStagedProducers = 8;
 
-__device__ __forceinline__ float2 fromLaneBelow(float2 v) { // lane k receives lane k-1's value (lane 0: zero)
-	return make_float2(__int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v.x), 0x138, 0xf, 0xf, true)),
-	                   __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v.y), 0x138, 0xf, 0xf, true)));
+__device__ __forceinline__ float2 fromLaneBelow(float2 v, float2 lane0) { // lane k receives lane k-1's v; lane 0 keeps its `lane0`
+	// DPP wave_shr:1 without bound_ctrl: a lane with no source lane keeps the old value of the destination register
+	return make_float2(__int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(lane0.x), __float_as_int(v.x), 0x138, 0xf, 0xf, false)),
+	                   __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(lane0.y), __float_as_int(v.y), 0x138, 0xf, 0xf, false)));
 }
 
 template <int CH, bool PLAIN, int L, bool STAGED>
@@ -1405,7 +1406,6 @@ __global__ __launch_bounds__(64*kVocWaves) __attribute__((amdgpu_waves_per_eu(4,
 
 	// ---------------- consumer (wave 0) ----------------
 	__builtin_amdgcn_s_setprio(3);
-	const bool active = k < nh;
 	const int kLag = lag*k;
 	float2 pf[CH];
 	float2 h[8][CH];   // this lane's outputs of the last 8 steps
@@ -1462,20 +1462,17 @@ __global__ __launch_bounds__(64*kVocWaves) __attribute__((amdgpu_waves_per_eu(4,
 #pragma unroll
 				for (int j = 0; j < NCH; ++j) { f[4*j] = q[i & 1][j].x; f[4*j + 1] = q[i & 1][j].y; f[4*j + 2] = q[i & 1][j].z; f[4*j + 3] = q[i & 1][j].w; }
 				const int b = t - kLag;
-				const bool valid = active && b >= 0 && b < M;
 				int mc = __float_as_int(f[8]);
 				mc = (mc < 0) ? 0 : ((mc > CH - 1) ? CH - 1 : mc);
 				// taps: own history, and lane k-1's history (lane 0: the staged carried state)
 				float2 o1 = h[(i + 7) & 7][0], oL = h[(i + 8 - L) & 7][0];
-				float2 p1 = fromLaneBelow(oL), pL = fromLaneBelow(o1);
-				if (k == 0) { p1 = sv1[0]; pL = svL[0]; }
+				float2 p1 = fromLaneBelow(oL, sv1[0]), pL = fromLaneBelow(o1, svL[0]); // lane 0: the staged carried state
 				float2 pm = make_float2(f[9], f[10]);
 				float sm = f[11];
 #pragma unroll
 				for (int c = 1; c < CH; ++c) {
 					const float2 o1c = h[(i + 7) & 7][c], oLc = h[(i + 8 - L) & 7][c];
-					float2 p1c = fromLaneBelow(oLc), pLc = fromLaneBelow(o1c);
-					if (k == 0) { p1c = sv1[c]; pLc = svL[c]; }
+					const float2 p1c = fromLaneBelow(oLc, sv1[c]), pLc = fromLaneBelow(o1c, svL[c]);
 					if (c == mc) { o1 = o1c; oL = oLc; p1 = p1c; pL = pLc; pm = make_float2(f[9 + 3*c], f[10 + 3*c]); sm = f[11 + 3*c]; }
 				}
 				// next step's staged values (only lane 0 uses them): bins (b+1)+1 and (b+1)+L
@@ -1493,8 +1490,8 @@ __global__ __launch_bounds__(64*kVocWaves) __attribute__((amdgpu_waves_per_eu(4,
 					const float2 pother = mc ? make_float2(f[9], f[10]) : make_float2(f[12], f[13]);
 					const float sother = mc ? f[11] : f[14];
 					float2 olock = makeOutput(cmul(om, cmulc(pother, pm)), pother, sother); // channel lock, :791-800
-					float2 oc0 = mc ? olock : om, oc1 = mc ? om : olock;
-					if (!valid) { oc0 = make_float2(0.f, 0.f); oc1 = oc0; }
+					// cells outside the tile (inactive hop, bin outside [0, M)) have all-zero records, which give exactly zero here
+					const float2 oc0 = mc ? olock : om, oc1 = mc ? om : olock;
 					h[i][0] = oc0;
 					h[i][CH - 1] = oc1;
 					blockOut[(i*CH)*64] = oc0;
@@ -1502,9 +1499,8 @@ __global__ __launch_bounds__(64*kVocWaves) __attribute__((amdgpu_waves_per_eu(4,
 				} else {
 #pragma unroll
 					for (int c = 0; c < CH; ++c) {
-						float2 oc = valid ? om : make_float2(0.f, 0.f);
-						h[i][c] = oc;
-						blockOut[(i*CH + c)*64] = oc;
+						h[i][c] = om;
+						blockOut[(i*CH + c)*64] = om;
 					}
 				}
 			}
@@ -1555,38 +1551,68 @@ __global__ __launch_bounds__(256) void kSynth(DevBatch d, int sBase, int hopBase
 // Sums are formed oldest-frame-first, as the reference's ring accumulates them.
 // ------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void kEmit(DevBatch d, IoArgs io, int sBase, int tileIndex) {
+	// four consecutive output samples per thread: the frame / window-product taps of a group are 16-byte loads
+	// (dword alignment suffices on gfx9), and the two integer divisions are paid once per group
 	const int s = blockIdx.z, sg = sBase + s, c = blockIdx.y;
 	const EmitDesc ed = d.emit[(size_t)sg*d.emitStride + tileIndex];
 	const int span = ed.nHi - ed.nLo;
-	const int i = blockIdx.x*blockDim.x + threadIdx.x;
+	const int i0 = 4*(blockIdx.x*blockDim.x + threadIdx.x);
 	const int CL = d.carryLen;
-	if (i >= span + CL) return;
+	const int total = span + CL;
+	if (i0 >= total) return;
 	const int B = d.B, I = d.I;
-	const int n = ed.nLo + i;
 	const size_t carryRow = ((size_t)sg*d.C + c)*(size_t)CL;
 	const float *carrySumOld = d.carrySum[d.carryCur] + carryRow;
 	const float *carryWpOld = d.carryWp[d.carryCur] + (size_t)sg*CL;
-	float sum = (i < CL) ? carrySumOld[i] : 0.0f;
-	float wp = (i < CL) ? carryWpOld[i] : 1e-30f;
-	if (ed.hopCount > 0) {
-		// frames q with pos_q <= n < pos_q + B, pos_q = firstHopPos + q*I + delta
-		const int rel = n - ed.firstHopPos - d.delta;
-		int qHi = (rel >= 0) ? rel/I : -1;
-		int qLo = (rel - B + 1 > 0) ? (rel - B + 1 + I - 1)/I : 0;
-		if (qHi > ed.hopCount - 1) qHi = ed.hopCount - 1;
-		for (int q = qLo; q <= qHi; ++q) {
-			const int idx = rel - q*I;
-			sum += d.frames[((size_t)((size_t)s*d.T + q)*d.C + c)*(size_t)B + idx];
-			wp += d.wprod[idx];
+	float sum[4], wp[4];
+	if (i0 + 3 < CL) {
+		const float4 a = *reinterpret_cast<const float4 *>(carrySumOld + i0), b = *reinterpret_cast<const float4 *>(carryWpOld + i0);
+		sum[0] = a.x; sum[1] = a.y; sum[2] = a.z; sum[3] = a.w;
+		wp[0] = b.x; wp[1] = b.y; wp[2] = b.z; wp[3] = b.w;
+	} else {
+#pragma unroll
+		for (int j = 0; j < 4; ++j) {
+			const int i = i0 + j;
+			sum[j] = (i < CL) ? carrySumOld[i] : 0.0f;
+			wp[j] = (i < CL) ? carryWpOld[i] : 1e-30f;
 		}
 	}
-	if (i < span) {
-		float *out = io.out + (size_t)sg*io.outStreamStride + (size_t)c*io.outChannelStride;
-		out[n] = sum/wp;
+	if (ed.hopCount > 0) {
+		// frames q with pos_q <= n < pos_q + B, pos_q = firstHopPos + q*I + delta; summed in ascending q per sample
+		const int rel0 = ed.nLo + i0 - ed.firstHopPos - d.delta;
+		int qHi = (rel0 + 3 >= 0) ? (rel0 + 3)/I : -1;
+		const int qLo = (rel0 - B + 1 > 0) ? (rel0 - B + 1 + I - 1)/I : 0;
+		if (qHi > ed.hopCount - 1) qHi = ed.hopCount - 1;
+		for (int q = qLo; q <= qHi; ++q) {
+			const int idx0 = rel0 - q*I;
+			const float *frame = d.frames + ((size_t)((size_t)s*d.T + q)*d.C + c)*(size_t)B;
+			if (idx0 >= 0 && idx0 + 3 < B) {
+				const float4 f = *reinterpret_cast<const float4 *>(frame + idx0), w = *reinterpret_cast<const float4 *>(d.wprod + idx0);
+				sum[0] += f.x; sum[1] += f.y; sum[2] += f.z; sum[3] += f.w;
+				wp[0] += w.x; wp[1] += w.y; wp[2] += w.z; wp[3] += w.w;
+			} else {
+#pragma unroll
+				for (int j = 0; j < 4; ++j) {
+					const int idx = idx0 + j;
+					if (idx >= 0 && idx < B) { sum[j] += frame[idx]; wp[j] += d.wprod[idx]; }
+				}
+			}
+		}
+	}
+	float *out = io.out + (size_t)sg*io.outStreamStride + (size_t)c*io.outChannelStride + ed.nLo;
+	if (i0 + 3 < span) {
+		*reinterpret_cast<float4 *>(out + i0) = make_float4(sum[0]/wp[0], sum[1]/wp[1], sum[2]/wp[2], sum[3]/wp[3]);
 	} else {
-		const int j = i - span;
-		d.carrySum[d.carryCur ^ 1][carryRow + j] = sum;
-		if (c == 0) d.carryWp[d.carryCur ^ 1][(size_t)sg*CL + j] = wp;
+#pragma unroll
+		for (int j = 0; j < 4; ++j) {
+			const int i = i0 + j;
+			if (i < span) {
+				out[i] = sum[j]/wp[j];
+			} else if (i < total) {
+				d.carrySum[d.carryCur ^ 1][carryRow + (i - span)] = sum[j];
+				if (c == 0) d.carryWp[d.carryCur ^ 1][(size_t)sg*CL + (i - span)] = wp[j];
+			}
+		}
 	}
 }
 
@@ -1828,7 +1854,7 @@ void launchSynth(const DevBatch &d, int sBase, int nStreams, int hopBase, int ti
 	hipLaunchKernelGGL(kSynth, grid, dim3(256), lds, st, d, sBase, hopBase);
 }
 void launchEmit(const DevBatch &d, const IoArgs &io, int sBase, int nStreams, int tileIndex, int maxSpan, hipStream_t st) {
-	hipLaunchKernelGGL(kEmit, dim3(divUp(maxSpan + d.carryLen, 256), d.C, nStreams), dim3(256), 0, st, d, io, sBase, tileIndex);
+	hipLaunchKernelGGL(kEmit, dim3(divUp(divUp(maxSpan + d.carryLen, 4), 256), d.C, nStreams), dim3(256), 0, st, d, io, sBase, tileIndex);
 }
 void launchCarryFeed(const DevBatch &d, int sBase, int nStreams, int hopBase, hipStream_t st) {
 	hipLaunchKernelGGL(kCarryFeed, dim3(divUp(d.M, 256), d.C, nStreams), dim3(256), 0, st, d, sBase, hopBase);
