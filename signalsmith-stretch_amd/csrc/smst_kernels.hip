@@ -24,7 +24,10 @@ __device__ __forceinline__ float2 cmul(float2 a, float2 b) { // a*b          (re
 __device__ __forceinline__ float2 cmulc(float2 a, float2 b) { // a*conj(b)   (reference _impl::mul<true>)
 	return make_float2(b.x*a.x + b.y*a.y, b.x*a.y - b.y*a.x);
 }
-__device__ __forceinline__ float cnorm(float2 a) { return a.x*a.x + a.y*a.y; } // :27-31
+// |a|^2 with three separate roundings, never a fused multiply-add: the compiler otherwise contracts this differently from
+// one call site to the next (mul+fma here, packed mul + add there), and the SAME energy is computed at several sites
+// (carried Prediction.energy in kCarryFeed vs the producers' on-the-fly value) that must agree bit for bit
+__device__ __forceinline__ float cnorm(float2 a) { return __fadd_rn(__fmul_rn(a.x, a.x), __fmul_rn(a.y, a.y)); } // :27-31
 __device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
 __device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
 __device__ __forceinline__ float2 cscale(float2 a, float s) { return make_float2(a.x*s, a.y*s); }
@@ -238,7 +241,7 @@ __device__ __forceinline__ void fftFast(float2 *lds, const float2 *__restrict__ 
 	// stage A: radix 16, stride 1
 	if (t < MA) {
 #pragma unroll
-		for (int k = 0; k < 16; ++k) v[k] = load(t + MA*k);
+		for (int k = 0; k < 16; ++k) v[k] = load(t + MA*k, k);
 		dft16<SIGN>(v);
 #pragma unroll
 		for (int pos = 0; pos < 16; ++pos) {
@@ -291,7 +294,7 @@ __device__ __forceinline__ void fftFast(float2 *lds, const float2 *__restrict__ 
 }
 
 template <int R3>
-__global__ __launch_bounds__(16*R3 > 256 ? 16*R3 : 256) void kAnalyseFast(DevBatch d, IoArgs io, int sBase, int hopBase) {
+__global__ __launch_bounds__(16*R3 > 256 ? 16*R3 : 256) __attribute__((amdgpu_waves_per_eu(4, 4))) void kAnalyseFast(DevBatch d, IoArgs io, int sBase, int hopBase) {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smemRaw[];
 	float2 *lds = reinterpret_cast<float2 *>(smemRaw);
 	const int k = blockIdx.x;
@@ -307,19 +310,34 @@ __global__ __launch_bounds__(16*R3 > 256 ? 16*R3 : 256) void kAnalyseFast(DevBat
 	const float *hist = d.hist[d.histCur] + ((size_t)(sBase + s)*d.C + c)*(size_t)d.histLen + d.histLen;
 	const float2 *__restrict__ winA = d.winA, *__restrict__ winB = d.winB;
 	float2 *dst = (which ? d.Xprev : d.Xcur) + rowOf(d, s, k, c);
+	auto store = [&](int j, float2 u) {
+		const int kk = 2*j;
+		if (kk < H) dst[kk] = u;
+		else dst[N - 1 - kk] = cconj(u);
+	};
+	constexpr int MA = 16*R3;
+	if (base >= 0 && H - halfB == MA && B - halfB == 15*MA) {
+		// the usual case (both presets): the whole window lies in this call's input, and the two halves of the packed
+		// input change validity exactly at element-slot boundaries: slot 0 has no imaginary part, slot 15 no real part
+		const float *x0 = x + base + halfB, *x1 = x + base - H + halfB;
+		fftFast<-1, R3>(lds, d.twA, d.twB,
+			[&](int m, int slot) {
+				// same roundings as the general path below: round(xi*b + round(xr*a)), with the absent half an exact zero
+				float2 r = make_float2(0.f, 0.f);
+				if (slot < 15) { const float xr = x0[m]; const float2 a = winA[m]; r = make_float2(xr*a.x, xr*a.y); }
+				if (slot > 0) { const float xi = x1[m]; const float2 b = winB[m]; r = make_float2(fmaf(xi, b.x, r.x), fmaf(xi, b.y, r.y)); }
+				return r;
+			}, store);
+		return;
+	}
 	fftFast<-1, R3>(lds, d.twA, d.twB,
-		[&](int m) {
+		[&](int m, int) {
 			float xr = 0, xi = 0;
 			if (m < B - halfB) { int src = base + m + halfB; xr = (src >= 0) ? x[src] : hist[src]; }
 			if (m >= H - halfB) { int src = base + m - H + halfB; xi = (src >= 0) ? x[src] : hist[src]; }
 			const float2 a = winA[m], b = winB[m];
-			return make_float2(xr*a.x + xi*b.x, xr*a.y + xi*b.y);
-		},
-		[&](int j, float2 u) {
-			const int kk = 2*j;
-			if (kk < H) dst[kk] = u;
-			else dst[N - 1 - kk] = cconj(u);
-		});
+			return make_float2(fmaf(xi, b.x, xr*a.x), fmaf(xi, b.y, xr*a.y));
+		}, store);
 }
 
 template <int R3>
@@ -335,7 +353,7 @@ __global__ __launch_bounds__(16*R3 > 256 ? 16*R3 : 256) void kSynthFast(DevBatch
 	const float *__restrict__ win = d.window;
 	const float2 *__restrict__ halfTw = d.halfTw;
 	fftFast<+1, R3>(lds, d.twA, d.twB,
-		[&](int j) {
+		[&](int j, int) {
 			const int kk = 2*j;
 			return (kk < H) ? X[kk] : cconj(X[N - 1 - kk]);
 		},

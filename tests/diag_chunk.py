@@ -7,7 +7,7 @@ from conftest import synth_input
 import torch
 pkg = importlib.import_module("signalsmith-stretch_amd")
 C, sr = 2, 48000
-for S in (1, 4, 64, 256):
+for S in (4, 256):
     x = torch.from_numpy(np.stack([synth_input(s % 12, C, 28800, sr) for s in range(S)])).cuda()
     b = pkg.StretchBatch(S, C, preset="default", sample_rate=sr)
     whole = b.process(x, 36000); b.synchronize()

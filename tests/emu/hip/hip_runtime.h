@@ -42,6 +42,8 @@ void emuSyncThreads();
 #define __syncthreads() emuSyncThreads()
 #define __builtin_amdgcn_wave_barrier() emuSyncThreads()
 #define __builtin_amdgcn_fence(order, scope) ((void)0)
+static inline float __fmul_rn(float a, float b) { return a*b; }
+static inline float __fadd_rn(float a, float b) { return a + b; }
 static inline float __builtin_amdgcn_rsqf(float x) { return 1.0f/std::sqrt(x); }
 static inline float __builtin_amdgcn_rcpf(float x) { return 1.0f/x; }
 
