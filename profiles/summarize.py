@@ -43,13 +43,16 @@ def main():
         for k, counters in acc.items():
             for c, vals in counters.items():
                 out.setdefault(k, {})[c] = sum(vals)/len(vals)
-    traffic = {}
+    traffic, best = {}, {}
     for k, v in out.items():
         if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
             v["hbm_bytes_per_launch"] = (2*v["FETCH_SIZE"] + v["WRITE_SIZE"])*1024
             if "avg_us" in v:
                 v["hbm_GBps"] = v["hbm_bytes_per_launch"]/(v["avg_us"]*1e-6)/1e9
-            traffic[k.split("<")[0]] = v["hbm_bytes_per_launch"]
+            base = k.split("<")[0] # template variants share a key: keep the one launched most often
+            if base not in traffic or v.get("calls", 0) > best.get(base, 0):
+                traffic[base] = v["hbm_bytes_per_launch"]
+                best[base] = v.get("calls", 0)
     json.dump(out, open(os.path.join(here, tag + "_pmc_summary.json"), "w"), indent=1, sort_keys=True)
     json.dump(traffic, open(os.path.join(here, "traffic_latest.json"), "w"), indent=1, sort_keys=True)
     for k in sorted(out, key=lambda k: -out[k].get("avg_us", 0)*out[k].get("calls", 0)):
