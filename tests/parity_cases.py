@@ -119,6 +119,33 @@ def case_api_surface(lib, ref, cfg=SMALL):
     assert not ok_a and not ok_b and np.abs(a).max() == 0
 
 
+def case_realtime_quanta(lib, ref, cfg=SMALL, quantum=128, quanta=70):
+    """The two calling patterns of the reference's AudioWorklet wrapper (web/web-wrapper.js:255-315), SURVEY.md 8(f)
+    rank 3: (i) live input, process(quantum, quantum) per render quantum; (ii) buffered playback, where every quantum
+    re-seeks with the last inputLatency+outputLatency input samples and asks for output without new input:
+    seek(bufferLength, rate); process(0, quantum)."""
+    C, sr = 2, 48000
+    x = synth_input(0, C, quantum*(quanta + 40), sr) + 0.3*synth_input(2, C, quantum*(quanta + 40), sr)
+
+    def live(o, xx):
+        return np.concatenate([o.process(xx[:, q*quantum:(q + 1)*quantum], quantum) for q in range(quanta)], axis=1)
+    check_scenario(lib, ref, cfg, x, live, "live quanta")
+
+    for rate in (1.0, 0.8):
+        def playback(o, xx, rate=rate):
+            buf_len = o.inputLatency() + o.outputLatency()
+            outs = []
+            for q in range(quanta):
+                end = int(round((q + 1)*quantum*rate)) + o.inputLatency()
+                buf = np.zeros((C, buf_len), np.float32)
+                lo = max(0, end - buf_len)
+                buf[:, buf_len - (end - lo):] = xx[:, lo:end]
+                o.seek(buf, rate)
+                outs.append(o.process(xx[:, :0], quantum))
+            return np.concatenate(outs, axis=1)
+        check_scenario(lib, ref, cfg, x, playback, "playback quanta rate %.1f" % rate)
+
+
 def case_split_mode(lib, ref):
     C, sr = 2, 48000
     x = synth_input(0, C, 12000, sr)

@@ -46,3 +46,7 @@ def test_sub_batches(emu, ref, monkeypatch):
 
 def test_cmd_main_flow_config1(emu, ref):
     pc.case_cmd_main_flow(emu, ref)
+
+
+def test_realtime_quanta(emu, ref):
+    pc.case_realtime_quanta(emu, ref)

@@ -208,3 +208,9 @@ def test_staged_producers_equal_gathered(hip, monkeypatch):
         outs.append(torch.cat([y1, y2], dim=2).clone())
         b.close()
     assert torch.equal(outs[0], outs[1]), float((outs[0] - outs[1]).abs().max())
+
+
+@pytest.mark.gpu
+def test_realtime_quanta(hip, ref):
+    pc.case_realtime_quanta(hip, ref)
+    pc.case_realtime_quanta(hip, ref, cfg=D48, quanta=40)
