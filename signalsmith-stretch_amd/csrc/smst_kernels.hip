@@ -1120,18 +1120,18 @@ __global__ __launch_bounds__(64) void kChain(DevBatch d, int sBase, int hopBase)
 
 // ------------------------------------------------------------------------------------------------------
 // K3 fused (mono / stereo): the recurrence and its coefficients in ONE kernel, so the records never touch HBM.
-// One workgroup of 16 waves per stream: wave 0 is the CONSUMER (the skewed wavefront, one lane per hop); 12 of
-// the other waves are PRODUCERS that compute the records (same arithmetic as kPredictB, 8 rows x 8 steps per
-// wave-pass, branch-free loads) into an LDS ring of 3 blocks x 8 steps; waves 4, 8, 12 would share the
-// consumer's SIMD and retire at once.  Hand-off is by LDS counters (units produced per slot, blocks consumed); LDS
-// operations of a wave execute in order, so a counter update issued after the data writes is seen after them.
+// One workgroup of 16 waves per stream: wave 0 is the CONSUMER (the skewed wavefront, one lane per hop), wave 4 the
+// WRITER (results -> HBM), and 8 (staged) or 14 (gathering) of the others are PRODUCERS that compute the records (same
+// arithmetic as kPredictB, 8 rows x 8 steps per wave-pass) into an LDS ring of 2 or 3 blocks x 8 steps; unused waves
+// retire at once.  Hand-off is by LDS counters (units produced per slot, blocks consumed, result blocks ready /
+// written); LDS operations of a wave execute in order, so a counter update issued after the data writes is seen after them.
 //
 // The consumer keeps the serial path in registers: each lane holds its last 8 outputs per channel (h[t & 7]), so
 //   own taps      out[b-1], out[b-L]                    = h[(i+7)&7], h[(i+8-L)&7]
 //   previous hop  out_{k-1}[b+1], out_{k-1}[b+L]        = the SAME two registers of lane k-1 (it runs lag = L+1 bins
 //                                                         ahead), fetched with one DPP wave_shr:1 each
-// and only lane 0 (whose "previous hop" is the carried Band.output) reads them from the staged LDS copy, one step
-// ahead.  No LDS round trip and no memory load sits on the recurrence.
+// and only lane 0 (whose "previous hop" is the carried Band.output) takes them from the staged LDS copy, read one step
+// ahead and passed as the DPP's `old` operand.  No LDS round trip and no memory load sits on the recurrence.
 // ------------------------------------------------------------------------------------------------------
 // Hand-off words in LDS: relaxed workgroup-scope atomics.  (A `volatile` access makes the backend drain EVERY
 // outstanding memory operation -- s_waitcnt vmcnt(0) -- around it, which serialised the producers' prefetch loads
