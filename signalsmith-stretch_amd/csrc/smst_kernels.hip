@@ -42,6 +42,24 @@ __device__ __forceinline__ size_t stateRow(const DevBatch &d, int sGlobal, int c
 	return ((size_t)sGlobal*d.C + c)*(size_t)d.M;
 }
 
+// XCD-aware block mapping for grids (x, y, streams) whose blocks of ONE stream share data (the analysis windows of
+// consecutive hops overlap by most of their length): workgroup number n is observed to run on XCD n % 8 (placement is an
+// optimisation only), so streams are dealt to XCDs in groups of 8 -- all blocks of a stream land on one XCD and its L2
+// serves the overlap, instead of 8 L2s each fetching the same samples.
+struct BlockCoord { int x, y, s; };
+__device__ __forceinline__ BlockCoord xcdAwareBlock() {
+	const int gx = gridDim.x, gy = gridDim.y, S = gridDim.z, n = gx*gy;
+	const int lin = blockIdx.x + gx*(blockIdx.y + gy*blockIdx.z);
+	const int g = lin/(8*n), rest = lin - g*8*n;
+	BlockCoord r;
+	int idx;
+	if (8*g + 8 <= S) { r.s = 8*g + (rest & 7); idx = rest >> 3; }
+	else { r.s = 8*g + rest/n; idx = rest%n; } // last, partial group: plain order
+	r.x = idx%gx;
+	r.y = idx/gx;
+	return r;
+}
+
 // counter-based uniform in [0,1) (replaces std::default_random_engine of :616,:640 -- implementation-defined
 // in the reference, so no parity is possible there)
 __device__ __forceinline__ float hashUniform(unsigned seed, unsigned a, unsigned b) {
@@ -297,10 +315,11 @@ template <int R3>
 __global__ __launch_bounds__(16*R3 > 256 ? 16*R3 : 256) __attribute__((amdgpu_waves_per_eu(4, 4))) void kAnalyseFast(DevBatch d, IoArgs io, int sBase, int hopBase) {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smemRaw[];
 	float2 *lds = reinterpret_cast<float2 *>(smemRaw);
-	const int k = blockIdx.x;
-	const int c = blockIdx.y >> 1;
-	const int which = blockIdx.y & 1;
-	const int s = blockIdx.z;
+	const BlockCoord bc = xcdAwareBlock();
+	const int k = bc.x;
+	const int c = bc.y >> 1;
+	const int which = bc.y & 1;
+	const int s = bc.s;
 	const HopDesc hd = d.hops[(size_t)(sBase + s)*d.hopStride + hopBase + k];
 	if (!(hd.flags & HOP_ACTIVE) || !(hd.flags & HOP_NEW_SPECTRUM)) return;
 	if (which == 1 && !(hd.flags & HOP_REANALYSE_PREV)) return;
@@ -403,10 +422,11 @@ __global__ __launch_bounds__(256) void kAnalyse(DevBatch d, IoArgs io, int sBase
 	float2 *bufA = reinterpret_cast<float2 *>(smemRaw);
 	float2 *bufB = bufA + d.M;
 
-	const int k = blockIdx.x;
-	const int c = blockIdx.y >> 1;
-	const int which = blockIdx.y & 1; // 0: current window, 1: window one interval earlier
-	const int s = blockIdx.z;
+	const BlockCoord bc = xcdAwareBlock();
+	const int k = bc.x;
+	const int c = bc.y >> 1;
+	const int which = bc.y & 1; // 0: current window, 1: window one interval earlier
+	const int s = bc.s;
 	const HopDesc hd = d.hops[(size_t)(sBase + s)*d.hopStride + hopBase + k];
 	if (!(hd.flags & HOP_ACTIVE) || !(hd.flags & HOP_NEW_SPECTRUM)) return;
 	if (which == 1 && !(hd.flags & HOP_REANALYSE_PREV)) return;
