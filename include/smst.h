@@ -16,7 +16,10 @@
  *      Buffers are planar with explicit strides: sample (s, c, i) at base[s*streamStride + c*channelStride + i].
  *      `memory` selects SMST_MEM_HOST (staged through the library's own device buffers) or SMST_MEM_DEVICE
  *      (pointers are device pointers on the batch's GPU; the call is asynchronous on the batch's stream
- *      except for one 4-byte-per-stream readback inside process -- use smst_batch_synchronize()).
+ *      except for one 64-byte-per-stream readback inside process -- use smst_batch_synchronize()).
+ *      Device inputs must be COMPLETE when the call is made (the library does not order itself after the
+ *      caller's streams), and inputs / outputs must stay valid until smst_batch_synchronize() returns; the
+ *      host-side part of a call (silence gate, block scheduler) overlaps the kernels of the previous call.
  *
  * Every function returns 0 on success and a negative code on failure (the reference has no error channel:
  * signalsmith-stretch.h is UB when unconfigured; only exact() reports, :471-480).  smst_last_error()

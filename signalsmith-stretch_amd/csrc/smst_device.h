@@ -72,7 +72,7 @@ void launchVocoder(const DevBatch &d, int sBase, int nStreams, int hopBase, bool
 bool fusedSupported(const DevBatch &d);
 void launchSynth(const DevBatch &d, int sBase, int nStreams, int hopBase, int tileHops, hipStream_t st);
 void launchEmit(const DevBatch &d, const IoArgs &io, int sBase, int nStreams, int tileIndex, int maxSpan, hipStream_t st);
-void launchCarryFeed(const DevBatch &d, int sBase, int nStreams, int hopBase, hipStream_t st);
+void launchCarryFeed(const DevBatch &d, int sBase, int nStreams, int hopBase, bool anyFormants, hipStream_t st);
 void launchCarryOut(const DevBatch &d, int sBase, int nStreams, hipStream_t st);
 void launchHistory(const DevBatch &d, const IoArgs &io, hipStream_t st);
 void launchPassThrough(const DevBatch &d, const IoArgs &io, const int *passFlags, int maxOut, hipStream_t st);

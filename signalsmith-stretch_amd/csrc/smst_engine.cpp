@@ -100,6 +100,8 @@ Batch::Batch(int streams, int channels, int block, int interval, bool splitCompu
 		SMST_HIP(hipStreamCreateWithPriority(&stChain, hipStreamNonBlocking, hi));
 	}
 	SMST_HIP(hipStreamCreateWithFlags(&stSynth, hipStreamNonBlocking));
+	SMST_HIP(hipStreamCreateWithFlags(&stGate, hipStreamNonBlocking));
+	for (int i = 0; i < 2; ++i) SMST_HIP(hipEventCreateWithFlags(&callSets[i].done, hipEventDisableTiming));
 	SMST_HIP(hipEventCreateWithFlags(&evStart, hipEventDisableTiming));
 	for (int i = 0; i < 2; ++i) {
 		SMST_HIP(hipEventCreateWithFlags(&evFeed[i], hipEventDisableTiming));
@@ -213,9 +215,14 @@ Batch::Batch(int streams, int channels, int block, int interval, bool splitCompu
 	dParams = devAlloc<StreamParams>(S);
 	d.params = dParams;
 	dEnergy = devAlloc<float>((size_t)S*kEnergyParts);
-	dInSamples = devAlloc<int>(S);
-	dOutSamples = devAlloc<int>(S);
-	dFlags = devAlloc<int>(S);
+	for (int i = 0; i < 2; ++i) {
+		callSets[i].inSamples = devAlloc<int>(S);
+		callSets[i].outSamples = devAlloc<int>(S);
+		callSets[i].flags = devAlloc<int>(S);
+	}
+	dInSamples = callSets[0].inSamples;
+	dOutSamples = callSets[0].outSamples;
+	dFlags = callSets[0].flags;
 	dAux0 = devAlloc<int>(S);
 	dAux1 = devAlloc<int>(S);
 
@@ -236,7 +243,10 @@ Batch::~Batch() {
 	if (st) hipStreamSynchronize(st);
 	if (stChain) hipStreamSynchronize(stChain);
 	if (stSynth) hipStreamSynchronize(stSynth);
+	if (stGate) hipStreamSynchronize(stGate);
 	for (void *p : allocations) hipFree(p);
+	for (int i = 0; i < 2; ++i) if (callSets[i].done) hipEventDestroy(callSets[i].done);
+	if (stGate) hipStreamDestroy(stGate);
 	if (evStart) hipEventDestroy(evStart);
 	for (int i = 0; i < 2; ++i) {
 		if (evFeed[i]) hipEventDestroy(evFeed[i]);
@@ -429,6 +439,14 @@ void Batch::process(const float *in, long long inSS, long long inCS, const int *
                     float *out, long long outSS, long long outCS, const int *outSamples, const unsigned char *active) {
 	SMST_HIP(hipSetDevice(dev));
 	uploadParams();
+	// This call's tables go into the set that the call before the previous one used (its kernels must have finished);
+	// everything up to the first tile launch runs on `stGate`, so the host-side scheduling of this call overlaps the
+	// kernels of the previous call that are still queued on `st`.
+	callCur ^= 1;
+	CallSet &cs = callSets[callCur];
+	if (cs.used) SMST_HIP(hipEventSynchronize(cs.done));
+	dInSamples = cs.inSamples; dOutSamples = cs.outSamples; dFlags = cs.flags;
+	dHops = cs.hops; hopsCapacity = cs.hopsCap; dEmit = cs.emit; emitCapacity = cs.emitCap; dTileInfo = cs.tileInfo; tileInfoCapacity = cs.tileInfoCap;
 	const int T = d.T;
 	std::vector<int> nIn(S), nOut(S);
 	int maxOut = 0;
@@ -439,15 +457,15 @@ void Batch::process(const float *in, long long inSS, long long inCS, const int *
 		if (nIn[s] < 0 || nOut[s] < 0) throw Error("negative sample count");
 		maxOut = std::max(maxOut, nOut[s]);
 	}
-	SMST_HIP(hipMemcpyAsync(dInSamples, nIn.data(), S*sizeof(int), hipMemcpyHostToDevice, st));
-	SMST_HIP(hipMemcpyAsync(dOutSamples, nOut.data(), S*sizeof(int), hipMemcpyHostToDevice, st));
+	SMST_HIP(hipMemcpyAsync(dInSamples, nIn.data(), S*sizeof(int), hipMemcpyHostToDevice, stGate));
+	SMST_HIP(hipMemcpyAsync(dOutSamples, nOut.data(), S*sizeof(int), hipMemcpyHostToDevice, stGate));
 	IoArgs io{in, out, inSS, inCS, outSS, outCS, dInSamples, dOutSamples};
 
 	// K5: silence gate needs the input energy on the host (one 4-byte-per-stream readback per call)
 	std::vector<float> energy(S), energyParts((size_t)S*kEnergyParts);
-	launchEnergy(d, io, 0, S, dEnergy, st);
-	SMST_HIP(hipMemcpyAsync(energyParts.data(), dEnergy, energyParts.size()*sizeof(float), hipMemcpyDeviceToHost, st));
-	SMST_HIP(hipStreamSynchronize(st));
+	launchEnergy(d, io, 0, S, dEnergy, stGate);
+	SMST_HIP(hipMemcpyAsync(energyParts.data(), dEnergy, energyParts.size()*sizeof(float), hipMemcpyDeviceToHost, stGate));
+	SMST_HIP(hipStreamSynchronize(stGate));
 	for (int s = 0; s < S; ++s) {
 		float e = 0;
 		for (int p = 0; p < kEnergyParts; ++p) e += energyParts[(size_t)s*kEnergyParts + p];
@@ -584,11 +602,12 @@ void Batch::process(const float *in, long long inSS, long long inCS, const int *
 		tileInfoCapacity = tileInfo.size() + tileInfo.size()/4;
 		dTileInfo = devAlloc<int>(tileInfoCapacity);
 	}
-	SMST_HIP(hipMemcpyAsync(dHops, hopsAll.data(), hopsAll.size()*sizeof(HopDesc), hipMemcpyHostToDevice, st));
-	SMST_HIP(hipMemcpyAsync(dEmit, emitAll.data(), emitAll.size()*sizeof(EmitDesc), hipMemcpyHostToDevice, st));
-	SMST_HIP(hipMemcpyAsync(dTileInfo, tileInfo.data(), tileInfo.size()*sizeof(int), hipMemcpyHostToDevice, st));
-	if (anyPass) SMST_HIP(hipMemcpyAsync(dFlags, passFlags.data(), S*sizeof(int), hipMemcpyHostToDevice, st));
-	SMST_HIP(hipStreamSynchronize(st)); // the staging vectors are pageable and go out of scope
+	SMST_HIP(hipMemcpyAsync(dHops, hopsAll.data(), hopsAll.size()*sizeof(HopDesc), hipMemcpyHostToDevice, stGate));
+	SMST_HIP(hipMemcpyAsync(dEmit, emitAll.data(), emitAll.size()*sizeof(EmitDesc), hipMemcpyHostToDevice, stGate));
+	SMST_HIP(hipMemcpyAsync(dTileInfo, tileInfo.data(), tileInfo.size()*sizeof(int), hipMemcpyHostToDevice, stGate));
+	if (anyPass) SMST_HIP(hipMemcpyAsync(dFlags, passFlags.data(), S*sizeof(int), hipMemcpyHostToDevice, stGate));
+	SMST_HIP(hipStreamSynchronize(stGate)); // the staging vectors are pageable and go out of scope; tables complete before any launch below
+	cs.hops = dHops; cs.hopsCap = hopsCapacity; cs.emit = dEmit; cs.emitCap = emitCapacity; cs.tileInfo = dTileInfo; cs.tileInfoCap = tileInfoCapacity;
 
 	d.hops = dHops;
 	d.emit = dEmit;
@@ -640,7 +659,7 @@ void Batch::process(const float *in, long long inSS, long long inCS, const int *
 				});
 				// the carried feed-forward state (Band.input/.prevInput, Prediction.energy) may only move on once every
 				// reader of the OLD state has run: in the fused path the producers inside kVocoder still read it
-				if (!fused) timed(timings.otherMs, [&] { launchCarryFeed(dd, sBase, ns, hopBase, sF); });
+				if (!fused) timed(timings.otherMs, [&] { launchCarryFeed(dd, sBase, ns, hopBase, th[2] != 0, sF); });
 			}
 			if (!serial) {
 				SMST_HIP(hipEventRecord(evFeed[slot], sF));
@@ -653,7 +672,7 @@ void Batch::process(const float *in, long long inSS, long long inCS, const int *
 					if (profiling) ++timings.chainLaunches;
 				});
 				timed(timings.otherMs, [&] {
-					if (fused) launchCarryFeed(dd, sBase, ns, hopBase, sC);
+					if (fused) launchCarryFeed(dd, sBase, ns, hopBase, th[2] != 0, sC);
 					launchCarryOut(dd, sBase, ns, sC);
 				});
 			}
@@ -678,6 +697,8 @@ void Batch::process(const float *in, long long inSS, long long inCS, const int *
 		launchHistory(d, io, st);
 	});
 	d.histCur ^= 1;
+	SMST_HIP(hipEventRecord(cs.done, st));
+	cs.used = true;
 	SMST_HIP(hipGetLastError());
 }
 

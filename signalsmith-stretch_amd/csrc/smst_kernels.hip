@@ -1658,7 +1658,7 @@ __global__ __launch_bounds__(256) void kEmit(DevBatch d, IoArgs io, int sBase, i
 // State that outlives a tile: Band.input / Band.prevInput (= input of the last hop that analysed a new
 // spectrum, signalsmith-stretch.h:806-811), Prediction.energy of the last hop (:707), pitch-estimate state.
 // ------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void kCarryFeed(DevBatch d, int sBase, int hopBase) { // everything that does not depend on the recurrence
+__global__ __launch_bounds__(256) void kCarryFeed(DevBatch d, int sBase, int hopBase, int anyFormants) { // everything that does not depend on the recurrence
 	const int s = blockIdx.z, sg = sBase + s, c = blockIdx.y;
 	const int b = blockIdx.x*blockDim.x + threadIdx.x;
 	const int nh = d.nHops[s];
@@ -1674,7 +1674,7 @@ __global__ __launch_bounds__(256) void kCarryFeed(DevBatch d, int sBase, int hop
 		const bool plain = !(hl.flags & (HOP_MAPPED | HOP_FORMANTS));
 		d.stEnergy[stateRow(d, sg, c) + b] = plain ? cnorm(inputRow(d, hl, s, sg, c)[b]) : d.E[rowOf(d, s, nh - 1, c) + b];
 	}
-	if (b == 0 && c == 0) {
+	if (anyFormants && b == 0 && c == 0) { // a serial walk over the tile's hops: skipped for tiles without formant processing
 		float w = d.stFreq[2*sg], wt = d.stFreq[2*sg + 1];
 		bool any = false;
 		for (int j = 0; j < nh; ++j) {
@@ -1894,8 +1894,8 @@ void launchSynth(const DevBatch &d, int sBase, int nStreams, int hopBase, int ti
 void launchEmit(const DevBatch &d, const IoArgs &io, int sBase, int nStreams, int tileIndex, int maxSpan, hipStream_t st) {
 	hipLaunchKernelGGL(kEmit, dim3(divUp(divUp(maxSpan + d.carryLen, 4), 256), d.C, nStreams), dim3(256), 0, st, d, io, sBase, tileIndex);
 }
-void launchCarryFeed(const DevBatch &d, int sBase, int nStreams, int hopBase, hipStream_t st) {
-	hipLaunchKernelGGL(kCarryFeed, dim3(divUp(d.M, 256), d.C, nStreams), dim3(256), 0, st, d, sBase, hopBase);
+void launchCarryFeed(const DevBatch &d, int sBase, int nStreams, int hopBase, bool anyFormants, hipStream_t st) {
+	hipLaunchKernelGGL(kCarryFeed, dim3(divUp(d.M, 256), d.C, nStreams), dim3(256), 0, st, d, sBase, hopBase, anyFormants ? 1 : 0);
 }
 void launchCarryOut(const DevBatch &d, int sBase, int nStreams, hipStream_t st) {
 	hipLaunchKernelGGL(kCarryOut, dim3(divUp(d.M, 256), d.C, nStreams), dim3(256), 0, st, d, sBase);
