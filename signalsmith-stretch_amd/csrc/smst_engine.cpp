@@ -92,15 +92,15 @@ Batch::Batch(int streams, int channels, int block, int interval, bool splitCompu
 	: S(streams), C(channels), B(block), I(interval), split(splitComputation), dev(device) {
 	if (S < 1 || C < 1 || C > kMaxChannels || B < 4 || I < 1 || I > B) throw Error("invalid configuration (need 1..8 channels, interval <= block)");
 	SMST_HIP(hipSetDevice(dev));
-	SMST_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-	{ // the recurrence is latency-bound with few waves: give its stream the highest priority so its workgroups are
-	  // dispatched ahead of the bulk kernels' when they share the machine
+	{ // Dispatch priorities follow the critical path of the tile pipeline: the recurrence (latency-bound, few waves) and
+	  // the analysis it waits for go first; synthesis and emission fill in behind them.
 		int lo = 0, hi = 0;
 		SMST_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+		SMST_HIP(hipStreamCreateWithPriority(&st, hipStreamNonBlocking, hi));
 		SMST_HIP(hipStreamCreateWithPriority(&stChain, hipStreamNonBlocking, hi));
+		SMST_HIP(hipStreamCreateWithPriority(&stSynth, hipStreamNonBlocking, lo));
+		SMST_HIP(hipStreamCreateWithPriority(&stEmit, hipStreamNonBlocking, lo));
 	}
-	SMST_HIP(hipStreamCreateWithFlags(&stSynth, hipStreamNonBlocking));
-	SMST_HIP(hipStreamCreateWithFlags(&stEmit, hipStreamNonBlocking));
 	SMST_HIP(hipStreamCreateWithFlags(&stGate, hipStreamNonBlocking));
 	for (int i = 0; i < 2; ++i) SMST_HIP(hipEventCreateWithFlags(&callSets[i].done, hipEventDisableTiming));
 	SMST_HIP(hipEventCreateWithFlags(&evStart, hipEventDisableTiming));
