@@ -159,7 +159,13 @@ def main():
     ok = bool(torch.isfinite(y).all().item()) and float(y.abs().max().item()) > 0.01
 
     total_out = sum(n_out) if per_stream else S*n_out
-    samples_per_step = world*C*(S*n_in + total_out)
+    samples_local = C*(S*n_in + total_out)
+    if world > 1:  # per-stream stretch factors differ between ranks (config 5): add up what every rank really processed
+        tot = torch.tensor([samples_local], dtype=torch.float64, device=device)
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+        samples_per_step = int(tot.item())
+    else:
+        samples_per_step = samples_local
     value = samples_per_step*args.steps/elapsed/1e6
     B, I, M = batch.blockSamples(), batch.intervalSamples(), batch.bands()
     hops_per_stream = -(-(total_out//S)//I)
