@@ -140,8 +140,11 @@ void *smst_batch_hip_stream(smst_batch *b);
 /* measurement hooks: per-kernel-class device time (hipEvent pairs on the batch's stream) accumulated since the
  * last call.  ms[0..6] = analyse, feed, predict, chain, synth, emit, other; launches[0..4] = analyse, predict,
  * chain, synth, emit. */
-int smst_batch_enable_profiling(smst_batch *b, int on);
-int smst_batch_take_timings(smst_batch *b, double ms[7], long long launches[5]);
+/* mode 1: HIP-event pairs around every kernel class, tiles serialised (ms[0..6]: analyse, feed, predict, recurrence, synth,
+ * emit, other; launches[0..4]: analyse, predict, recurrence, synth, emit).  mode 2: only the recurrence kernel, timed in
+ * place on its own stream while the other streams keep overlapping it (ms[7], launches[5]).  0: off. */
+int smst_batch_enable_profiling(smst_batch *b, int mode);
+int smst_batch_take_timings(smst_batch *b, double ms[8], long long launches[6]);
 
 /* test hooks (tests/ only): per-stream state rows.  which: 0 Band.input, 1 Band.prevInput, 2 Band.output
  * (interleaved re,im: 2*channels*bands floats), 3 Prediction.energy (channels*bands floats). */

@@ -227,14 +227,14 @@ class StretchBatch:
         inflight.append(tensors)
         self._inflight = inflight
 
-    def enableProfiling(self, on=True): _check(self.lib, self.lib.smst_batch_enable_profiling(self.h, int(on)))
+    def enableProfiling(self, mode=1): _check(self.lib, self.lib.smst_batch_enable_profiling(self.h, int(mode)))
 
     def takeTimings(self):
-        ms = (C.c_double*7)()
-        n = (_ll*5)()
+        ms = (C.c_double*8)()
+        n = (_ll*6)()
         _check(self.lib, self.lib.smst_batch_take_timings(self.h, ms, n))
-        keys = ["analyse", "feed", "predict", "chain", "synth", "emit", "other"]
-        lk = ["analyse", "predict", "chain", "synth", "emit"]
+        keys = ["analyse", "feed", "predict", "chain", "synth", "emit", "other", "chain_live"]
+        lk = ["analyse", "predict", "chain", "synth", "emit", "chain_live"]
         return dict(zip(keys, list(ms))), dict(zip(lk, list(n)))
 
     # --- buffers

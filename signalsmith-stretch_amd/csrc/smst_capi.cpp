@@ -116,12 +116,13 @@ int smst_batch_set_formant_base(smst_batch *b, int s, float f) { BATCH_CALL(b->e
 int smst_batch_set_freq_map_table(smst_batch *b, int s, const float *table, int n) { BATCH_CALL(b->engine->setFreqMapTable(s, table, n)) }
 int smst_batch_synchronize(smst_batch *b) { BATCH_CALL(b->engine->synchronize()) }
 void *smst_batch_hip_stream(smst_batch *b) { return (b && b->engine) ? (void *)b->engine->stream() : nullptr; }
-int smst_batch_enable_profiling(smst_batch *b, int on) { BATCH_CALL(b->engine->enableProfiling(on != 0)) }
-int smst_batch_take_timings(smst_batch *b, double ms[7], long long launches[5]) {
+int smst_batch_enable_profiling(smst_batch *b, int mode) { BATCH_CALL(b->engine->enableProfiling(mode)) }
+int smst_batch_take_timings(smst_batch *b, double ms[8], long long launches[6]) {
 	BATCH_CALL({
 		smst::BatchTimings t = b->engine->takeTimings();
 		ms[0] = t.analyseMs; ms[1] = t.feedMs; ms[2] = t.predictMs; ms[3] = t.chainMs; ms[4] = t.synthMs; ms[5] = t.emitMs; ms[6] = t.otherMs;
 		launches[0] = t.analyseLaunches; launches[1] = t.predictLaunches; launches[2] = t.chainLaunches; launches[3] = t.synthLaunches; launches[4] = t.emitLaunches;
+		ms[7] = t.chainLiveMs; launches[5] = t.chainLiveLaunches;
 	})
 }
 int smst_batch_debug_get_state(smst_batch *b, int stream, int which, float *dst) { BATCH_CALL(b->engine->debugGetState(stream, which, dst)) }

@@ -430,6 +430,19 @@ template <typename F> void Batch::timed(double &acc, F &&f) {
 	hipEventDestroy(b);
 }
 BatchTimings Batch::takeTimings() {
+	if (!liveEvents.empty()) {
+		SMST_HIP(hipSetDevice(dev));
+		SMST_HIP(hipStreamSynchronize(st));
+		for (auto &e : liveEvents) {
+			float ms = 0;
+			SMST_HIP(hipEventElapsedTime(&ms, e.first, e.second));
+			timings.chainLiveMs += ms;
+			++timings.chainLiveLaunches;
+			hipEventDestroy(e.first);
+			hipEventDestroy(e.second);
+		}
+		liveEvents.clear();
+	}
 	BatchTimings t = timings;
 	timings = BatchTimings();
 	return t;
@@ -684,11 +697,21 @@ void Batch::process(const float *in, long long inSS, long long inCS, const int *
 				flushEmit(slot); // emission of the previous tile, beside this tile's recurrence
 			}
 			if (th[0]) {
+				hipEvent_t liveA = nullptr, liveB = nullptr;
+				if (liveTiming && !serial) {
+					SMST_HIP(hipEventCreate(&liveA));
+					SMST_HIP(hipEventCreate(&liveB));
+					SMST_HIP(hipEventRecord(liveA, sC));
+				}
 				timed(timings.chainMs, [&] {
 					if (fused) launchVocoder(dd, sBase, ns, hopBase, plain, !th[4], sC);
 					else launchChain(dd, sBase, ns, hopBase, sC);
 					if (profiling) ++timings.chainLaunches;
 				});
+				if (liveA) {
+					SMST_HIP(hipEventRecord(liveB, sC));
+					liveEvents.emplace_back(liveA, liveB);
+				}
 				timed(timings.otherMs, [&] {
 					if (fused) launchCarryFeed(dd, sBase, ns, hopBase, th[2] != 0, sC);
 					launchCarryOut(dd, sBase, ns, sC);

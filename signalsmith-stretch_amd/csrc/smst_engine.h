@@ -24,6 +24,8 @@ struct StreamSched { // reference members: signalsmith-stretch.h:494-529
 struct BatchTimings { // filled when profiling is enabled (hipEvent pairs around each kernel class)
 	double analyseMs = 0, feedMs = 0, predictMs = 0, chainMs = 0, synthMs = 0, emitMs = 0, otherMs = 0;
 	long analyseLaunches = 0, synthLaunches = 0, chainLaunches = 0, predictLaunches = 0, emitLaunches = 0;
+	double chainLiveMs = 0;   // mode 2: the recurrence kernel timed in place (events on its own stream, nothing serialised)
+	long chainLiveLaunches = 0;
 };
 
 class Batch {
@@ -69,7 +71,7 @@ public:
 
 	hipStream_t stream() const { return st; }
 	int device() const { return dev; }
-	void enableProfiling(bool on) { profiling = on; }
+	void enableProfiling(int mode) { profiling = mode == 1; liveTiming = mode == 2; } // 1: every kernel class, serialised; 2: recurrence kernel in place
 	BatchTimings takeTimings();
 	size_t workspaceBytes() const { return wsBytes; }
 	int subBatchStreams() const { return subS; }
@@ -99,7 +101,8 @@ private:
 	std::vector<StreamSched> sched;
 	std::vector<StreamParams> params;
 	bool paramsDirty = true;
-	bool profiling = false;
+	bool profiling = false, liveTiming = false;
+	std::vector<std::pair<hipEvent_t, hipEvent_t>> liveEvents;
 	BatchTimings timings;
 
 	std::vector<void *> allocations;
