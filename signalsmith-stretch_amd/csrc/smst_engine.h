@@ -86,13 +86,12 @@ private:
 	int dev;
 	hipStream_t st = nullptr;       // feed-forward kernels + everything the caller synchronises on
 	hipStream_t stChain = nullptr;  // the bin recurrence (few waves, latency-bound): overlaps with the bulk kernels
-	hipStream_t stSynth = nullptr;  // synthesis of the previous tile
-	hipStream_t stEmit = nullptr;   // emission (no LDS): held back until the NEXT tile's recurrence starts, which it fits beside
+	hipStream_t stSynth = nullptr;  // synthesis + emission of the previous tile
 	hipStream_t stGate = nullptr;   // silence-gate reduction + table uploads of the NEXT call, while the previous call still runs
 	// Per-call device tables exist twice: a call fills one set on `stGate` while kernels of the previous call read the other
 	struct CallSet { int *inSamples, *outSamples, *flags, *tileInfo; HopDesc *hops; EmitDesc *emit; size_t hopsCap, emitCap, tileInfoCap; hipEvent_t done; bool used; } callSets[2]{};
 	int callCur = 0;
-	hipEvent_t evStart = nullptr, evFeed[2] = {nullptr, nullptr}, evChain[2] = {nullptr, nullptr}, evSynth[2] = {nullptr, nullptr}, evEmit[2] = {nullptr, nullptr};
+	hipEvent_t evStart = nullptr, evFeed[2] = {nullptr, nullptr}, evChain[2] = {nullptr, nullptr}, evSynth[2] = {nullptr, nullptr};
 	struct TileBuffers { float2 *Xcur, *Xprev, *P, *OUT, *dump, *map, *peaksT; float4 *REC; float *E, *ratio, *energyT, *smoothT, *est, *frames; } slots[2]{};
 	bool overlap = true;
 	int subS = 0;

@@ -88,6 +88,7 @@ static inline hipError_t hipMemset(void *d, int v, size_t n) { std::memset(d, v,
 static inline hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t) { std::memset(d, v, n); return 0; }
 static inline hipError_t hipEventCreate(hipEvent_t *e) { *e = nullptr; return 0; }
 #define hipEventDisableTiming 2
+#define hipEventDisableSystemFence 0x20000000
 static inline hipError_t hipEventCreateWithFlags(hipEvent_t *e, unsigned) { *e = nullptr; return 0; }
 static inline hipError_t hipStreamWaitEvent(hipStream_t, hipEvent_t, unsigned) { return 0; }
 static inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return 0; }
