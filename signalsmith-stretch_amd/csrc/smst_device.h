@@ -17,6 +17,7 @@ struct DevBatch {
 	int mapTableLen;
 	int histCur, carryCur;        // which half of the double buffers is current
 	int debugMode;                // SMST_DEBUG_MODE experiments (0 = product behaviour)
+	int feedSerial;               // SMST_FEED_SERIAL: bin-by-bin feed recurrences (kFeedSerial) instead of the scan form
 	int noStage;                  // SMST_NO_STAGE: producers of the fused kernel gather from HBM even where staging applies
 	FftPlan plan;
 	// constant tables
@@ -49,6 +50,7 @@ struct DevBatch {
 	float *energyT, *smoothT; // [subS][M][64 hops]: feed scratch, hop index fastest
 	float2 *peaksT;           // [subS][M/2 + 2][64 hops]
 	float *est;     // [subS][T][2]
+	float *freqEst; // [subS][T]: pitch estimate (in bins) each hop's formant envelope uses
 	float *frames;  // [subS][T][C][B]
 	const int *nHops;      // [subS] hops of this tile
 	const int *lastNewHop; // [subS] tile-local index of the last hop with a new spectrum, or -1
@@ -64,7 +66,7 @@ struct IoArgs {
 
 void launchEnergy(const DevBatch &d, const IoArgs &io, int sBase, int nStreams, float *energyOut, hipStream_t st);
 void launchAnalyse(const DevBatch &d, const IoArgs &io, int sBase, int nStreams, int hopBase, int tileHops, hipStream_t st);
-void launchFeed(const DevBatch &d, int sBase, int nStreams, int hopBase, hipStream_t st);
+void launchFeed(const DevBatch &d, int sBase, int nStreams, int hopBase, int tileHops, bool anyFormants, hipStream_t st);
 void launchPredict(const DevBatch &d, int sBase, int nStreams, int hopBase, int tileHops, bool plain, hipStream_t st);
 void launchChain(const DevBatch &d, int sBase, int nStreams, int hopBase, hipStream_t st);
 void launchPredictFused(const DevBatch &d, int sBase, int nStreams, int hopBase, int tileHops, bool plain, hipStream_t st);

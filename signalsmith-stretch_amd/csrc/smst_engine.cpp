@@ -130,6 +130,7 @@ Batch::Batch(int streams, int channels, int block, int interval, bool splitCompu
 	d.debugMode = 0;
 	if (const char *env = std::getenv("SMST_DEBUG_MODE")) d.debugMode = atoi(env);
 	d.noStage = std::getenv("SMST_NO_STAGE") != nullptr;
+	d.feedSerial = std::getenv("SMST_FEED_SERIAL") != nullptr;
 
 	// constant tables
 	std::vector<float2> tw(M), half(M), rot(M);
@@ -293,6 +294,7 @@ void Batch::allocateWorkspace() {
 		w.smoothT = devAlloc<float>((size_t)subS*M*64);
 		w.peaksT = devAlloc<float2>((size_t)subS*(M/2 + 2)*64);
 		w.est = devAlloc<float>((size_t)subS*d.T*2);
+		w.freqEst = devAlloc<float>((size_t)subS*d.T);
 		w.frames = devAlloc<float>((size_t)subS*d.T*C*B);
 	}
 	wsBytes = 2*perStream*subS;
@@ -654,7 +656,7 @@ void Batch::process(const float *in, long long inSS, long long inCS, const int *
 			const TileBuffers &w = slots[slot];
 			DevBatch dd = d;
 			dd.Xcur = w.Xcur; dd.Xprev = w.Xprev; dd.P = w.P; dd.OUT = w.OUT; dd.REC = w.REC; dd.dump = w.dump; dd.E = w.E;
-			dd.map = w.map; dd.ratio = w.ratio; dd.energyT = w.energyT; dd.smoothT = w.smoothT; dd.peaksT = w.peaksT; dd.est = w.est; dd.frames = w.frames;
+			dd.map = w.map; dd.ratio = w.ratio; dd.energyT = w.energyT; dd.smoothT = w.smoothT; dd.peaksT = w.peaksT; dd.est = w.est; dd.freqEst = w.freqEst; dd.frames = w.frames;
 			dd.carryCur = (carryBase + t) & 1;
 			dd.nHops = dTileInfo + ((size_t)(sub*nTiles + t)*2)*subS;
 			dd.lastNewHop = dd.nHops + subS;
@@ -665,7 +667,7 @@ void Batch::process(const float *in, long long inSS, long long inCS, const int *
 			if (!serial && fused && !plain && q >= 1) SMST_HIP(hipStreamWaitEvent(sF, evChain[slot ^ 1], 0)); // pass A reads the carried state
 			if (th[0]) {
 				if (th[3]) timed(timings.analyseMs, [&] { launchAnalyse(dd, io, sBase, ns, hopBase, tileHops, sF); if (profiling) ++timings.analyseLaunches; });
-				if (th[1] || th[2]) timed(timings.feedMs, [&] { launchFeed(dd, sBase, ns, hopBase, sF); });
+				if (th[1] || th[2]) timed(timings.feedMs, [&] { launchFeed(dd, sBase, ns, hopBase, tileHops, th[2] != 0, sF); });
 				timed(timings.predictMs, [&] {
 					if (fused) launchPredictFused(dd, sBase, ns, hopBase, tileHops, plain, sF);
 					else launchPredict(dd, sBase, ns, hopBase, tileHops, plain, sF);

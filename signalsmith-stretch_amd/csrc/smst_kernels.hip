@@ -758,6 +758,284 @@ __global__ __launch_bounds__(64) void kFeedSerial(DevBatch d, int sBase, int hop
 }
 
 // ------------------------------------------------------------------------------------------------------
+// K2b-e, scan form.  The same recurrences, one workgroup per (stream, hop) with the hop's arrays in LDS: every pass over
+// the bins is a composition of per-bin maps  y -> m*y + c  (one-pole smoothing),  y -> max(c, m*y)  (formant decay) or
+// y -> min(c, m*y)  (formant growth), which are closed under composition.  Each thread composes the maps of its own
+// chunk of bins, the chunks' maps are scanned across the workgroup, and each thread then RE-RUNS THE REFERENCE'S SERIAL
+// FORMULA over its chunk from the carry it received -- so only the carry entering a chunk is rounded differently from a
+// bin-by-bin evaluation (and its influence decays geometrically inside the chunk).  Peak runs are summed by the thread
+// that owns the run's first bin, in the reference's order.  The serial form above (kFeedEnergy + kFeedSerial) streams
+// five [bin][64] arrays per tile through HBM (10 GB per 64-hop tile of 1024 streams, 4 ms); this form reads the input
+// spectra once.
+// ------------------------------------------------------------------------------------------------------
+struct ScanMap { float m, c; };
+template <int OP> __device__ __forceinline__ float scanApply(ScanMap f, float y) { // OP 0: m*y + c, 1: max(c, m*y), 2: min(c, m*y)
+	const float v = f.m*y;
+	return OP == 0 ? v + f.c : (OP == 1 ? fmaxf(f.c, v) : fminf(f.c, v));
+}
+template <int OP> __device__ __forceinline__ ScanMap scanCompose(ScanMap second, ScanMap first) { // second after first
+	ScanMap r;
+	r.m = second.m*first.m;
+	r.c = scanApply<OP>(second, first.c);
+	return r;
+}
+// One pass over src[0..M) in the given direction, result to dst (may alias src); `carry` enters the first bin of the
+// pass and the value after the last bin is returned.  mStep / cOf(x): the per-bin map; step(e, x): the serial formula.
+// maps: 4 entries of LDS scratch (the wave totals).  All 256 threads must call this.
+template <int OP, bool DOWN, typename COf, typename Step>
+__device__ __forceinline__ float scanPass(const float *src, float *dst, int M, float carry, float mStep, COf cOf, Step step, ScanMap *maps) {
+	const int t = threadIdx.x;
+	const int n = (M + 255)/256;              // bins per thread, in pass order
+	const int p0 = t*n, p1 = min(M, p0 + n);  // pass positions [p0, p1); position p is bin DOWN ? M-1-p : p
+	ScanMap f; f.m = 1.0f; f.c = OP == 0 ? 0.0f : (OP == 1 ? -INFINITY : INFINITY); // identity
+	for (int p = p0; p < p1; ++p) {
+		ScanMap g; g.m = mStep; g.c = cOf(src[DOWN ? M - 1 - p : p]);
+		f = scanCompose<OP>(g, f);
+	}
+	// inclusive scan of the chunk maps inside each wave (Hillis-Steele over lane shuffles), the wave totals through LDS
+	const int lane = t & 63;
+	ScanMap inc = f;
+#pragma unroll
+	for (int dlt = 1; dlt < 64; dlt <<= 1) {
+		ScanMap prev;
+		prev.m = __shfl(inc.m, max(lane - dlt, 0));
+		prev.c = __shfl(inc.c, max(lane - dlt, 0));
+		if (lane >= dlt) inc = scanCompose<OP>(inc, prev);
+	}
+	ScanMap ex; // exclusive: the composition of the chunks before this one inside the wave
+	ex.m = __shfl(inc.m, max(lane - 1, 0));
+	ex.c = __shfl(inc.c, max(lane - 1, 0));
+	if (lane == 0) { ex.m = 1.0f; ex.c = OP == 0 ? 0.0f : (OP == 1 ? -INFINITY : INFINITY); }
+	if (lane == 63) maps[t >> 6] = inc;
+	__syncthreads();
+	float waveCarry = carry; // value entering this thread's wave
+	for (int w = 0; w < (t >> 6); ++w) waveCarry = scanApply<OP>(maps[w], waveCarry);
+	float e = scanApply<OP>(ex, waveCarry);
+	float total = carry;
+	for (int w = 0; w < 4; ++w) total = scanApply<OP>(maps[w], total);
+	// the chunk again, with the reference's own formula, from the carry (src may alias dst: every thread reads and then
+	// writes only its own chunk, and nobody reads another chunk after the barriers above)
+	for (int p = p0; p < p1; ++p) {
+		const int b = DOWN ? M - 1 - p : p;
+		e = step(e, src[b]);
+		dst[b] = e;
+	}
+	__syncthreads();
+	return total;
+}
+
+// energy, smoothing, peaks, output map, raw pitch estimate: one workgroup per (hop, stream)
+__global__ __launch_bounds__(256) void kFeedScanA(DevBatch d, int sBase, int hopBase) {
+	extern __shared__ __attribute__((aligned(16))) unsigned char smemRaw[];
+	const int k = blockIdx.x, s = blockIdx.y, sg = sBase + s;
+	if (k >= d.nHops[s]) return;
+	const HopDesc hd = d.hops[(size_t)sg*d.hopStride + hopBase + k];
+	const bool mapped = hd.flags & HOP_MAPPED, formants = hd.flags & HOP_FORMANTS;
+	if (!mapped && !formants) return;
+	const int M = d.M, C = d.C, t = threadIdx.x;
+	const float Nf = float(d.N);
+	float *en = reinterpret_cast<float *>(smemRaw);         // [M] channel-summed energy
+	float *sm = en + M;                                       // [M] smoothed
+	float2 *pk = reinterpret_cast<float2 *>(sm + M);          // [M/2 + 2] peaks
+	ScanMap *maps = reinterpret_cast<ScanMap *>(pk + M/2 + 2); // [264]
+	int *counts = reinterpret_cast<int *>(maps + 264);         // [264]
+	const StreamParams prm = d.params[sg];
+	for (int b = t; b < M; b += 256) {
+		float e = 0;
+		for (int c = 0; c < C; ++c) e += cnorm(inputRow(d, hd, s, sg, c)[b]);
+		en[b] = e;
+	}
+	__syncthreads();
+	if (mapped) {
+		const float smoothingBins = Nf/float(d.I);
+		const float slew = 1/(1 + smoothingBins*0.5f);
+		auto pole = [slew](float acc, float x) { return acc + (x - acc)*slew; };
+		auto cOf = [slew](float x) { return slew*x; };
+		float e = 0;
+		e = scanPass<0, true>(en, sm, M, e, 1 - slew, cOf, pole, maps);
+		e = scanPass<0, false>(sm, sm, M, e, 1 - slew, cOf, pole, maps);
+		e = scanPass<0, true>(sm, sm, M, e, 1 - slew, cOf, pole, maps);
+		e = scanPass<0, false>(sm, sm, M, e, 1 - slew, cOf, pole, maps);
+		// findPeaks: every thread counts the runs that START in its chunk, an exclusive scan numbers them, and the owner
+		// of a run's first bin sums the run in the reference's order (:866-873)
+		const int n = (M + 255)/256, b0 = t*n, b1 = min(M, b0 + n);
+		int starts = 0;
+		for (int b = b0; b < b1; ++b) starts += (en[b] > sm[b]) && !(b > 0 && en[b - 1] > sm[b - 1]);
+		counts[t] = starts;
+		__syncthreads();
+		if ((t & 63) == 0) {
+			int acc = 0;
+			for (int i = 0; i < 64; ++i) { const int c = counts[t + i]; counts[t + i] = acc; acc += c; }
+			counts[256 + (t >> 6)] = acc;
+		}
+		__syncthreads();
+		int idx = counts[t];
+		for (int w = 0; w < (t >> 6); ++w) idx += counts[256 + w];
+		const int nPeaks = counts[256] + counts[257] + counts[258] + counts[259];
+		for (int b = b0; b < b1; ++b) {
+			if ((en[b] > sm[b]) && !(b > 0 && en[b - 1] > sm[b - 1])) {
+				float bandSum = 0, energySum = 0;
+				for (int q = b; q < M && en[q] > sm[q]; ++q) { bandSum += q*en[q]; energySum += en[q]; }
+				const float avgBand = bandSum/energySum;
+				const float avgFreq = (avgBand + 0.5f)/Nf;
+				pk[idx++] = make_float2(avgBand, mapFreqDev(d, prm, sg, avgFreq)*Nf - 0.5f);
+			}
+		}
+		__syncthreads();
+		// updateOutputMap, :882-917 (same segment rules as the serial form; the covering pair by bisection)
+		float2 *mapRow = d.map + ((size_t)s*d.T + k)*M;
+		const float2 first = nPeaks > 0 ? pk[0] : make_float2(0.f, 0.f);
+		const float2 lastP = nPeaks > 0 ? pk[nPeaks - 1] : make_float2(0.f, 0.f);
+		const int topStart = max(0, (int)lastP.y), bottomEnd = min(M, (int)ceilf(first.y));
+		for (int b = t; b < M; b += 256) {
+			float2 mp = make_float2(float(b), 1.0f);
+			if (nPeaks > 0) {
+				if (b >= topStart) {
+					mp = make_float2(b + (lastP.x - lastP.y), 1.0f);
+				} else if (b < bottomEnd) {
+					mp = make_float2(b + (first.x - first.y), 1.0f);
+				} else if (nPeaks >= 2) {
+					// largest q in [0, nPeaks-2] with max(0, ceil(peaks[q].out)) <= b (q = 0 qualifies: b >= bottomEnd)
+					int lo = 0, hi = nPeaks - 2;
+					while (lo < hi) {
+						const int mid = (lo + hi + 1) >> 1;
+						if (max(0, (int)ceilf(pk[mid].y)) <= b) lo = mid; else hi = mid - 1;
+					}
+					const float2 prev = pk[lo], next = pk[lo + 1];
+					if (b < min(M, (int)ceilf(next.y))) {
+						float rangeScale = 1/(next.y - prev.y);
+						float outOffset = prev.x - prev.y;
+						float outScale = next.x - next.y - prev.x + prev.y;
+						float gradScale = outScale*rangeScale;
+						float r = (b - prev.y)*rangeScale;
+						float h = r*r*(3 - 2*r);
+						float outB = b + outOffset + h*outScale;
+						float gradH = 6*r*(1 - r);
+						mp = make_float2(outB, 1 + gradH*gradScale);
+					}
+				}
+			}
+			mapRow[b] = mp;
+		}
+	}
+	if (formants && prm.formantBaseFreq <= 0) {
+		// estimateFrequency() raw part, :929-960: the three highest local maxima of the metric (= the channel-summed
+		// energy), ties to the earlier bin, three copies of bin 0 as the initial entries -- a serial walk by one thread
+		// (compares only, no arithmetic: 3 k steps)
+		__syncthreads();
+		if (t == 0) {
+			int p0 = 0, p1 = 0, p2 = 0;
+			float e0 = en[0], e1 = en[0], e2 = en[0];
+			for (int b = 1; b < M - 1; ++b) {
+				const float e = en[b];
+				if (!(e < en[b - 1] || e <= en[b + 1])) {
+					if (e > e0) {
+						if (e > e1) {
+							if (e > e2) { p0 = p1; e0 = e1; p1 = p2; e1 = e2; p2 = b; e2 = e; }
+							else { p0 = p1; e0 = e1; p1 = b; e1 = e; }
+						} else {
+							p0 = b; e0 = e;
+						}
+					}
+				}
+			}
+			int peakEstimate = p2;
+			if (e1 > e2*0.1f) {
+				int diff = abs(peakEstimate - p1);
+				if (diff > peakEstimate/8 && diff < peakEstimate*7/8) peakEstimate = peakEstimate%diff;
+				if (e0 > e2*0.01f) {
+					int diff2 = abs(peakEstimate - p0);
+					if (diff2 > peakEstimate/8 && diff2 < peakEstimate*7/8) peakEstimate = peakEstimate%diff2;
+				}
+			}
+			d.est[((size_t)s*d.T + k)*2] = peakEstimate*e2;
+			d.est[((size_t)s*d.T + k)*2 + 1] = e2;
+		}
+	}
+}
+
+// The pitch estimate is smoothed from hop to hop (:962-965): one thread per stream replays the tile's hops in order
+__global__ __launch_bounds__(64) void kFeedFreq(DevBatch d, int sBase, int nStreams, int hopBase) {
+	const int s = blockIdx.x*blockDim.x + threadIdx.x;
+	if (s >= nStreams) return;
+	const int sg = sBase + s, nh = d.nHops[s];
+	const StreamParams prm = d.params[sg];
+	const float Nf = float(d.N);
+	float w = d.stFreq[2*sg], wt = d.stFreq[2*sg + 1];
+	for (int j = 0; j < nh; ++j) {
+		const HopDesc hj = d.hops[(size_t)sg*d.hopStride + hopBase + j];
+		float fe = prm.formantBaseFreq*Nf - 0.5f; // freqToBand, :982
+		if ((hj.flags & HOP_FORMANTS) && prm.formantBaseFreq <= 0) {
+			w += (d.est[((size_t)s*d.T + j)*2] - w)*0.25f;
+			wt += (d.est[((size_t)s*d.T + j)*2 + 1] - wt)*0.25f;
+			fe = w/(wt + 1e-30f);
+		}
+		d.freqEst[(size_t)s*d.T + j] = fe;
+	}
+}
+
+// formant envelope (2 x (down, up) max-decay, 2 x (down, up) min-grow, :987-1006) and the per-bin energy ratio (:1018-1033)
+__global__ __launch_bounds__(256) void kFeedScanC(DevBatch d, int sBase, int hopBase) {
+	extern __shared__ __attribute__((aligned(16))) unsigned char smemRaw[];
+	const int k = blockIdx.x, s = blockIdx.y, sg = sBase + s;
+	if (k >= d.nHops[s]) return;
+	const HopDesc hd = d.hops[(size_t)sg*d.hopStride + hopBase + k];
+	if (!(hd.flags & HOP_FORMANTS)) return;
+	const int M = d.M, C = d.C, t = threadIdx.x;
+	const float Nf = float(d.N);
+	float *en = reinterpret_cast<float *>(smemRaw);
+	float *sm = en + M;
+	ScanMap *maps = reinterpret_cast<ScanMap *>(sm + M);
+	const StreamParams prm = d.params[sg];
+	for (int b = t; b < M; b += 256) {
+		float e = 0;
+		for (int c = 0; c < C; ++c) e += cnorm(inputRow(d, hd, s, sg, c)[b]);
+		en[b] = e;
+	}
+	__syncthreads();
+	const float freqEstimate = d.freqEst[(size_t)s*d.T + k];
+	float decay = 1 - 1/(freqEstimate*0.5f + 1);
+	float e = 0;
+	{
+		const float dk = decay;
+		auto maxDecay = [dk](float acc, float x) { return fmaxf(x, acc*dk); };
+		auto cOf = [](float x) { return x; };
+		e = scanPass<1, true>(en, sm, M, e, dk, cOf, maxDecay, maps);
+		e = scanPass<1, false>(sm, sm, M, e, dk, cOf, maxDecay, maps);
+		e = scanPass<1, true>(sm, sm, M, e, dk, cOf, maxDecay, maps);
+		e = scanPass<1, false>(sm, sm, M, e, dk, cOf, maxDecay, maps);
+	}
+	decay = 1/decay;
+	{
+		const float dk = decay;
+		auto minGrow = [dk](float acc, float x) { return fminf(x, acc*dk); };
+		auto cOf = [](float x) { return x; };
+		for (int rep = 0; rep < 2; ++rep) {
+			e = scanPass<2, true>(sm, sm, M, e, dk, cOf, minGrow, maps);
+			e = scanPass<2, false>(sm, sm, M, e, dk, cOf, minGrow, maps);
+		}
+	}
+	float *ratio = d.ratio + ((size_t)s*d.T + k)*M;
+	for (int b = t; b < M; b += 256) {
+		float inputF = (b + 0.5f)/Nf;
+		float outputF = prm.formantCompensation ? mapFreqDev(d, prm, sg, inputF) : inputF;
+		if (outputF*prm.invFormantMultiplier > prm.freqTonalityLimit) outputF = outputF + (1 - prm.formantMultiplier)*prm.freqTonalityLimit; // invMapFormant, :920-925
+		else outputF = outputF*prm.invFormantMultiplier;
+		const float inputE = sm[b];
+		float band = outputF*Nf - 0.5f;
+		float targetE = 0;
+		if (!(band < 0)) { // getFormant, :1009-1016 (entries M and M+1 of the metric are zero)
+			band = fminf(band, float(M));
+			const int fl = (int)floorf(band);
+			const float fr = band - fl;
+			const float low = (fl < M) ? sm[fl] : 0.0f, high = (fl + 1 < M) ? sm[fl + 1] : 0.0f;
+			targetE = low + (high - low)*fr;
+		}
+		ratio[b] = targetE/(inputE + 1e-30f);
+	}
+}
+
+// ------------------------------------------------------------------------------------------------------
 // K2a+K2f: per-(hop, channel, bin) prediction coefficients -- everything the bin recurrence needs that does
 // not depend on previous outputs (signalsmith-stretch.h:642-660 rotation, :697-719 preliminary prediction,
 // :748-785 vertical twists):
@@ -1802,9 +2080,19 @@ void launchAnalyse(const DevBatch &d, const IoArgs &io, int sBase, int nStreams,
 	size_t lds = 2*(size_t)d.M*sizeof(float2);
 	hipLaunchKernelGGL(kAnalyse, grid, dim3(256), lds, st, d, io, sBase, hopBase);
 }
-void launchFeed(const DevBatch &d, int sBase, int nStreams, int hopBase, hipStream_t st) {
-	hipLaunchKernelGGL(kFeedEnergy, dim3(divUp(d.M, 64), nStreams), dim3(256), 64*65*sizeof(float), st, d, sBase, hopBase);
-	hipLaunchKernelGGL(kFeedSerial, dim3(nStreams), dim3(64), 0, st, d, sBase, hopBase);
+void launchFeed(const DevBatch &d, int sBase, int nStreams, int hopBase, int tileHops, bool anyFormants, hipStream_t st) {
+	if (d.feedSerial) { // bin-by-bin evaluation (SMST_FEED_SERIAL=1)
+		hipLaunchKernelGGL(kFeedEnergy, dim3(divUp(d.M, 64), nStreams), dim3(256), 64*65*sizeof(float), st, d, sBase, hopBase);
+		hipLaunchKernelGGL(kFeedSerial, dim3(nStreams), dim3(64), 0, st, d, sBase, hopBase);
+		return;
+	}
+	const size_t ldsA = (size_t)2*d.M*sizeof(float) + (size_t)(d.M/2 + 2)*sizeof(float2) + 264*sizeof(ScanMap) + 264*sizeof(int);
+	const size_t ldsC = (size_t)2*d.M*sizeof(float) + 264*sizeof(ScanMap);
+	hipLaunchKernelGGL(kFeedScanA, dim3(tileHops, nStreams), dim3(256), ldsA, st, d, sBase, hopBase);
+	if (anyFormants) {
+		hipLaunchKernelGGL(kFeedFreq, dim3(divUp(nStreams, 64)), dim3(64), 0, st, d, sBase, nStreams, hopBase);
+		hipLaunchKernelGGL(kFeedScanC, dim3(tileHops, nStreams), dim3(256), ldsC, st, d, sBase, hopBase);
+	}
 }
 template <int CH>
 static void launchPredictT(const DevBatch &d, int sBase, int nStreams, int hopBase, int tileHops, bool plain, hipStream_t st) {

@@ -66,7 +66,7 @@ void emuLaunch(dim3 grid, dim3 block, size_t ldsBytes, const std::function<void(
 	}
 }
 
-// ---- wave-level collectives for 64-thread (single wave) kernels: every lane deposits its value, yields once so that
+// ---- wave-level collectives (votes span the block and are only used by single-wave kernels): every lane deposits its value, yields once so that
 // all lanes of the block have deposited, then reads.  Two alternating banks keep back-to-back collectives apart.
 namespace {
 float shflBankF[2][1024];
@@ -89,7 +89,7 @@ float emuShflF(float v, int lane) {
 	const int me = laneIndex(), bank = collectiveSeq[me]++ & 1;
 	shflBankF[bank][me] = v;
 	emuSyncThreads();
-	float r = shflBankF[bank][lane];
+	float r = shflBankF[bank][(me & ~63) + (lane & 63)]; // source lane within the caller's own wave
 	emuSyncThreads();
 	return r;
 }
@@ -97,7 +97,7 @@ int emuShflI(int v, int lane) {
 	const int me = laneIndex(), bank = collectiveSeq[me]++ & 1;
 	shflBankI[bank][me] = v;
 	emuSyncThreads();
-	int r = shflBankI[bank][lane];
+	int r = shflBankI[bank][(me & ~63) + (lane & 63)];
 	emuSyncThreads();
 	return r;
 }
