@@ -238,3 +238,53 @@ def test_feed_scan_close_to_serial(hip, monkeypatch):
         b.close()
     d = (outs[0] - outs[1]).pow(2).mean().sqrt()/outs[1].pow(2).mean().sqrt()
     assert float(d) < 2e-4, float(d)
+
+
+@pytest.mark.gpu
+def test_mapped_path_chunking_and_determinism(hip):
+    """Pitch map + formants (scan-form feed, gathering record producers): the same call twice is bit-identical, and
+    hop-aligned chunks are bit-identical to one call, as on the plain path."""
+    import torch
+    pkg = package()
+    S, C, sr = 8, 2, 48000
+    x = torch.from_numpy(np.stack([synth_input(s, C, 28800, sr) for s in range(S)])).cuda()
+
+    def make():
+        b = pkg.StretchBatch(S, C, preset="default", sample_rate=sr, lib=hip)
+        b.setTransposeSemitones(5, 8000/48000)
+        b.setFormantFactor(0.9, True)
+        b.setFormantBase(150/48000)
+        return b
+    b = make()
+    whole = b.process(x, 36000)
+    b.synchronize()  # results are ordered on the batch's own stream, not on torch's
+    whole = whole.clone()
+    b.reset()
+    again = b.process(x, 36000)
+    b.synchronize()
+    again = again.clone()
+    b.reset()
+    parts = [b.process(x[:, :, 5760*k:5760*(k + 1)].contiguous(), 7200) for k in range(5)]
+    b.synchronize()
+    chunked = torch.cat(parts, dim=2)
+    b.close()
+    assert float(whole.abs().max()) > 0.05
+    assert torch.equal(whole, again)
+    assert torch.equal(whole, chunked), float((whole - chunked).abs().max())
+
+
+@pytest.mark.gpu
+def test_eight_channel_identity_at_scale(hip):
+    """BASELINE config-5 geometry (8 channels, 96 kHz, presetCheaper, split computation) through the un-fused recurrence
+    (kPredictB + kChain): 1.0x / 0 st reproduces every input delayed by inputLatency + outputLatency."""
+    import torch
+    pkg = package()
+    S, C, sr, n = 48, 8, 96000, 96000
+    x = torch.from_numpy(np.stack([synth_input(s, C, n, sr) for s in range(12)])).repeat(4, 1, 1)[:S].contiguous().cuda()
+    b = pkg.StretchBatch(S, C, preset="cheaper", sample_rate=sr, lib=hip)
+    lag = b.inputLatency() + b.outputLatency()
+    y = b.process(x, n)
+    b.synchronize()
+    b.close()
+    err = torch.sqrt(((y[:, :, lag:] - x[:, :, :-lag])**2).mean(dim=(1, 2))/(x[:, :, :-lag]**2).mean(dim=(1, 2)))
+    assert float(err.max()) < 4e-6, float(err.max())
