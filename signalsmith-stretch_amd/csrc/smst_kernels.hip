@@ -251,8 +251,10 @@ __device__ __forceinline__ void dftLast(float2 (&v)[R3]) {
 
 // load(idx) -> float2 supplies the natural-order input, store(idx, value) receives the natural-order output.
 // lds: H + H/16 float2.  All threads of the block must call this (it synchronises).
-template <int SIGN, int R3, typename Load, typename Store>
-__device__ __forceinline__ void fftFast(float2 *lds, const float2 *__restrict__ twA, const float2 *__restrict__ twB, Load load, Store store) {
+// prep(idx) -> any value: called for ALL outputs of a thread before the first store(idx, value, prepared), so whatever it
+// loads is in flight together (a load placed inside `store` is not moved above the preceding stores by the compiler).
+template <int SIGN, int R3, typename Load, typename Prep, typename Store>
+__device__ __forceinline__ void fftFast(float2 *lds, const float2 *__restrict__ twA, const float2 *__restrict__ twB, Load load, Prep prep, Store store) {
 	constexpr int MA = 16*R3;
 	const int t = threadIdx.x;
 	float2 v[16];
@@ -302,11 +304,17 @@ __device__ __forceinline__ void fftFast(float2 *lds, const float2 *__restrict__ 
 		float2 u[R3];
 #pragma unroll
 		for (int k = 0; k < R3; ++k) u[k] = lds[t + 256*k];
+		decltype(prep(0)) ready[R3];
+#pragma unroll
+		for (int pos = 0; pos < R3; ++pos) {
+			const int e = pos/G, c = pos - G*e;
+			ready[pos] = prep(t + 256*(e + 4*c));
+		}
 		dftLast<SIGN, R3>(u);
 #pragma unroll
 		for (int pos = 0; pos < R3; ++pos) {
 			const int e = pos/G, c = pos - G*e;
-			store(t + 256*(e + 4*c), u[pos]);
+			store(t + 256*(e + 4*c), u[pos], ready[pos]);
 		}
 	}
 }
@@ -329,7 +337,8 @@ __global__ __launch_bounds__(16*R3 > 256 ? 16*R3 : 256) __attribute__((amdgpu_wa
 	const float *hist = d.hist[d.histCur] + ((size_t)(sBase + s)*d.C + c)*(size_t)d.histLen + d.histLen;
 	const float2 *__restrict__ winA = d.winA, *__restrict__ winB = d.winB;
 	float2 *dst = (which ? d.Xprev : d.Xcur) + rowOf(d, s, k, c);
-	auto store = [&](int j, float2 u) {
+	auto prep = [](int) { return 0; };
+	auto store = [&](int j, float2 u, int) {
 		const int kk = 2*j;
 		if (kk < H) dst[kk] = u;
 		else dst[N - 1 - kk] = cconj(u);
@@ -346,7 +355,7 @@ __global__ __launch_bounds__(16*R3 > 256 ? 16*R3 : 256) __attribute__((amdgpu_wa
 				if (slot < 15) { const float xr = x0[m]; const float2 a = winA[m]; r = make_float2(xr*a.x, xr*a.y); }
 				if (slot > 0) { const float xi = x1[m]; const float2 b = winB[m]; r = make_float2(fmaf(xi, b.x, r.x), fmaf(xi, b.y, r.y)); }
 				return r;
-			}, store);
+			}, prep, store);
 		return;
 	}
 	fftFast<-1, R3>(lds, d.twA, d.twB,
@@ -356,7 +365,7 @@ __global__ __launch_bounds__(16*R3 > 256 ? 16*R3 : 256) __attribute__((amdgpu_wa
 			if (m >= H - halfB) { int src = base + m - H + halfB; xi = (src >= 0) ? x[src] : hist[src]; }
 			const float2 a = winA[m], b = winB[m];
 			return make_float2(fmaf(xi, b.x, xr*a.x), fmaf(xi, b.y, xr*a.y));
-		}, store);
+		}, prep, store);
 }
 
 template <int R3>
@@ -368,18 +377,28 @@ __global__ __launch_bounds__(16*R3 > 256 ? 16*R3 : 256) void kSynthFast(DevBatch
 	if (!(hd.flags & HOP_ACTIVE)) return;
 	const int B = d.B, H = d.M, N = d.N, halfB = B/2;
 	const float2 *X = d.OUT + rowOf(d, s, k, c);
-	float *frame = d.frames + ((size_t)((size_t)s*d.T + k)*d.C + c)*(size_t)B;
+	float *__restrict__ frame = d.frames + ((size_t)((size_t)s*d.T + k)*d.C + c)*(size_t)B;
 	const float *__restrict__ win = d.window;
 	const float2 *__restrict__ halfTw = d.halfTw;
 	fftFast<+1, R3>(lds, d.twA, d.twB,
 		[&](int j, int) {
+			// one load at a selected address, conjugated afterwards: with a load in each arm of the conditional the
+			// compiler emitted 16 loads each followed by s_waitcnt vmcnt(0) -- sixteen memory round trips per FFT
 			const int kk = 2*j;
-			return (kk < H) ? X[kk] : cconj(X[N - 1 - kk]);
+			const bool upper = kk >= H;
+			float2 v = X[upper ? N - 1 - kk : kk];
+			if (upper) v.y = -v.y;
+			return v;
 		},
-		[&](int m, float2 u) {
-			const float2 v = cmulc(u, halfTw[m]); // * e^{+i pi m / N}
-			if (m < B - halfB) { const int i = m + halfB; frame[i] = (2*v.x)*win[i]; }
-			if (m >= H - halfB) { const int i = m - H + halfB; frame[i] = (2*v.y)*win[i]; }
+		[&](int m) { // everything the R3 outputs of a thread need from memory, requested before the first store
+			const int i0 = m + halfB, i1 = m - H + halfB;
+			const float2 tw = halfTw[m];
+			return make_float4(tw.x, tw.y, win[(m < B - halfB) ? i0 : 0], win[(m >= H - halfB) ? i1 : 0]);
+		},
+		[&](int m, float2 u, float4 r) {
+			const float2 v = cmulc(u, make_float2(r.x, r.y)); // * e^{+i pi m / N}
+			if (m < B - halfB) frame[m + halfB] = (2*v.x)*r.z;
+			if (m >= H - halfB) frame[m - H + halfB] = (2*v.y)*r.w;
 		});
 }
 
@@ -1899,19 +1918,41 @@ __global__ __launch_bounds__(256) void kEmit(DevBatch d, IoArgs io, int sBase, i
 		int qHi = (rel0 + 3 >= 0) ? (rel0 + 3)/I : -1;
 		const int qLo = (rel0 - B + 1 > 0) ? (rel0 - B + 1 + I - 1)/I : 0;
 		if (qHi > ed.hopCount - 1) qHi = ed.hopCount - 1;
-		for (int q = qLo; q <= qHi; ++q) {
-			const int idx0 = rel0 - q*I;
-			const float *frame = d.frames + ((size_t)((size_t)s*d.T + q)*d.C + c)*(size_t)B;
-			if (idx0 >= 0 && idx0 + 3 < B) {
-				const float4 f = *reinterpret_cast<const float4 *>(frame + idx0), w = *reinterpret_cast<const float4 *>(d.wprod + idx0);
-				sum[0] += f.x; sum[1] += f.y; sum[2] += f.z; sum[3] += f.w;
-				wp[0] += w.x; wp[1] += w.y; wp[2] += w.z; wp[3] += w.w;
-			} else {
+		// all covering frames' loads are issued before the first addition (a loop with a load per iteration costs one
+		// memory round trip per frame); the additions then run in ascending q, the order the reference sums in
+		constexpr int KMAX = 6;
+		float4 f[KMAX], w[KMAX];
+		bool fast[KMAX];
+#pragma unroll
+		for (int k = 0; k < KMAX; ++k) {
+			const int q = qLo + k, idx0 = rel0 - q*I;
+			fast[k] = q <= qHi && idx0 >= 0 && idx0 + 3 < B;
+			const float *frame = d.frames + ((size_t)((size_t)s*d.T + (fast[k] ? q : 0))*d.C + c)*(size_t)B;
+			f[k] = *reinterpret_cast<const float4 *>(frame + (fast[k] ? idx0 : 0));
+			w[k] = *reinterpret_cast<const float4 *>(d.wprod + (fast[k] ? idx0 : 0));
+		}
+#pragma unroll
+		for (int k = 0; k < KMAX; ++k) {
+			const int q = qLo + k, idx0 = rel0 - q*I;
+			if (fast[k]) {
+				sum[0] += f[k].x; sum[1] += f[k].y; sum[2] += f[k].z; sum[3] += f[k].w;
+				wp[0] += w[k].x; wp[1] += w[k].y; wp[2] += w[k].z; wp[3] += w[k].w;
+			} else if (q <= qHi) { // a group that straddles a frame edge
+				const float *frame = d.frames + ((size_t)((size_t)s*d.T + q)*d.C + c)*(size_t)B;
 #pragma unroll
 				for (int j = 0; j < 4; ++j) {
 					const int idx = idx0 + j;
 					if (idx >= 0 && idx < B) { sum[j] += frame[idx]; wp[j] += d.wprod[idx]; }
 				}
+			}
+		}
+		for (int q = qLo + KMAX; q <= qHi; ++q) { // more than KMAX covering frames (block/interval > 5): plain loop
+			const int idx0 = rel0 - q*I;
+			const float *frame = d.frames + ((size_t)((size_t)s*d.T + q)*d.C + c)*(size_t)B;
+#pragma unroll
+			for (int j = 0; j < 4; ++j) {
+				const int idx = idx0 + j;
+				if (idx >= 0 && idx < B) { sum[j] += frame[idx]; wp[j] += d.wprod[idx]; }
 			}
 		}
 	}
