@@ -304,17 +304,28 @@ __device__ __forceinline__ void fftFast(float2 *lds, const float2 *__restrict__ 
 		float2 u[R3];
 #pragma unroll
 		for (int k = 0; k < R3; ++k) u[k] = lds[t + 256*k];
-		decltype(prep(0)) ready[R3];
+		constexpr int CHUNK = R3 <= 12 ? R3 : 5; // outputs prepared ahead of their stores (R3 = 20: four rounds, or the registers cost a wave of occupancy)
+		decltype(prep(0)) ready[CHUNK];
 #pragma unroll
-		for (int pos = 0; pos < R3; ++pos) {
-			const int e = pos/G, c = pos - G*e;
-			ready[pos] = prep(t + 256*(e + 4*c));
+		for (int i = 0; i < CHUNK; ++i) { // the first round's loads fly during the butterflies
+			const int e = i/G, c = i - G*e;
+			ready[i] = prep(t + 256*(e + 4*c));
 		}
 		dftLast<SIGN, R3>(u);
 #pragma unroll
-		for (int pos = 0; pos < R3; ++pos) {
-			const int e = pos/G, c = pos - G*e;
-			store(t + 256*(e + 4*c), u[pos], ready[pos]);
+		for (int p0 = 0; p0 < R3; p0 += CHUNK) {
+			if (p0 > 0) {
+#pragma unroll
+				for (int i = 0; i < CHUNK; ++i) {
+					const int pos = p0 + i, e = pos/G, c = pos - G*e;
+					if (pos < R3) ready[i] = prep(t + 256*(e + 4*c));
+				}
+			}
+#pragma unroll
+			for (int i = 0; i < CHUNK; ++i) {
+				const int pos = p0 + i, e = pos/G, c = pos - G*e;
+				if (pos < R3) store(t + 256*(e + 4*c), u[pos], ready[i]);
+			}
 		}
 	}
 }
@@ -492,9 +503,8 @@ __device__ __forceinline__ const float2 *inputRow(const DevBatch &d, const HopDe
 	return (hd.inSrc >= 0) ? d.Xcur + rowOf(d, s, hd.inSrc, c) : d.stInput + stateRow(d, sGlobal, c);
 }
 __device__ __forceinline__ const float2 *prevRow(const DevBatch &d, const HopDesc &hd, int s, int k, int sGlobal, int c) {
-	if (hd.prevSrc >= 0) return d.Xcur + rowOf(d, s, hd.prevSrc, c);
-	if (hd.prevSrc == SRC_REANALYSED) return d.Xprev + rowOf(d, s, k, c);
-	return d.stPrev + stateRow(d, sGlobal, c);
+	const float2 *fromTile = ((hd.prevSrc >= 0) ? d.Xcur : d.Xprev) + rowOf(d, s, (hd.prevSrc >= 0) ? hd.prevSrc : k, c);
+	return (hd.prevSrc >= 0 || hd.prevSrc == SRC_REANALYSED) ? fromTile : d.stPrev + stateRow(d, sGlobal, c);
 }
 
 __device__ __forceinline__ float mapFreqDev(const DevBatch &d, const StreamParams &p, int sGlobal, float freq) { // :850-856
@@ -1087,10 +1097,10 @@ __device__ __forceinline__ float2 lerpBand(const float2 *row, LerpIndex li, int 
 	const int ci = min(max(li.lo, 0), M - 2);
 	const float4 v = *reinterpret_cast<const float4 *>(row + ci); // 8-byte aligned; gfx9 global loads need dword alignment only
 	const int delta = li.lo - ci; // 0 in range; -1: low tap is bin -1; +1: low tap is bin M-1; otherwise both taps are outside
-	float2 low = make_float2(v.x, v.y), high = make_float2(v.z, v.w);
-	if (delta == -1) { high = low; low = make_float2(0.f, 0.f); }
-	else if (delta == 1) { low = high; high = make_float2(0.f, 0.f); }
-	else if (delta != 0) { low = make_float2(0.f, 0.f); high = low; }
+	// selects, not branches (a branch here ends the basic block and the loads of the next tap wait behind it)
+	const bool d0 = delta == 0, dp = delta == 1, dm = delta == -1;
+	const float2 low = make_float2(d0 ? v.x : (dp ? v.z : 0.f), d0 ? v.y : (dp ? v.w : 0.f));
+	const float2 high = make_float2(d0 ? v.z : (dm ? v.x : 0.f), d0 ? v.w : (dm ? v.y : 0.f));
 	return make_float2(low.x + (high.x - low.x)*li.fr, low.y + (high.y - low.y)*li.fr);
 }
 __device__ __forceinline__ float2 rotAt(const DevBatch &d, int idx, bool rotate) { // hop rotation of bin idx, 1 outside / when off
@@ -1154,7 +1164,9 @@ struct RecordSource {
 	__device__ __forceinline__ float2 P(int c, int b) const { return PLAIN ? in0[(size_t)c*pitch + b] : d.P[rowOf(d, s, k, c) + b]; }
 	__device__ __forceinline__ float E(int c, int b, float2 p) const { return PLAIN ? cnorm(p) : d.E[rowOf(d, s, k, c) + b]; }
 	__device__ __forceinline__ float2 mapAt(int b) const {
-		return (!PLAIN && (hd.flags & HOP_MAPPED)) ? d.map[((size_t)s*d.T + k)*M + b] : make_float2(float(b), 1.0f);
+		if (PLAIN) return make_float2(float(b), 1.0f);
+		const float2 m = d.map[((size_t)s*d.T + k)*M + b]; // always loaded (the row exists, mapped or not), selected afterwards
+		return (hd.flags & HOP_MAPPED) ? m : make_float2(float(b), 1.0f);
 	}
 };
 
