@@ -288,3 +288,69 @@ def test_eight_channel_identity_at_scale(hip):
     b.close()
     err = torch.sqrt(((y[:, :, lag:] - x[:, :, :-lag])**2).mean(dim=(1, 2))/(x[:, :, :-lag]**2).mean(dim=(1, 2)))
     assert float(err.max()) < 4e-6, float(err.max())
+
+
+def _inputs_cuda(S, C, n, sr):
+    import torch
+    base = torch.from_numpy(np.stack([synth_input(s, C, n, sr) for s in range(12)]))
+    return base.repeat((S + 11)//12, 1, 1)[:S].contiguous().cuda()
+
+
+@pytest.mark.gpu
+def test_full_size_config3_and_4(hip):
+    """BASELINE configs 3 and 4b at their full per-GPU stream counts (1024 resp. 512 stereo streams; 2 s instead of 10 s):
+    size-independent properties on the mapped path -- every output finite and of input-like level, the same call twice
+    bit-identical, and streams inside the big batch bit-identical to the same streams in a batch of their own."""
+    import torch
+    pkg = package()
+    sr, C, n = 48000, 2, 96000
+
+    def cfg3(b):
+        b.setTransposeSemitones(12, 8000/48000)
+
+    def cfg4b(b):
+        b.setTransposeSemitones(4, 8000/48000)
+        b.setFormantFactor(1, True)
+        b.setFormantBase(200/48000)
+    for S, stretch, setup in ((1024, 1.0, cfg3), (512, 0.75, cfg4b)):
+        x = _inputs_cuda(S, C, n, sr)
+        n_out = int(n*stretch)
+        b = pkg.StretchBatch(S, C, preset="default", sample_rate=sr, lib=hip)
+        setup(b)
+        y = b.process(x, n_out)
+        b.synchronize()
+        y = y.clone()
+        b.reset()
+        y2 = b.process(x, n_out)
+        b.synchronize()
+        assert torch.equal(y, y2)
+        b.close()
+        assert bool(torch.isfinite(y).all())
+        rms_in, rms_out = x.pow(2).mean(dim=(1, 2)).sqrt(), y[:, :, n_out//4:].pow(2).mean(dim=(1, 2)).sqrt()
+        ratio = rms_out/rms_in
+        # (the chirp streams lose most of their energy above the fold when shifted up an octave: 0.09)
+        assert 0.02 < float(ratio.min()) and float(ratio.max()) < 3.0, (float(ratio.min()), float(ratio.max()))
+        picks = [0, S//2 + 1, S - 1]
+        small = pkg.StretchBatch(len(picks), C, preset="default", sample_rate=sr, lib=hip)
+        setup(small)
+        ys = small.process(x[picks].contiguous(), n_out)
+        small.synchronize()
+        assert torch.equal(ys, y[picks])
+        small.close()
+
+
+@pytest.mark.gpu
+def test_full_size_config5_identity(hip):
+    """BASELINE config 5 at its full per-GPU size (1024 streams x 8 channels, 96 kHz, presetCheaper / split, 2 s):
+    1.0x / 0 st is the identity with the documented delay."""
+    import torch
+    pkg = package()
+    S, C, sr, n = 1024, 8, 96000, 192000
+    x = _inputs_cuda(S, C, n, sr)
+    b = pkg.StretchBatch(S, C, preset="cheaper", sample_rate=sr, lib=hip)
+    lag = b.inputLatency() + b.outputLatency()
+    y = b.process(x, n)
+    b.synchronize()
+    b.close()
+    err = torch.sqrt(((y[:, :, lag:] - x[:, :, :-lag])**2).mean(dim=(1, 2))/(x[:, :, :-lag]**2).mean(dim=(1, 2)))
+    assert float(err.max()) < 4e-6, float(err.max())
