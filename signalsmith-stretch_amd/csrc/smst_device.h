@@ -26,6 +26,8 @@ struct DevBatch {
 	const float2 *rot;     // per-bin hop rotation (signalsmith-stretch.h:647-655)
 	const float2 *twA, *twB; // fast FFT (H = 256*R3): stage twiddles laid out [n-1][p]
 	const float2 *winA, *winB; // analysis window folded with e^{-i pi m/N}: u[m] = x[m+B/2]*winA[m] + x[m-H+B/2]*winB[m]
+	const float4 *win4;        // (winA[m], winB[m]) interleaved: one 16-byte load per element in the fast analysis kernel
+	const float4 *synTab;      // (halfTw[m], window[m+B/2] or 0, window[m-M+B/2] or 0): one 16-byte load per synthesis output
 	const float *window;   // analysis == synthesis window (Kaiser, perfect reconstruction)
 	const float *wprod;    // window[i]^2 * N
 	// per-stream state

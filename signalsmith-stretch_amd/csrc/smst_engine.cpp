@@ -182,6 +182,13 @@ Batch::Batch(int streams, int channels, int block, int interval, bool splitCompu
 		}
 		d.winA = static_cast<float2 *>(upload(wa.data(), M*sizeof(float2)));
 		d.winB = static_cast<float2 *>(upload(wb.data(), M*sizeof(float2)));
+		std::vector<float4> w4(M), st4(M);
+		for (int m = 0; m < M; ++m) {
+			w4[m] = make_float4(wa[m].x, wa[m].y, wb[m].x, wb[m].y);
+			st4[m] = make_float4(half[m].x, half[m].y, (m < B - halfB) ? win[m + halfB] : 0.0f, (m >= M - halfB) ? win[m - M + halfB] : 0.0f);
+		}
+		d.win4 = static_cast<float4 *>(upload(w4.data(), M*sizeof(float4)));
+		d.synTab = static_cast<float4 *>(upload(st4.data(), M*sizeof(float4)));
 		d.twA = d.twB = nullptr;
 		if (M%256 == 0 && (M/256 == 12 || M/256 == 20)) {
 			const int R3 = M/256, MA = 16*R3;

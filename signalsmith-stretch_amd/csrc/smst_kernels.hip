@@ -359,12 +359,14 @@ __global__ __launch_bounds__(16*R3 > 256 ? 16*R3 : 256) __attribute__((amdgpu_wa
 		// the usual case (both presets): the whole window lies in this call's input, and the two halves of the packed
 		// input change validity exactly at element-slot boundaries: slot 0 has no imaginary part, slot 15 no real part
 		const float *x0 = x + base + halfB, *x1 = x + base - H + halfB;
+		const float4 *__restrict__ win4 = d.win4;
 		fftFast<-1, R3>(lds, d.twA, d.twB,
 			[&](int m, int slot) {
 				// same roundings as the general path below: round(xi*b + round(xr*a)), with the absent half an exact zero
+				const float4 w = win4[m]; // (winA, winB) in one 16-byte load
 				float2 r = make_float2(0.f, 0.f);
-				if (slot < 15) { const float xr = x0[m]; const float2 a = winA[m]; r = make_float2(xr*a.x, xr*a.y); }
-				if (slot > 0) { const float xi = x1[m]; const float2 b = winB[m]; r = make_float2(fmaf(xi, b.x, r.x), fmaf(xi, b.y, r.y)); }
+				if (slot < 15) { const float xr = x0[m]; r = make_float2(xr*w.x, xr*w.y); }
+				if (slot > 0) { const float xi = x1[m]; r = make_float2(fmaf(xi, w.z, r.x), fmaf(xi, w.w, r.y)); }
 				return r;
 			}, prep, store);
 		return;
@@ -389,8 +391,7 @@ __global__ __launch_bounds__(16*R3 > 256 ? 16*R3 : 256) void kSynthFast(DevBatch
 	const int B = d.B, H = d.M, N = d.N, halfB = B/2;
 	const float2 *X = d.OUT + rowOf(d, s, k, c);
 	float *__restrict__ frame = d.frames + ((size_t)((size_t)s*d.T + k)*d.C + c)*(size_t)B;
-	const float *__restrict__ win = d.window;
-	const float2 *__restrict__ halfTw = d.halfTw;
+	const float4 *__restrict__ synTab = d.synTab;
 	fftFast<+1, R3>(lds, d.twA, d.twB,
 		[&](int j, int) {
 			// one load at a selected address, conjugated afterwards: with a load in each arm of the conditional the
@@ -401,10 +402,9 @@ __global__ __launch_bounds__(16*R3 > 256 ? 16*R3 : 256) void kSynthFast(DevBatch
 			if (upper) v.y = -v.y;
 			return v;
 		},
-		[&](int m) { // everything the R3 outputs of a thread need from memory, requested before the first store
-			const int i0 = m + halfB, i1 = m - H + halfB;
-			const float2 tw = halfTw[m];
-			return make_float4(tw.x, tw.y, win[(m < B - halfB) ? i0 : 0], win[(m >= H - halfB) ? i1 : 0]);
+		[&](int m) { // everything an output needs from memory in ONE 16-byte load (twiddle + its two window samples),
+			// requested for all of a thread's outputs before the first store
+			return synTab[m];
 		},
 		[&](int m, float2 u, float4 r) {
 			const float2 v = cmulc(u, make_float2(r.x, r.y)); // * e^{+i pi m / N}
