@@ -28,6 +28,7 @@ struct DevBatch {
 	const float2 *winA, *winB; // analysis window folded with e^{-i pi m/N}: u[m] = x[m+B/2]*winA[m] + x[m-H+B/2]*winB[m]
 	const float4 *win4;        // (winA[m], winB[m]) interleaved: one 16-byte load per element in the fast analysis kernel
 	const float4 *synTab;      // (halfTw[m], window[m+B/2] or 0, window[m-M+B/2] or 0): one 16-byte load per synthesis output
+	const float4 *twA4, *twB4; // stage twiddles of the register-blocked FFT, rows (2i, 2i+1) paired: [8][16*R3], [8][R3]
 	const float *window;   // analysis == synthesis window (Kaiser, perfect reconstruction)
 	const float *wprod;    // window[i]^2 * N
 	// per-stream state

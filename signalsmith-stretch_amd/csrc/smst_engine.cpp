@@ -205,6 +205,19 @@ Batch::Batch(int streams, int channels, int block, int interval, bool splitCompu
 			}
 			d.twA = static_cast<float2 *>(upload(ta.data(), ta.size()*sizeof(float2)));
 			d.twB = static_cast<float2 *>(upload(tb.data(), tb.size()*sizeof(float2)));
+			std::vector<float4> ta4((size_t)8*MA), tb4((size_t)8*R3);
+			for (int i = 0; i < 8; ++i) {
+				for (int p = 0; p < MA; ++p) {
+					const float2 lo = ta[(size_t)(2*i)*MA + p], hi = (2*i + 1 < 15) ? ta[(size_t)(2*i + 1)*MA + p] : make_float2(1.f, 0.f);
+					ta4[(size_t)i*MA + p] = make_float4(lo.x, lo.y, hi.x, hi.y);
+				}
+				for (int p = 0; p < R3; ++p) {
+					const float2 lo = tb[(size_t)(2*i)*R3 + p], hi = (2*i + 1 < 15) ? tb[(size_t)(2*i + 1)*R3 + p] : make_float2(1.f, 0.f);
+					tb4[(size_t)i*R3 + p] = make_float4(lo.x, lo.y, hi.x, hi.y);
+				}
+			}
+			d.twA4 = static_cast<float4 *>(upload(ta4.data(), ta4.size()*sizeof(float4)));
+			d.twB4 = static_cast<float4 *>(upload(tb4.data(), tb4.size()*sizeof(float4)));
 		}
 	}
 	d.wprod = static_cast<float *>(upload(wprod.data(), B*sizeof(float)));

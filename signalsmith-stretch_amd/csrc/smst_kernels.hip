@@ -254,7 +254,7 @@ __device__ __forceinline__ void dftLast(float2 (&v)[R3]) {
 // prep(idx) -> any value: called for ALL outputs of a thread before the first store(idx, value, prepared), so whatever it
 // loads is in flight together (a load placed inside `store` is not moved above the preceding stores by the compiler).
 template <int SIGN, int R3, typename Load, typename Prep, typename Store>
-__device__ __forceinline__ void fftFast(float2 *lds, const float2 *__restrict__ twA, const float2 *__restrict__ twB, Load load, Prep prep, Store store) {
+__device__ __forceinline__ void fftFast(float2 *lds, const float4 *__restrict__ twA, const float4 *__restrict__ twB, Load load, Prep prep, Store store) {
 	constexpr int MA = 16*R3;
 	const int t = threadIdx.x;
 	float2 v[16];
@@ -262,13 +262,17 @@ __device__ __forceinline__ void fftFast(float2 *lds, const float2 *__restrict__ 
 	if (t < MA) {
 #pragma unroll
 		for (int k = 0; k < 16; ++k) v[k] = load(t + MA*k, k);
+		float4 wA[8]; // the 15 stage twiddles, two per 16-byte load, in flight during the butterflies
+#pragma unroll
+		for (int i = 0; i < 8; ++i) wA[i] = twA[i*MA + t];
 		dft16<SIGN>(v);
 #pragma unroll
 		for (int pos = 0; pos < 16; ++pos) {
 			const int n = (pos >> 2) + 4*(pos & 3);
 			float2 val = v[pos];
 			if (n > 0) {
-				float2 w = twA[(n - 1)*MA + t];
+				const float4 pr = wA[(n - 1) >> 1];
+				float2 w = ((n - 1) & 1) ? make_float2(pr.z, pr.w) : make_float2(pr.x, pr.y);
 				if (SIGN > 0) w.y = -w.y;
 				val = cmul(val, w);
 			}
@@ -284,13 +288,17 @@ __device__ __forceinline__ void fftFast(float2 *lds, const float2 *__restrict__ 
 	}
 	__syncthreads();
 	if (t < MA) {
+		float4 wB[8];
+#pragma unroll
+		for (int i = 0; i < 8; ++i) wB[i] = twB[i*R3 + p];
 		dft16<SIGN>(v);
 #pragma unroll
 		for (int pos = 0; pos < 16; ++pos) {
 			const int n = (pos >> 2) + 4*(pos & 3);
 			float2 val = v[pos];
 			if (n > 0) {
-				float2 w = twB[(n - 1)*R3 + p];
+				const float4 pr = wB[(n - 1) >> 1];
+				float2 w = ((n - 1) & 1) ? make_float2(pr.z, pr.w) : make_float2(pr.x, pr.y);
 				if (SIGN > 0) w.y = -w.y;
 				val = cmul(val, w);
 			}
@@ -360,7 +368,7 @@ __global__ __launch_bounds__(16*R3 > 256 ? 16*R3 : 256) __attribute__((amdgpu_wa
 		// input change validity exactly at element-slot boundaries: slot 0 has no imaginary part, slot 15 no real part
 		const float *x0 = x + base + halfB, *x1 = x + base - H + halfB;
 		const float4 *__restrict__ win4 = d.win4;
-		fftFast<-1, R3>(lds, d.twA, d.twB,
+		fftFast<-1, R3>(lds, d.twA4, d.twB4,
 			[&](int m, int slot) {
 				// same roundings as the general path below: round(xi*b + round(xr*a)), with the absent half an exact zero
 				const float4 w = win4[m]; // (winA, winB) in one 16-byte load
@@ -371,7 +379,7 @@ __global__ __launch_bounds__(16*R3 > 256 ? 16*R3 : 256) __attribute__((amdgpu_wa
 			}, prep, store);
 		return;
 	}
-	fftFast<-1, R3>(lds, d.twA, d.twB,
+	fftFast<-1, R3>(lds, d.twA4, d.twB4,
 		[&](int m, int) {
 			float xr = 0, xi = 0;
 			if (m < B - halfB) { int src = base + m + halfB; xr = (src >= 0) ? x[src] : hist[src]; }
@@ -392,7 +400,7 @@ __global__ __launch_bounds__(16*R3 > 256 ? 16*R3 : 256) void kSynthFast(DevBatch
 	const float2 *X = d.OUT + rowOf(d, s, k, c);
 	float *__restrict__ frame = d.frames + ((size_t)((size_t)s*d.T + k)*d.C + c)*(size_t)B;
 	const float4 *__restrict__ synTab = d.synTab;
-	fftFast<+1, R3>(lds, d.twA, d.twB,
+	fftFast<+1, R3>(lds, d.twA4, d.twB4,
 		[&](int j, int) {
 			// one load at a selected address, conjugated afterwards: with a load in each arm of the conditional the
 			// compiler emitted 16 loads each followed by s_waitcnt vmcnt(0) -- sixteen memory round trips per FFT
