@@ -1,0 +1,63 @@
+"""The C++ drop-in header (include/signalsmith-stretch/signalsmith-stretch.h) must accept code written against the
+reference class: every public member of signalsmith-stretch.h:38-491 with the reference's argument lists, called the way
+cmd/main.cpp:44-82 and the README call them (any buffer type indexable as buf[channel][index]).  Compile-only."""
+import os
+import subprocess
+import textwrap
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+SOURCE = textwrap.dedent(r'''
+    #include "signalsmith-stretch/signalsmith-stretch.h"
+    #include <vector>
+    #include <array>
+    #include <functional>
+    using Stretch = signalsmith::stretch::SignalsmithStretch<float>;
+    int main() {
+        Stretch stretch;          // :38
+        Stretch seeded(12345L);   // :39
+        stretch.presetDefault(2, 48000.0f);            // :63
+        stretch.presetDefault(2, 48000.0f, true);
+        stretch.presetCheaper(2, 48000.0f);            // :66
+        stretch.presetCheaper(2, 48000.0f, false);
+        stretch.configure(2, 4096, 1024);              // :71
+        stretch.configure(2, 4096, 1024, true);
+        int a = stretch.blockSamples() + stretch.intervalSamples() + stretch.inputLatency() + stretch.outputLatency();  // :42-47,:96-101
+        bool split = stretch.splitComputation();       // :102
+        stretch.reset();                               // :49
+        stretch.setTransposeFactor(1.5f);              // :107
+        stretch.setTransposeFactor(1.5f, 0.25f);
+        stretch.setTransposeSemitones(3);              // :116
+        stretch.setTransposeSemitones(3.0f, 8000.0f/48000);
+        stretch.setFreqMap([](float f) { return f*1.2f; });   // :120
+        stretch.setFreqMap(nullptr);
+        stretch.setFormantFactor(1.1f);                // :124
+        stretch.setFormantFactor(1.1f, true);
+        stretch.setFormantSemitones(2);                // :129
+        stretch.setFormantSemitones(2.0f, true);
+        stretch.setFormantBase();                      // :133
+        stretch.setFormantBase(200.0f/48000);
+        std::vector<std::vector<float>> in(2, std::vector<float>(8192)), out(2, std::vector<float>(8192));
+        float *inPtr[2] = {in[0].data(), in[1].data()}, *outPtr[2] = {out[0].data(), out[1].data()};
+        std::array<std::vector<float>, 2> inArr{{in[0], in[1]}};
+        stretch.seek(in, 1000, 1.0);                   // :140 (any indexable buffers)
+        stretch.seek(inPtr, stretch.seekLength(), 0.5);   // :166
+        int osl = stretch.outputSeekLength(1.0f);      // :205
+        stretch.outputSeek(inArr, osl);                // :173
+        stretch.process(in, 4096, out, 4096);          // :210
+        stretch.process(inPtr, 1000, outPtr, 1500);
+        stretch.flush(out, 512);                       // :427
+        stretch.flush(outPtr, 512, 1.0f);
+        bool ok = stretch.exact(in, 8192, out, 8192);  // :468
+        static_assert(Stretch::version[0] == 1 && Stretch::version[1] == 3, "reference API version");   // :36
+        return (a > 0 && ok && split) ? 0 : 1;
+    }
+''')
+
+
+def test_reference_style_code_compiles(tmp_path):
+    src = tmp_path / "dropin.cpp"
+    src.write_text(SOURCE)
+    r = subprocess.run(["g++", "-std=c++11", "-Wall", "-Wextra", "-fsyntax-only", "-I", os.path.join(ROOT, "include"), str(src)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
