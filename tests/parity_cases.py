@@ -79,26 +79,28 @@ SMALL = dict(preset="configure", block=512, interval=128, split=False)
 SMALL_SPLIT = dict(preset="configure", block=512, interval=128, split=True)
 
 
-def case_api_surface(lib, ref, cfg=SMALL):
-    """seek / process in ragged chunks / flush / process-after-flush / outputSeek / exact, small geometry."""
+def case_api_surface(lib, ref, cfg=SMALL, scale=1):
+    """seek / process in ragged chunks / flush / process-after-flush / outputSeek / exact; `scale` stretches every
+    sample count of the walk (1 for the small geometry it was written for, ~block/512 for larger blocks)."""
     C, sr = 2, 48000
-    x = synth_input(0, C, 128*150, sr) + 0.3*synth_input(1, C, 128*150, sr)
+    x = synth_input(0, C, 128*150*scale, sr) + 0.3*synth_input(1, C, 128*150*scale, sr)
     # many hops in one call (crosses the 64-hop tile boundary twice)
     check_scenario(lib, ref, cfg, x, lambda o, xx: o.process(xx, int(xx.shape[1]*1.25)), "one long call")
 
     def ragged(o, xx):  # ragged chunk sizes, ratio 1.3 (0..5 hops per call)
         rng = np.random.default_rng(0)
         pos, outs = 0, []
-        while pos < xx.shape[1] - 700:
-            ni = int(rng.integers(1, 600))
+        while pos < xx.shape[1] - 700*scale:
+            ni = int(rng.integers(1, 600*scale))
             outs.append(o.process(xx[:, pos:pos + ni], int(ni*1.3)))
             pos += ni
         return np.concatenate(outs, axis=1)
     check_scenario(lib, ref, cfg, x, ragged, "ragged chunks")
 
     def seek_flush(o, xx):  # seek, process, flush (short), process again, flush (exactly one interval)
-        o.seek(xx[:, :640], 0.8)
-        return np.concatenate([o.process(xx[:, 640:4640], 5000), o.flush(100), o.process(xx[:, 5000:7000], 2000), o.flush(128)], axis=1)
+        o.seek(xx[:, :640*scale], 0.8)
+        k = scale
+        return np.concatenate([o.process(xx[:, 640*k:4640*k], 5000*k), o.flush(100*k), o.process(xx[:, 5000*k:7000*k], 2000*k), o.flush(o.intervalSamples())], axis=1)
     check_scenario(lib, ref, cfg, x, seek_flush, "seek/process/flush")
 
     g, r = make("product", lib, ref, C, cfg), make("ref", lib, ref, C, cfg)
@@ -107,11 +109,11 @@ def case_api_surface(lib, ref, cfg=SMALL):
 
     def output_seek(o, xx):
         o.outputSeek(xx[:, :n])
-        return o.process(xx[:, n:n + 4000], 5000)
+        return o.process(xx[:, n:n + 4000*scale], 5000*scale)
     check_scenario(lib, ref, cfg, x, output_seek, "outputSeek")
 
     def exact(o, xx):
-        out, ok = o.exact(xx[:, :6000], 7000)
+        out, ok = o.exact(xx[:, :6000*scale], 7000*scale)
         assert ok
         return out
     check_scenario(lib, ref, cfg, x, exact, "exact")

@@ -21,6 +21,11 @@ def test_api_surface_small(hip, ref):
     pc.case_api_surface(hip, ref)
 
 
+def test_api_surface_d48(hip, ref):
+    """The same API walk at presetDefault @ 48 kHz (the fast FFT kernels and the staged record producers)."""
+    pc.case_api_surface(hip, ref, cfg=D48, scale=12)
+
+
 def test_split_mode(hip, ref):
     pc.case_split_mode(hip, ref)
 
