@@ -1099,17 +1099,23 @@ __device__ __forceinline__ float2 bandAt(const float2 *row, int idx, int M) { //
 	const float2 v = row[ci];
 	return (ci == idx) ? v : make_float2(0.f, 0.f);
 }
-__device__ __forceinline__ float2 lerpBand(const float2 *row, LerpIndex li, int M) { // getFractional, :553-557
-	// both taps with ONE 16-byte load (they are adjacent bins): half the memory transactions of two 8-byte loads.
-	// The pair is read at a clamped position and the taps outside [0, M) are zeroed afterwards (branch-free).
-	const int ci = min(max(li.lo, 0), M - 2);
+struct BandPair { float2 lo, hi; };
+// bins idx and idx+1 of a row with ONE 16-byte load (half the memory instructions of two 8-byte loads): the pair is read at
+// a clamped position and the taps outside [0, M) are zeroed afterwards with selects (a branch here would end the basic
+// block and the loads of the next tap would wait behind it)
+__device__ __forceinline__ BandPair pairAt(const float2 *row, int idx, int M) {
+	const int ci = min(max(idx, 0), M - 2);
 	const float4 v = *reinterpret_cast<const float4 *>(row + ci); // 8-byte aligned; gfx9 global loads need dword alignment only
-	const int delta = li.lo - ci; // 0 in range; -1: low tap is bin -1; +1: low tap is bin M-1; otherwise both taps are outside
-	// selects, not branches (a branch here ends the basic block and the loads of the next tap wait behind it)
+	const int delta = idx - ci; // 0 in range; -1: low tap is bin -1; +1: low tap is bin M-1; otherwise both taps are outside
 	const bool d0 = delta == 0, dp = delta == 1, dm = delta == -1;
-	const float2 low = make_float2(d0 ? v.x : (dp ? v.z : 0.f), d0 ? v.y : (dp ? v.w : 0.f));
-	const float2 high = make_float2(d0 ? v.z : (dm ? v.x : 0.f), d0 ? v.w : (dm ? v.y : 0.f));
-	return make_float2(low.x + (high.x - low.x)*li.fr, low.y + (high.y - low.y)*li.fr);
+	BandPair r;
+	r.lo = make_float2(d0 ? v.x : (dp ? v.z : 0.f), d0 ? v.y : (dp ? v.w : 0.f));
+	r.hi = make_float2(d0 ? v.z : (dm ? v.x : 0.f), d0 ? v.w : (dm ? v.y : 0.f));
+	return r;
+}
+__device__ __forceinline__ float2 lerpBand(const float2 *row, LerpIndex li, int M) { // getFractional, :553-557
+	const BandPair p = pairAt(row, li.lo, M);
+	return make_float2(p.lo.x + (p.hi.x - p.lo.x)*li.fr, p.lo.y + (p.hi.y - p.lo.y)*li.fr);
 }
 __device__ __forceinline__ float2 rotAt(const DevBatch &d, int idx, bool rotate) { // hop rotation of bin idx, 1 outside / when off
 	const int ci = min(max(idx, 0), d.M - 1);
@@ -1180,21 +1186,23 @@ struct RecordSource {
 
 // coefficient multiplying the previous hop's final output at bin bx (bx = b+1 or b+L), see the record description
 template <int CH, bool PLAIN>
-__device__ __forceinline__ float2 twistAt(const RecordSource<CH, PLAIN> &src, int mc, int bx, bool rotate, const float2 *in,
+__device__ __forceinline__ float2 twistAt(const RecordSource<CH, PLAIN> &src, int mc, int bx, float2 mp, bool rotate, const float2 *in,
                                           const float2 *pv, const float *EprevRow, const float2 *inPrevHop, float tfDown, float stepMul) {
-	// bx may be one past the last bin for the callers' masked-out cases: every access below clamps
+	// bx may be one past the last bin for the callers' masked-out cases: every access below clamps; mp = mapAt(min(bx, M-1))
 	const DevBatch &d = src.d;
 	const int M = src.M;
 	const int bc = min(bx, M - 1);
-	const float2 mp = src.mapAt(bc);
 	const float2 rotB = rotAt(d, bc, rotate);
 	float2 Q;
 	if (PLAIN) { // identity map: the previous-input tap sits exactly on bin bc (fraction 0), and shares its rotation
 		Q = cmul(pv[bc], rotB);
 	} else {
 		const LerpIndex li = lerpIndex(mp.x);
-		const float2 qLo = cmul(bandAt(pv, li.lo, M), rotAt(d, li.lo, rotate));
-		const float2 qHi = cmul(bandAt(pv, li.lo + 1, M), rotAt(d, li.lo + 1, rotate));
+		const BandPair pvp = pairAt(pv, li.lo, M), rp = pairAt(d.rot, li.lo, M); // two 16-byte loads instead of four 8-byte ones
+		const bool loIn = li.lo >= 0 && li.lo < M, hiIn = li.lo + 1 >= 0 && li.lo + 1 < M;
+		const float2 one = make_float2(1.f, 0.f);
+		const float2 qLo = cmul(pvp.lo, (rotate && loIn) ? rp.lo : one);
+		const float2 qHi = cmul(pvp.hi, (rotate && hiIn) ? rp.hi : one);
 		Q = make_float2(qLo.x + (qHi.x - qLo.x)*li.fr, qLo.y + (qHi.y - qLo.y)*li.fr);
 	}
 	const float2 Px = src.P(mc, bc);
@@ -1233,7 +1241,19 @@ __device__ __forceinline__ void computeRecord(const DevBatch &d, const HopDesc &
 	float2 Pm = p[0];
 #pragma unroll
 	for (int c = 1; c < CH; ++c) if (c == mc) Pm = p[c];
-	const float2 mp = src.mapAt(b);
+	// the map entries of bins b and b+1 are adjacent: one 16-byte load; b+L separately
+	float2 mp, mp1;
+	if (PLAIN) {
+		mp = make_float2(float(b), 1.0f);
+		mp1 = make_float2(float(min(b + 1, M - 1)), 1.0f);
+	} else {
+		const int ci = min(b, M - 2);
+		const float4 pr = *reinterpret_cast<const float4 *>(d.map + ((size_t)s*d.T + k)*M + ci);
+		const bool mapped = hd.flags & HOP_MAPPED;
+		mp = mapped ? ((b == ci) ? make_float2(pr.x, pr.y) : make_float2(pr.z, pr.w)) : make_float2(float(b), 1.0f);
+		mp1 = mapped ? make_float2(pr.z, pr.w) : make_float2(float(ci + 1), 1.0f);
+	}
+	const float2 mpL = src.mapAt(min(b + L, M - 1));
 	float tfUp = hd.timeFactor, tfDn = hd.timeFactor;
 	if (randomTf) { // uniform(4 - tf, tf): one draw per bin and direction (:640,:749,:769)
 		const float lo = 4.0f - hd.timeFactor, span = hd.timeFactor - lo;
@@ -1249,8 +1269,8 @@ __device__ __forceinline__ void computeRecord(const DevBatch &d, const HopDesc &
 		const float2 zero = make_float2(0.f, 0.f);
 		A = cmulc(Pcm, lerpBand(in, lerpIndex(mp.x - tfUp), M));
 		B = cmulc(Pcm, lerpBand(in, lerpIndex(mp.x - L*tfUp), M));
-		Cc = twistAt<CH, PLAIN>(src, cm, b + 1, rotate, in, pv, EprevRow, inPrevHop, tfDn, 1.0f);
-		Dc = twistAt<CH, PLAIN>(src, cm, b + L, rotate, in, pv, EprevRow, inPrevHop, tfDn, float(L));
+		Cc = twistAt<CH, PLAIN>(src, cm, b + 1, mp1, rotate, in, pv, EprevRow, inPrevHop, tfDn, 1.0f);
+		Dc = twistAt<CH, PLAIN>(src, cm, b + L, mpL, rotate, in, pv, EprevRow, inPrevHop, tfDn, float(L));
 		if (!(b > 0)) A = zero;      // :748
 		if (!(b >= L)) B = zero;     // :756
 		if (!(b < M - 1)) Cc = zero; // :765
