@@ -44,10 +44,10 @@ struct DevBatch {
 	const HopDesc *hops;   // [S][hopStride]
 	const EmitDesc *emit;  // [S][emitStride]
 	// per-tile workspace, [subS][T][C][M] unless noted
-	float2 *Xcur, *Xprev, *P, *OUT;
+	float2 *Xcur, *Xprev, *OUT;
+	float4 *PE;     // (Prediction.input, Prediction.energy, -) per (hop, channel, bin): [subS][T][C][Mp]
 	float2 *dump;   // [subS][C][64] parking lot for the recurrence kernel's out-of-range lanes
 	float4 *REC;    // skewed per-step records of the bin recurrence [subS][recSteps][chunks][64 lanes]
-	float *E;
 	float2 *map;    // [subS][T][M]
 	float *ratio;   // [subS][T][M]
 	float *energyT, *smoothT; // [subS][M][64 hops]: feed scratch, hop index fastest

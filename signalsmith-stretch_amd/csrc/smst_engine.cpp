@@ -281,15 +281,22 @@ Batch::~Batch() {
 }
 
 void Batch::allocateWorkspace() {
-	// Per (stream, hop, channel): 4 complex rows + 1 float row of M bins + one B-sample frame, plus the skewed records.
-	// Sub-batch the streams so the tile workspace stays under a budget (default 48 GiB of the 288 GB HBM).
-	double budgetGiB = 24; // per workspace; there are two
+	// Per (stream, hop, channel): 3 complex rows + 1 float4 row of M bins + one B-sample frame, plus the skewed records.
+	// Sub-batch the streams so the tile workspace stays under a budget.  Default: a third of the HBM that is free when the
+	// batch is created, per workspace (there are two), at most 96 GiB -- fewer, larger sub-batches keep the one-wave-per-
+	// stream kernels of the 3-8 channel path at more than one wave per CU (config 5: 2 sub-batches instead of 7).
+	double budgetGiB = 24;
+	{
+		size_t freeB = 0, totalB = 0;
+		if (hipMemGetInfo(&freeB, &totalB) == hipSuccess && freeB > 0)
+			budgetGiB = std::min(96.0, std::max(8.0, double(freeB)/(1024.0*1024.0*1024.0)/3.0));
+	}
 	if (const char *env = std::getenv("SMST_WORKSPACE_GIB")) budgetGiB = std::max(0.0005, atof(env));
 	const size_t recChunks = (9 + 3*(size_t)C + 3)/4;
 	d.recSteps = ((M + d.lag*(d.T - 1) + 63)/64)*64 + 8;
 	d.recPitch = int(recChunks*64 + 16);
 	d.Mp = M + 32;
-	const size_t perStream = (size_t)d.T*((size_t)C*((size_t)d.Mp*(4*sizeof(float2) + sizeof(float)) + (size_t)B*sizeof(float))
+	const size_t perStream = (size_t)d.T*((size_t)C*((size_t)d.Mp*(3*sizeof(float2) + sizeof(float4)) + (size_t)B*sizeof(float))
 	                                      + (size_t)M*(sizeof(float2) + 2*sizeof(float)) + 2*sizeof(float))
 	                         + (size_t)d.recSteps*d.recPitch*sizeof(float4);
 	size_t maxStreams = size_t(budgetGiB*1024.0*1024.0*1024.0/double(perStream));
@@ -302,12 +309,11 @@ void Batch::allocateWorkspace() {
 		TileBuffers &w = slots[i];
 		w.Xcur = devAlloc<float2>(rows);
 		w.Xprev = devAlloc<float2>(rows);
-		w.P = devAlloc<float2>(rows);
+		w.PE = devAlloc<float4>(rows);
 		w.OUT = devAlloc<float2>(rows);
 		w.REC = devAlloc<float4>((size_t)subS*d.recSteps*d.recPitch);
 		SMST_HIP(hipMemset(w.REC, 0, (size_t)subS*d.recSteps*d.recPitch*sizeof(float4)));
 		w.dump = devAlloc<float2>((size_t)subS*C*64);
-		w.E = devAlloc<float>(rows);
 		w.map = devAlloc<float2>((size_t)subS*d.T*M);
 		w.ratio = devAlloc<float>((size_t)subS*d.T*M);
 		w.energyT = devAlloc<float>((size_t)subS*M*64);
@@ -675,7 +681,7 @@ void Batch::process(const float *in, long long inSS, long long inCS, const int *
 			const bool fused = fusedSupported(d) && !noFuse; // mono/stereo: records stay in LDS (kVocoder)
 			const TileBuffers &w = slots[slot];
 			DevBatch dd = d;
-			dd.Xcur = w.Xcur; dd.Xprev = w.Xprev; dd.P = w.P; dd.OUT = w.OUT; dd.REC = w.REC; dd.dump = w.dump; dd.E = w.E;
+			dd.Xcur = w.Xcur; dd.Xprev = w.Xprev; dd.PE = w.PE; dd.OUT = w.OUT; dd.REC = w.REC; dd.dump = w.dump;
 			dd.map = w.map; dd.ratio = w.ratio; dd.energyT = w.energyT; dd.smoothT = w.smoothT; dd.peaksT = w.peaksT; dd.est = w.est; dd.freqEst = w.freqEst; dd.frames = w.frames;
 			dd.carryCur = (carryBase + t) & 1;
 			dd.nHops = dTileInfo + ((size_t)(sub*nTiles + t)*2)*subS;

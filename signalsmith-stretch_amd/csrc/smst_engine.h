@@ -92,7 +92,7 @@ private:
 	struct CallSet { int *inSamples, *outSamples, *flags, *tileInfo; HopDesc *hops; EmitDesc *emit; size_t hopsCap, emitCap, tileInfoCap; hipEvent_t done; bool used; } callSets[2]{};
 	int callCur = 0;
 	hipEvent_t evStart = nullptr, evFeed[2] = {nullptr, nullptr}, evChain[2] = {nullptr, nullptr}, evSynth[2] = {nullptr, nullptr};
-	struct TileBuffers { float2 *Xcur, *Xprev, *P, *OUT, *dump, *map, *peaksT; float4 *REC; float *E, *ratio, *energyT, *smoothT, *est, *freqEst, *frames; } slots[2]{};
+	struct TileBuffers { float2 *Xcur, *Xprev, *OUT, *dump, *map, *peaksT; float4 *REC, *PE; float *ratio, *energyT, *smoothT, *est, *freqEst, *frames; } slots[2]{};
 	bool overlap = true;
 	int subS = 0;
 	size_t wsBytes = 0;

@@ -1145,8 +1145,8 @@ __global__ __launch_bounds__(256) void kPredictA(DevBatch d, int sBase, int hopB
 			if (loIn) eLo *= ratio[li.lo];
 			if (hiIn) eHi *= ratio[li.lo + 1];
 		}
-		d.E[o] = (eLo + (eHi - eLo)*li.fr)*gradScale;
-		d.P[o] = make_float2(inLo.x + (inHi.x - inLo.x)*li.fr, inLo.y + (inHi.y - inLo.y)*li.fr);
+		// Prediction.input and Prediction.energy of a bin side by side: their readers fetch both with one 16-byte load
+		d.PE[o] = make_float4(inLo.x + (inHi.x - inLo.x)*li.fr, inLo.y + (inHi.y - inLo.y)*li.fr, (eLo + (eHi - eLo)*li.fr)*gradScale, 0.0f);
 	}
 }
 
@@ -1175,8 +1175,11 @@ struct RecordSource {
 		pitch = (hd.inSrc >= 0) ? d.Mp : d.M;
 	}
 	__device__ __forceinline__ const float2 *inRow(int c) const { return in0 + (size_t)c*pitch; }
-	__device__ __forceinline__ float2 P(int c, int b) const { return PLAIN ? in0[(size_t)c*pitch + b] : d.P[rowOf(d, s, k, c) + b]; }
-	__device__ __forceinline__ float E(int c, int b, float2 p) const { return PLAIN ? cnorm(p) : d.E[rowOf(d, s, k, c) + b]; }
+	// (Prediction.input.x, .y, Prediction.energy, -) of channel c at bin b
+	__device__ __forceinline__ float4 PE(int c, int b) const {
+		if (PLAIN) { const float2 p = in0[(size_t)c*pitch + b]; return make_float4(p.x, p.y, cnorm(p), 0.0f); }
+		return d.PE[rowOf(d, s, k, c) + b];
+	}
 	__device__ __forceinline__ float2 mapAt(int b) const {
 		if (PLAIN) return make_float2(float(b), 1.0f);
 		const float2 m = d.map[((size_t)s*d.T + k)*M + b]; // always loaded (the row exists, mapped or not), selected afterwards
@@ -1187,7 +1190,7 @@ struct RecordSource {
 // coefficient multiplying the previous hop's final output at bin bx (bx = b+1 or b+L), see the record description
 template <int CH, bool PLAIN>
 __device__ __forceinline__ float2 twistAt(const RecordSource<CH, PLAIN> &src, int mc, int bx, float2 mp, bool rotate, const float2 *in,
-                                          const float2 *pv, const float *EprevRow, const float2 *inPrevHop, float tfDown, float stepMul) {
+                                          const float2 *pv, const float *EprevRow, int eprevStride, const float2 *inPrevHop, float tfDown, float stepMul) {
 	// bx may be one past the last bin for the callers' masked-out cases: every access below clamps; mp = mapAt(min(bx, M-1))
 	const DevBatch &d = src.d;
 	const int M = src.M;
@@ -1205,10 +1208,11 @@ __device__ __forceinline__ float2 twistAt(const RecordSource<CH, PLAIN> &src, in
 		const float2 qHi = cmul(pvp.hi, (rotate && hiIn) ? rp.hi : one);
 		Q = make_float2(qLo.x + (qHi.x - qLo.x)*li.fr, qLo.y + (qHi.y - qLo.y)*li.fr);
 	}
-	const float2 Px = src.P(mc, bc);
+	const float4 pe = src.PE(mc, bc);
+	const float2 Px = make_float2(pe.x, pe.y);
 	const float2 TW = cmul(rotB, cmulc(Px, Q));
-	const float eNow = src.E(mc, bc, Px);
-	const float ePrev = (PLAIN && inPrevHop) ? cnorm(inPrevHop[bc]) : EprevRow[bc];
+	const float eNow = pe.z;
+	const float ePrev = (PLAIN && inPrevHop) ? cnorm(inPrevHop[bc]) : EprevRow[(size_t)bc*eprevStride];
 	const float den = fmaxf(ePrev, eNow) + 1e-15f; // :716
 	const float2 down = cmulc(Px, lerpBand(in, lerpIndex(mp.x - stepMul*tfDown), M));
 	const float2 r = cmulc(TW, down);
@@ -1229,8 +1233,9 @@ __device__ __forceinline__ void computeRecord(const DevBatch &d, const HopDesc &
 	float e[CH];
 #pragma unroll
 	for (int c = 0; c < CH; ++c) {
-		p[c] = src.P(c, b);
-		e[c] = src.E(c, b, p[c]);
+		const float4 pe = src.PE(c, b);
+		p[c] = make_float2(pe.x, pe.y);
+		e[c] = pe.z;
 	}
 	int mc = 0; // maximum-energy channel, first maximum wins (:729-737)
 	float eMax = e[0];
@@ -1264,13 +1269,15 @@ __device__ __forceinline__ void computeRecord(const DevBatch &d, const HopDesc &
 		const float2 *in = src.inRow(cm);
 		const float2 *pv = prevRow(d, hd, s, k, sg, cm);
 		// Prediction.energy of the previous hop: the carried state for the tile's first hop, else hop k-1's
-		const float *EprevRow = (k == 0) ? d.stEnergy + stateRow(d, sg, cm) : (PLAIN ? nullptr : d.E + rowOf(d, s, k - 1, cm));
+		// the carried state is a plain float row; inside the tile the energy is the third float of hop k-1's (P, E) entries
+		const float *EprevRow = (k == 0) ? d.stEnergy + stateRow(d, sg, cm) : (PLAIN ? nullptr : reinterpret_cast<const float *>(d.PE + rowOf(d, s, k - 1, cm)) + 2);
+		const int eprevStride = (k == 0) ? 1 : 4;
 		const float2 *inPrevHop = (PLAIN && k > 0) ? inputRow(d, hp, s, sg, cm) : nullptr;
 		const float2 zero = make_float2(0.f, 0.f);
 		A = cmulc(Pcm, lerpBand(in, lerpIndex(mp.x - tfUp), M));
 		B = cmulc(Pcm, lerpBand(in, lerpIndex(mp.x - L*tfUp), M));
-		Cc = twistAt<CH, PLAIN>(src, cm, b + 1, mp1, rotate, in, pv, EprevRow, inPrevHop, tfDn, 1.0f);
-		Dc = twistAt<CH, PLAIN>(src, cm, b + L, mpL, rotate, in, pv, EprevRow, inPrevHop, tfDn, float(L));
+		Cc = twistAt<CH, PLAIN>(src, cm, b + 1, mp1, rotate, in, pv, EprevRow, eprevStride, inPrevHop, tfDn, 1.0f);
+		Dc = twistAt<CH, PLAIN>(src, cm, b + L, mpL, rotate, in, pv, EprevRow, eprevStride, inPrevHop, tfDn, float(L));
 		if (!(b > 0)) A = zero;      // :748
 		if (!(b >= L)) B = zero;     // :756
 		if (!(b < M - 1)) Cc = zero; // :765
@@ -2031,7 +2038,7 @@ __global__ __launch_bounds__(256) void kCarryFeed(DevBatch d, int sBase, int hop
 	{
 		const HopDesc hl = d.hops[(size_t)sg*d.hopStride + hopBase + nh - 1];
 		const bool plain = !(hl.flags & (HOP_MAPPED | HOP_FORMANTS));
-		d.stEnergy[stateRow(d, sg, c) + b] = plain ? cnorm(inputRow(d, hl, s, sg, c)[b]) : d.E[rowOf(d, s, nh - 1, c) + b];
+		d.stEnergy[stateRow(d, sg, c) + b] = plain ? cnorm(inputRow(d, hl, s, sg, c)[b]) : d.PE[rowOf(d, s, nh - 1, c) + b].z;
 	}
 	if (anyFormants && b == 0 && c == 0) { // a serial walk over the tile's hops: skipped for tiles without formant processing
 		float w = d.stFreq[2*sg], wt = d.stFreq[2*sg + 1];

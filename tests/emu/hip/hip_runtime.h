@@ -80,6 +80,7 @@ static inline int atomicAdd(int *p, int v) { int o = *p; *p = o + v; return o; }
 #define __hip_atomic_store(p, v, order, scope) (*(volatile int *)(p) = (v))
 #define __hip_atomic_fetch_add(p, v, order, scope) atomicAdd((p), (v))
 static inline hipError_t hipStreamDestroy(hipStream_t) { return 0; }
+static inline hipError_t hipMemGetInfo(size_t *freeB, size_t *totalB) { *freeB = *totalB = (size_t)24 << 30; return 0; }
 static inline hipError_t hipMalloc(void **p, size_t n) { *p = std::calloc(n ? n : 1, 1); return *p ? 0 : 2; }
 static inline hipError_t hipFree(void *p) { std::free(p); return 0; }
 static inline hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind) { std::memcpy(d, s, n); return 0; }
