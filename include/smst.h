@@ -150,6 +150,14 @@ int smst_batch_take_timings(smst_batch *b, double ms[8], long long launches[6]);
  * (interleaved re,im: 2*channels*bands floats), 3 Prediction.energy (channels*bands floats). */
 int smst_batch_debug_get_state(smst_batch *b, int stream, int which, float *dst);
 int smst_batch_debug_get_carry(smst_batch *b, int stream, float *sums, float *products);
+/* teacher forcing (SURVEY.md App. D.2 i): overwrite one stream's carried per-bin state (same selectors / layouts as
+ * the getters) or its overlap-add carry ([channels][block+interval] sums, [block+interval] window products, index 0 =
+ * the next output sample).  The batch is synchronised first. */
+int smst_batch_debug_set_state(smst_batch *b, int stream, int which, const float *src);
+int smst_batch_debug_set_carry(smst_batch *b, int stream, const float *sums, const float *products);
+/* output map of the stream's newest hop (2*bands floats: inputBin, freqGrad per bin; signalsmith-stretch.h:587-590,
+ * :882-917).  Returns 1 if that hop had a frequency map, 0 if not (dst untouched), negative on error. */
+int smst_batch_debug_get_map(smst_batch *b, int stream, float *dst);
 
 #ifdef __cplusplus
 }

@@ -122,6 +122,30 @@ void smst_ref_get_bands(void *h, int which, float *dst) {
 		}
 	}
 }
+// teacher forcing between two checker instances (one-hop conditioning measurements): overwrite the per-bin state
+void smst_ref_set_bands(void *h, int which, const float *src) {
+	int n = S.channels*S.bands;
+	for (int i = 0; i < n; ++i) {
+		auto &b = S.channelBands[i];
+		switch (which) {
+		case 0: b.input = {src[2*i], src[2*i + 1]}; break;
+		case 1: b.prevInput = {src[2*i], src[2*i + 1]}; break;
+		case 2: b.output = {src[2*i], src[2*i + 1]}; break;
+		case 3: b.inputEnergy = src[i]; break;
+		case 4: S.channelPredictions[i].energy = src[i]; break;
+		}
+	}
+}
+void smst_ref_set_output_ring(void *h, const float *sums, const float *products) {
+	int B = S.blockSamples();
+	for (int c = 0; c < S.channels; ++c) {
+		for (int i = 0; i < B; ++i) {
+			size_t i2 = (S.stft.output.pos + i)%B;
+			S.stft.output.buffer[i2 + size_t(c)*B] = sums[c*B + i];
+			if (c == 0) S.stft.output.windowProducts[i2] = products[i];
+		}
+	}
+}
 void smst_ref_get_output_map(void *h, float *dst) {
 	for (int b = 0; b < S.bands; ++b) {
 		dst[2*b] = S.outputMap[b].inputBin;

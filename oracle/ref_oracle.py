@@ -37,6 +37,7 @@ def lib():
             smst_ref_flush=[_fp, C.c_long, C.c_int, C.c_float],
             smst_ref_get_bands=[C.c_int, _fp], smst_ref_get_output_map=[_fp], smst_ref_get_window=[_fp],
             smst_ref_get_output_ring=[_fp, _fp], smst_ref_analyse_block=[_fp, _fp],
+            smst_ref_set_bands=[C.c_int, _fp], smst_ref_set_output_ring=[_fp, _fp],
         ).items():
             f = getattr(L, name)
             f.restype = None
@@ -139,6 +140,26 @@ class RefStretch:
         a = np.zeros((self.channels, self.bands()), np.float32)
         self.L.smst_ref_get_bands(self.h, which, _p(a))
         return a
+
+    def set_bands(self, which, values):
+        if which in (3, 4):
+            a = np.ascontiguousarray(np.asarray(values, np.float32).reshape(self.channels, self.bands()))
+        else:
+            v = np.asarray(values).reshape(self.channels, self.bands())
+            a = np.ascontiguousarray(np.stack([v.real, v.imag], axis=-1).astype(np.float32))
+        self.L.smst_ref_set_bands(self.h, which, _p(a))
+
+    def set_output_ring(self, sums, products):
+        s = np.ascontiguousarray(sums, np.float32)
+        p = np.ascontiguousarray(products, np.float32)
+        self.L.smst_ref_set_output_ring(self.h, _p(s), _p(p))
+
+    def copy_state_from(self, other):
+        """Teacher forcing between two checker instances: per-bin state and overlap-add ring := other's."""
+        for which in (0, 1, 2):
+            self.set_bands(which, other.bands_complex(which))
+        self.set_bands(4, other.bands_real(4))
+        self.set_output_ring(*other.output_ring())
 
     def output_map(self):
         a = np.zeros((self.bands(), 2), np.float32)

@@ -86,6 +86,9 @@ _SIGNATURES = {
     "smst_batch_take_timings": (C.c_int, [C.c_void_p, _dp, C.POINTER(_ll)]),
     "smst_batch_debug_get_state": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _fp]),
     "smst_batch_debug_get_carry": (C.c_int, [C.c_void_p, C.c_int, _fp, _fp]),
+    "smst_batch_debug_set_state": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _fp]),
+    "smst_batch_debug_set_carry": (C.c_int, [C.c_void_p, C.c_int, _fp, _fp]),
+    "smst_batch_debug_get_map": (C.c_int, [C.c_void_p, C.c_int, _fp]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 
@@ -318,6 +321,30 @@ class StretchBatch:
         a = np.zeros((Cn, M, 2), np.float32)
         _check(self.lib, self.lib.smst_batch_debug_get_state(self.h, stream, which, a.ctypes.data_as(_fp)))
         return a[..., 0] + 1j*a[..., 1]
+
+    def debug_set_state(self, stream, which, values):
+        """Teacher forcing: overwrite Band.input / .prevInput / .output (complex [C, M]) or Prediction.energy ([C, M])."""
+        Cn, M = self.channels, self.bands()
+        if which == 3:
+            a = np.ascontiguousarray(np.asarray(values, np.float32).reshape(Cn, M))
+        else:
+            v = np.asarray(values).reshape(Cn, M)
+            a = np.ascontiguousarray(np.stack([v.real, v.imag], axis=-1).astype(np.float32))
+        _check(self.lib, self.lib.smst_batch_debug_set_state(self.h, stream, which, a.ctypes.data_as(_fp)))
+
+    def debug_set_carry(self, stream, sums, products):
+        n = self.blockSamples() + self.intervalSamples()
+        s = np.ascontiguousarray(np.asarray(sums, np.float32).reshape(self.channels, n))
+        p = np.ascontiguousarray(np.asarray(products, np.float32).reshape(n))
+        _check(self.lib, self.lib.smst_batch_debug_set_carry(self.h, stream, s.ctypes.data_as(_fp), p.ctypes.data_as(_fp)))
+
+    def debug_map(self, stream):
+        """(inputBin, freqGrad) per bin of the stream's newest hop, or None if that hop had no frequency map."""
+        a = np.zeros((self.bands(), 2), np.float32)
+        rc = self.lib.smst_batch_debug_get_map(self.h, stream, a.ctypes.data_as(_fp))
+        if rc < 0:
+            _check(self.lib, rc)
+        return a if rc == 1 else None
 
     def debug_carry(self, stream):
         n = self.blockSamples() + self.intervalSamples()

@@ -127,6 +127,14 @@ int smst_batch_take_timings(smst_batch *b, double ms[8], long long launches[6]) 
 }
 int smst_batch_debug_get_state(smst_batch *b, int stream, int which, float *dst) { BATCH_CALL(b->engine->debugGetState(stream, which, dst)) }
 int smst_batch_debug_get_carry(smst_batch *b, int stream, float *sums, float *products) { BATCH_CALL(b->engine->debugGetCarry(stream, sums, products)) }
+int smst_batch_debug_set_state(smst_batch *b, int stream, int which, const float *src) { BATCH_CALL(b->engine->debugSetState(stream, which, src)) }
+int smst_batch_debug_set_carry(smst_batch *b, int stream, const float *sums, const float *products) { BATCH_CALL(b->engine->debugSetCarry(stream, sums, products)) }
+int smst_batch_debug_get_map(smst_batch *b, int stream, float *dst) {
+	if (!b || !b->engine) return fail("null batch");
+	SMST_TRY
+	return b->engine->debugGetMap(stream, dst) ? 1 : 0;
+	SMST_CATCH
+}
 
 // host staging: copy the strided host planes into a dense device image [S][C][maxLen]
 static const float *stageIn(smst_batch *b, const float *in, long long ss, long long cs, const int *n, int &maxLen) {

@@ -249,6 +249,7 @@ Batch::Batch(int streams, int channels, int block, int interval, bool splitCompu
 	dAux1 = devAlloc<int>(S);
 
 	sched.assign(S, StreamSched());
+	lastHop.assign(S, LastHop());
 	for (int s = 0; s < S; ++s) sched[s].seed = unsigned(seed)*2654435761u + unsigned(s)*40503u + 12345u;
 	StreamParams p{};
 	p.freqMultiplier = 1; p.freqTonalityLimit = 0.5f; // :513
@@ -626,6 +627,13 @@ void Batch::process(const float *in, long long inSS, long long inCS, const int *
 				if (list[h].flags & HOP_RANDOM_TF) th[4] = 1;
 			}
 			info[subS + sl] = lastNewLocal;
+			if (cnt > 0) {
+				LastHop &lh = lastHop[s];
+				lh.slot = (sub*nTiles + t) & 1;
+				lh.local = cnt - 1;
+				lh.subLocal = sl;
+				lh.mapped = (list[h1 - 1].flags & HOP_MAPPED) != 0;
+			}
 			maxSpan[(size_t)sub*nTiles + t] = std::max(maxSpan[(size_t)sub*nTiles + t], ed.nHi - ed.nLo);
 		}
 	}
@@ -908,6 +916,34 @@ void Batch::debugGetState(int stream, int which, float *dst) {
 	}
 	const float2 *src = which == 0 ? d.stInput : (which == 1 ? d.stPrev : d.stOut);
 	SMST_HIP(hipMemcpy(dst, src + off, (size_t)C*M*sizeof(float2), hipMemcpyDeviceToHost));
+}
+void Batch::debugSetState(int stream, int which, const float *src) {
+	if (stream < 0 || stream >= S || which < 0 || which > 3) throw Error("debugSetState: bad stream / selector");
+	SMST_HIP(hipSetDevice(dev));
+	SMST_HIP(hipStreamSynchronize(st));
+	const size_t off = (size_t)stream*C*M;
+	if (which == 3) {
+		SMST_HIP(hipMemcpy(d.stEnergy + off, src, (size_t)C*M*sizeof(float), hipMemcpyHostToDevice));
+		return;
+	}
+	float2 *dst = which == 0 ? d.stInput : (which == 1 ? d.stPrev : d.stOut);
+	SMST_HIP(hipMemcpy(dst + off, src, (size_t)C*M*sizeof(float2), hipMemcpyHostToDevice));
+}
+void Batch::debugSetCarry(int stream, const float *sums, const float *products) {
+	if (stream < 0 || stream >= S) throw Error("debugSetCarry: bad stream");
+	SMST_HIP(hipSetDevice(dev));
+	SMST_HIP(hipStreamSynchronize(st));
+	SMST_HIP(hipMemcpy(d.carrySum[d.carryCur] + (size_t)stream*C*d.carryLen, sums, (size_t)C*d.carryLen*sizeof(float), hipMemcpyHostToDevice));
+	SMST_HIP(hipMemcpy(d.carryWp[d.carryCur] + (size_t)stream*d.carryLen, products, (size_t)d.carryLen*sizeof(float), hipMemcpyHostToDevice));
+}
+bool Batch::debugGetMap(int stream, float *dst) {
+	if (stream < 0 || stream >= S) throw Error("debugGetMap: bad stream");
+	const LastHop &lh = lastHop[stream];
+	if (lh.slot < 0 || !lh.mapped) return false;
+	SMST_HIP(hipSetDevice(dev));
+	SMST_HIP(hipStreamSynchronize(st));
+	SMST_HIP(hipMemcpy(dst, slots[lh.slot].map + ((size_t)lh.subLocal*d.T + lh.local)*M, (size_t)M*sizeof(float2), hipMemcpyDeviceToHost));
+	return true;
 }
 void Batch::debugGetCarry(int stream, float *sums, float *products) {
 	SMST_HIP(hipSetDevice(dev));

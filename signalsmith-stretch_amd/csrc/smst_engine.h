@@ -79,6 +79,12 @@ public:
 	// test hooks: copy state rows to the host (which: 0 input, 1 prevInput, 2 output -> 2*C*M floats; 3 energy -> C*M)
 	void debugGetState(int stream, int which, float *dst);
 	void debugGetCarry(int stream, float *sums, float *products); // [C][B+I], [B+I]
+	// teacher-forcing hooks (tests only): overwrite the carried per-bin state / overlap-add carry of one stream
+	void debugSetState(int stream, int which, const float *src);
+	void debugSetCarry(int stream, const float *sums, const float *products);
+	// output map (inputBin, freqGrad per bin, signalsmith-stretch.h:587-590) of the stream's last hop of the last process()
+	// call; false if that hop had no frequency map
+	bool debugGetMap(int stream, float *dst);
 
 private:
 	int S, C, B, I, N, M, L;
@@ -98,6 +104,8 @@ private:
 	size_t wsBytes = 0;
 	DevBatch d{};
 	std::vector<StreamSched> sched;
+	struct LastHop { int slot = -1, local = -1, subLocal = 0; bool mapped = false; };
+	std::vector<LastHop> lastHop; // where each stream's newest hop sits in the tile workspaces (debugGetMap)
 	std::vector<StreamParams> params;
 	bool paramsDirty = true;
 	bool profiling = false, liveTiming = false;

@@ -4,13 +4,24 @@ Every case drives the product through its C ABI (python ctypes mirror of the ref
 
 TOLERANCE (stated here once).  The whole path is fp32 and the phase recurrence is chaotic (a 1e-7
 relative perturbation of the INPUT changes the reference's own output by 1e-5..1e-2 within 16 hops, more for noise
-and for pitch-mapped material where peak decisions flip).  So the bound is conditioning-aware, as App. D.2 prescribes:
-over every horizon h in HORIZONS (hops), rel-RMS(product, checker) <= max(FLOOR, SELF_FACTOR * max over 3 seeds of
-rel-RMS(checker on the input perturbed by PERTURBATION = 1e-6 relative, checker)).  1e-6 (~8 ulp) is the measured
-rel-RMS difference between our FFT and the reference's on the identity path (test_full_batch_identity: 1.6e-6), i.e.
-the input-equivalent size of "same algorithm, different fp32 rounding".  FLOOR = 1e-4 covers the fp32 rounding differences of a different FFT
-factorisation / FMA contraction when the self-sensitivity is tiny; cases with no phase-vocoder feedback (1.0x
-identity, ring bookkeeping) use TOL_EXACT = 2e-6 instead."""
+and for pitch-mapped material where peak decisions flip).  Three kinds of comparison, as App. D.2 prescribes:
+
+ (a) sample domain, free running (`assert_parity`): over every horizon h in HORIZONS (hops),
+     rel-RMS(product, checker) <= max(FLOOR, SELF_FACTOR * S_h),  S_h = max over 3 seeds of
+     rel-RMS(checker(x*(1 + PERTURBATION*u)), checker(x)) over the same horizon -- and the bound is CAPPED at `cap`
+     (CAP_TONAL 5e-3; CAP_FORMANT 5e-2 with formant processing, D.2 iii): it never exceeds the cap, and once
+     SELF_FACTOR * (MEDIAN over the seeds) exceeds the cap the horizon is chaos-dominated (most perturbed runs of the
+     checker itself have diverged), a sample-domain bound would assert nothing, and the comparison stops there (at
+     least the first horizon must have been checked).  The median, not the maximum, decides that: a single perturbed
+     run in which a discrete decision flipped (peak list, arg-max channel) does not switch the comparison off.  PERTURBATION = 1e-6 is NOT a free choice: it is the input-equivalent size of the
+     arithmetic difference between the two implementations, measured by `case_teacher_forced` (the product's analysis
+     spectra differ from the checker's by e rel-RMS; an input perturbation p moves them by p/sqrt(3)) and asserted there
+     (test_teacher_forced_*: sqrt(3)*e <= PERTURBATION).
+ (b) teacher-forced single hops (`case_teacher_forced`, D.2 i): product state := checker state, ONE hop, spectra and
+     emitted samples <= 1e-5 -- no chaos amplification, a plain fp32 bound.
+ (c) phase-free quantities, free running over long horizons (`case_hop_magnitudes`, D.2 iv/v): per-hop |output_c[b]|
+     <= 1e-4 rel-RMS, arg-max-channel and output-map agreement rates, output RMS within 1 %.
+Cases without phase-vocoder feedback (1.0x identity, ring bookkeeping) use TOL_EXACT = 2e-6."""
 import numpy as np
 
 from conftest import package, rel_rms, synth_input
@@ -19,9 +30,11 @@ import scenarios
 TOL_EXACT = 2e-6
 FLOOR = 1e-4
 SELF_FACTOR = 5.0
-PERTURBATION = 1e-6  # ~8 ulp: the size of the rounding difference between two fp32 FFT implementations of this length
-HORIZONS = (6, 12, 24, 48, 1 << 30)
+PERTURBATION = 1e-6  # input-equivalent size of the two implementations' arithmetic difference (measured: see above)
+HORIZONS = (3, 6, 12, 24, 48, 96, 192, 1 << 30)
 SELF_SEEDS = (1, 2, 3)
+CAP_TONAL = 5e-3    # D.2 (iii): stretch-only / pitch-only
+CAP_FORMANT = 5e-2  # D.2 (iii): with formant processing
 
 
 def make(kind, lib, ref, channels, cfg, setup=None, seed=0):
@@ -37,29 +50,39 @@ def perturbed(x, seed=1):
     return (x*(1 + PERTURBATION*u)).astype(np.float32)
 
 
-def assert_parity(y, o, o_self, interval, label):
-    """o_self: one array or a list of arrays = checker outputs for differently perturbed inputs (max is used)."""
+def assert_parity(y, o, o_self, interval, label, cap=CAP_TONAL):
+    """o_self: one array or a list of arrays = checker outputs for differently perturbed inputs (max is used).
+    Returns the number of hops up to which the sample-domain comparison was informative (and was asserted)."""
     assert y.shape == o.shape, (label, y.shape, o.shape)
     selfs = o_self if isinstance(o_self, (list, tuple)) else [o_self]
     total = o.shape[1]
+    checked = 0
     for h in HORIZONS:
         n = min(total, h*interval)
         if n <= 0:
             continue
-        err, own = rel_rms(y[:, :n], o[:, :n]), max(rel_rms(v[:, :n], o[:, :n]) for v in selfs)
-        tol = max(FLOOR, SELF_FACTOR*own)
+        if np.mean(np.square(o[:, :n], dtype=np.float64))*n < 1e-6*np.mean(np.square(o, dtype=np.float64))*total:
+            continue  # the checker's own output is still (numerically) silent over this horizon: nothing to compare
+        owns = sorted(rel_rms(v[:, :n], o[:, :n]) for v in selfs)
+        err, own, typical = rel_rms(y[:, :n], o[:, :n]), owns[-1], owns[len(owns)//2]
+        if SELF_FACTOR*typical > cap:  # chaos-dominated from here on: the phase-free checks take over (case_hop_magnitudes)
+            break
+        tol = min(cap, max(FLOOR, SELF_FACTOR*own))
         assert err <= tol, "%s: horizon %d hops: rel-RMS %.3e > %.3e (checker self-sensitivity %.3e)" % (label, min(h, total//interval), err, tol, own)
+        checked = min(h, -(-total//interval))
         if n == total:
             break
+    assert checked > 0, "%s: not even the first horizon is informative (self-sensitivity above the cap)" % label
+    return checked
 
 
-def check_scenario(lib, ref, cfg, x, play, label, setup=None):
+def check_scenario(lib, ref, cfg, x, play, label, setup=None, cap=CAP_TONAL):
     """play(obj, x) -> concatenated output; run on the product, the checker, and the checker with perturbed input."""
     C = x.shape[0]
     g, r = make("product", lib, ref, C, cfg, setup), make("ref", lib, ref, C, cfg, setup)
     y, o = play(g, x), play(r, x)
     o2 = [play(make("ref", lib, ref, C, cfg, setup), perturbed(x, seed)) for seed in SELF_SEEDS]
-    assert_parity(y, o, o2, r.intervalSamples(), label)
+    assert_parity(y, o, o2, r.intervalSamples(), label, cap=cap)
     return y, o
 
 
@@ -168,7 +191,8 @@ def case_pitch_and_formants(lib, ref, cfg=SMALL, n=9000):
         ("freq-map-table", lambda o: o.setFreqMapTable(np.array([(i + 0.5)/128*1.5 for i in range(64)], np.float32)), 1.0),
     ]
     for label, setup, stretch in settings:
-        check_scenario(lib, ref, cfg, x, lambda o, xx, stretch=stretch: o.process(xx, int(n*stretch)), label, setup=setup)
+        check_scenario(lib, ref, cfg, x, lambda o, xx, stretch=stretch: o.process(xx, int(n*stretch)), label, setup=setup,
+                       cap=CAP_FORMANT if label.startswith("formant") else CAP_TONAL)
 
 
 def case_silence(lib, ref):
@@ -280,3 +304,147 @@ def case_cmd_main_flow(lib, ref, sr=44100, seconds=1.5, time_factor=1.0, semiton
         tail = 2*head
         assert rel_rms(y[:, head:-tail], x[:, head:y.shape[1] - tail]) < 5e-6
         assert rel_rms(o[:, head:-tail], x[:, head:o.shape[1] - tail]) < 5e-6
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Chaos-free parity instruments (SURVEY.md App. D.2 i, iv, v): teacher-forced single hop, per-hop magnitude spectra,
+# discrete-decision agreement.  They use the state hooks of both sides (smst_batch_debug_* / smst_ref_get_*).
+# ---------------------------------------------------------------------------------------------------------------
+TOL_FORCED_SPECTRUM = 1e-5   # rel-RMS of Band.output after ONE hop from injected checker state (D.2 i)
+TOL_FORCED_SAMPLES = 1e-5    # rel-RMS of the interval of samples that hop emits
+TOL_MAGNITUDE = 1e-4         # per-hop rel-RMS of |output_c[b]| (phase-free, = sqrt(Prediction.energy), stretch.h:596-603)
+
+
+def _crel(a, b):
+    """rel-RMS distance of two complex arrays."""
+    a, b = np.asarray(a, np.complex128), np.asarray(b, np.complex128)
+    return float(np.sqrt(np.mean(np.abs(a - b)**2)/max(np.mean(np.abs(b)**2), 1e-300)))
+
+
+def _crel_trimmed(a, b, drop=0.01):
+    """rel-RMS distance after dropping the `drop` fraction of bins with the largest error: with a frequency map a few
+    near-silent bins have an ill-conditioned phase (four tiny prediction terms that nearly cancel), and one ulp of the
+    map's inputBin turns them around; they carry no energy but dominate an untrimmed spectrum distance."""
+    a, b = np.asarray(a, np.complex128).ravel(), np.asarray(b, np.complex128).ravel()
+    d = np.sort(np.abs(a - b)**2)
+    keep = d[:max(1, int(round(len(d)*(1 - drop))))]
+    return float(np.sqrt(np.sum(keep)/max(np.sum(np.abs(b)**2), 1e-300)))
+
+
+def _hop_io(interval, stretch, k):
+    """Input range consumed by hop-aligned call number k (each call emits exactly one interval)."""
+    lo = int(round(k*interval/stretch))
+    hi = int(round((k + 1)*interval/stretch))
+    return lo, hi
+
+
+def _inject(batch, stream, r):
+    """Product state := checker state (Band.input/.prevInput/.output, Prediction.energy, overlap-add ring)."""
+    B, I = r.blockSamples(), r.intervalSamples()
+    batch.debug_set_state(stream, 0, r.bands_complex(0))
+    batch.debug_set_state(stream, 1, r.bands_complex(1))
+    batch.debug_set_state(stream, 2, r.bands_complex(2))
+    batch.debug_set_state(stream, 3, r.bands_real(4))
+    sums, prods = r.output_ring()  # from the read position: index 0 = the next output sample
+    cs = np.zeros((r.channels, B + I), np.float32)
+    cp = np.full(B + I, 1e-30, np.float32)
+    cs[:, :B] = sums
+    cp[:B] = prods
+    batch.debug_set_carry(stream, cs, cp)
+
+
+def case_teacher_forced(lib, ref, cfg, channels, stretch, label, setup=None, warm_hops=9, forced_hops=3, streams=(0, 1, 2)):
+    """D.2 (i): run `warm_hops` hops on both sides, then `forced_hops` times: overwrite the product's carried state with
+    the checker's, run ONE hop on both, compare the emitted interval and Band.output.  Every compared hop starts from
+    identical state, so nothing is amplified over time -- but one hop still has a condition number: with a frequency
+    map, the rounding noise of the analysis (a few 1e-7 of the spectrum's norm) moves the peak centroids of low-energy
+    regions and with them the phase advance of whole groups of bins.  So the bound is
+        max(TOL_FORCED_*, SELF_FACTOR * the CHECKER'S OWN one-hop sensitivity),
+    where the latter is measured with a second checker instance that has seen the input perturbed by PERTURBATION
+    throughout and is forced to the first one's state before each compared hop.  Returns the worst figures."""
+    pkg = package()
+    sr = int(cfg.get("sample_rate", 48000))
+    S = len(streams)
+    kw = dict(preset=cfg["preset"], sample_rate=cfg.get("sample_rate", 48000.0)) if cfg.get("preset") in ("default", "cheaper") else \
+        dict(block=cfg["block"], interval=cfg["interval"], split=cfg.get("split", False))
+    b = pkg.StretchBatch(S, channels, lib=lib, **kw)
+    refs = [make("ref", lib, ref, channels, cfg, setup) for _ in streams]
+    twins = [make("ref", lib, ref, channels, cfg, setup) for _ in streams]  # the perturbed-input checkers
+    if setup:
+        setup(b)
+    I = b.intervalSamples()
+    total_hops = warm_hops + forced_hops
+    n_in = _hop_io(I, stretch, total_hops)[1] + 8
+    xs = np.stack([synth_input(s, channels, n_in, sr) for s in streams])
+    xp = np.stack([perturbed(x, 1 + i) for i, x in enumerate(xs)])
+    worst = dict(spectrum=0.0, spectrum_self=0.0, spectrum_trimmed=0.0, samples=0.0, samples_self=0.0, analysis=0.0, analysis_self=0.0)
+    for k in range(total_hops):
+        lo, hi = _hop_io(I, stretch, k)
+        forced = k >= warm_hops
+        if forced:
+            for i, r in enumerate(refs):
+                _inject(b, i, r)
+                twins[i].copy_state_from(r)
+        y = b.process(xs[:, :, lo:hi] if hi > lo else np.zeros((S, channels, 1), np.float32), I, in_samples=hi - lo)
+        outs = [r.process(xs[i][:, lo:hi], I) for i, r in enumerate(refs)]
+        outs_p = [t.process(xp[i][:, lo:hi], I) for i, t in enumerate(twins)]
+        if forced:
+            for i, r in enumerate(refs):
+                ro = r.bands_complex(2)
+                s_samp, s_spec = rel_rms(outs_p[i], outs[i]), _crel(twins[i].bands_complex(2), ro)
+                e_samp, e_spec, e_trim = rel_rms(y[i], outs[i]), _crel(b.debug_state(i, 2), ro), _crel_trimmed(b.debug_state(i, 2), ro)
+                e_ana, s_ana = _crel(b.debug_state(i, 0), r.bands_complex(0)), _crel(twins[i].bands_complex(0), r.bands_complex(0))
+                for key, v in (("samples", e_samp), ("samples_self", s_samp), ("spectrum", e_spec), ("spectrum_self", s_spec),
+                               ("spectrum_trimmed", e_trim), ("analysis", e_ana), ("analysis_self", s_ana)):
+                    worst[key] = max(worst[key], v)
+                tol_samp, tol_spec = max(TOL_FORCED_SAMPLES, SELF_FACTOR*s_samp), max(TOL_FORCED_SPECTRUM, SELF_FACTOR*s_spec)
+                assert e_samp <= tol_samp, "%s: stream %d hop %d: emitted samples rel-RMS %.3e > %.1e (checker's one-hop sensitivity %.1e)" % (label, streams[i], k, e_samp, tol_samp, s_samp)
+                assert e_spec <= tol_spec, "%s: stream %d hop %d: Band.output rel-RMS %.3e > %.1e (checker's one-hop sensitivity %.1e)" % (label, streams[i], k, e_spec, tol_spec, s_spec)
+    b.close()
+    return worst
+
+
+def case_hop_magnitudes(lib, ref, cfg, channels, stretch, label, setup=None, hops=40, streams=(2, 5), tol=TOL_MAGNITUDE,
+                        min_argmax_agreement=0.999, min_map_agreement=0.98):
+    """D.2 (iv) + (v), free-running (no state injection): after every hop compare the phase-free quantities, which stay
+    comparable after the phases have decorrelated (noise streams): |Band.output| per bin (= sqrt(Prediction.energy) by
+    stretch.h:596-603), the arg-max channel per bin derived from Prediction.energy (:729-737), and -- with a frequency
+    map -- the output map the peak list produces (:859-917).  Returns the rates it measured."""
+    pkg = package()
+    sr = int(cfg.get("sample_rate", 48000))
+    S = len(streams)
+    kw = dict(preset=cfg["preset"], sample_rate=cfg.get("sample_rate", 48000.0)) if cfg.get("preset") in ("default", "cheaper") else \
+        dict(block=cfg["block"], interval=cfg["interval"], split=cfg.get("split", False))
+    b = pkg.StretchBatch(S, channels, lib=lib, **kw)
+    refs = [make("ref", lib, ref, channels, cfg, setup) for _ in streams]
+    if setup:
+        setup(b)
+    I = b.intervalSamples()
+    n_in = _hop_io(I, stretch, hops)[1] + 8
+    xs = np.stack([synth_input(s, channels, n_in, sr) for s in streams])
+    worst_mag, agree, cells, map_ok, map_cells = 0.0, 0, 0, 0, 0
+    for k in range(hops):
+        lo, hi = _hop_io(I, stretch, k)
+        b.process(xs[:, :, lo:hi] if hi > lo else np.zeros((S, channels, 1), np.float32), I, in_samples=hi - lo)
+        for i, r in enumerate(refs):
+            r.process(xs[i][:, lo:hi], I)
+            mo, mr = np.abs(b.debug_state(i, 2)), np.abs(r.bands_complex(2))
+            if k >= 4:  # the first hops ramp up from the zero state: |output| is tiny and dominated by the window edge
+                e = rel_rms(mo, mr)
+                worst_mag = max(worst_mag, e)
+                assert e <= tol, "%s: stream %d hop %d: |output| rel-RMS %.3e > %.1e" % (label, streams[i], k, e, tol)
+            if channels > 1:
+                eo, er = b.debug_state(i, 3), r.bands_real(4)
+                loud = er.max(axis=0) > 1e-12*max(float(er.max()), 1e-30)  # ties between silent channels are not decisions
+                agree += int(np.sum((np.argmax(eo, axis=0) == np.argmax(er, axis=0)) & loud))
+                cells += int(np.sum(loud))
+            m = b.debug_map(i)
+            if m is not None:
+                mr2 = r.output_map()
+                map_ok += int(np.sum(np.abs(m[:, 0] - mr2[:, 0]) <= 1e-3*np.maximum(1.0, np.abs(mr2[:, 0]))))
+                map_cells += m.shape[0]
+    b.close()
+    rates = dict(magnitude=worst_mag, argmax=(agree/cells if cells else 1.0), map=(map_ok/map_cells if map_cells else 1.0))
+    assert rates["argmax"] >= min_argmax_agreement, (label, rates)
+    assert rates["map"] >= min_map_agreement, (label, rates)
+    return rates

@@ -50,3 +50,17 @@ def test_cmd_main_flow_config1(emu, ref):
 
 def test_realtime_quanta(emu, ref):
     pc.case_realtime_quanta(emu, ref)
+
+
+def test_teacher_forced_small(emu, ref):
+    """Teacher-forced single hops (SURVEY App. D.2 i) at the small geometry: plain, pitch-mapped, formants, 3 channels."""
+    print(pc.case_teacher_forced(emu, ref, pc.SMALL, 2, 1.5, "forced plain"))
+    print(pc.case_teacher_forced(emu, ref, pc.SMALL, 2, 1.0, "forced pitch", setup=lambda o: o.setTransposeSemitones(12, 8000/48000)))
+    print(pc.case_teacher_forced(emu, ref, pc.SMALL, 2, 0.75, "forced formants",
+                                 setup=lambda o: (o.setTransposeSemitones(4, 8000/48000), o.setFormantFactor(1, True), o.setFormantBase(200/48000))))
+    print(pc.case_teacher_forced(emu, ref, pc.SMALL_SPLIT, 3, 1.2, "forced split 3ch", setup=lambda o: o.setTransposeSemitones(-5, 0)))
+
+
+def test_hop_magnitudes_small(emu, ref):
+    print(pc.case_hop_magnitudes(emu, ref, pc.SMALL, 2, 1.5, "magnitudes plain", hops=24))
+    print(pc.case_hop_magnitudes(emu, ref, pc.SMALL, 2, 1.0, "magnitudes pitch", hops=24, setup=lambda o: o.setTransposeSemitones(12, 8000/48000)))
