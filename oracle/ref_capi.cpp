@@ -146,6 +146,11 @@ void smst_ref_set_output_ring(void *h, const float *sums, const float *products)
 		}
 	}
 }
+// formant envelope (bands + 2 entries) and the pitch estimate it was built with (signalsmith-stretch.h:968-1006)
+float smst_ref_get_formant_metric(void *h, float *dst) {
+	std::copy(S.formantMetric.begin(), S.formantMetric.end(), dst);
+	return S.freqEstimate;
+}
 void smst_ref_get_output_map(void *h, float *dst) {
 	for (int b = 0; b < S.bands; ++b) {
 		dst[2*b] = S.outputMap[b].inputBin;

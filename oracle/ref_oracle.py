@@ -11,7 +11,10 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "_ref", "libsmst_ref.so")
-_lib = None
+# the formant-envelope revision of the shipped WASM build (oracle/Makefile, target wasmrev): explains the WASM fixtures under
+# tests/golden/wasm_revision/, never checks the product
+WASMREV_LIB_PATH = os.path.join(_HERE, "_ref", "libsmst_ref_wasmrev.so")
+_libs = {}
 _fp = C.POINTER(C.c_float)
 
 
@@ -19,10 +22,10 @@ def available():
     return os.path.exists(LIB_PATH)
 
 
-def lib():
-    global _lib
-    if _lib is None:
-        L = C.CDLL(LIB_PATH)
+def lib(path=None):
+    path = path or LIB_PATH
+    if path not in _libs:
+        L = C.CDLL(path)
         L.smst_ref_create.restype = C.c_void_p
         L.smst_ref_create.argtypes = [C.c_long]
         for name, args in dict(
@@ -50,8 +53,10 @@ def lib():
             f = getattr(L, name)
             f.restype = C.c_int
             f.argtypes = [C.c_void_p] + args
-        _lib = L
-    return _lib
+        L.smst_ref_get_formant_metric.restype = C.c_float
+        L.smst_ref_get_formant_metric.argtypes = [C.c_void_p, _fp]
+        _libs[path] = L
+    return _libs[path]
 
 
 def _p(a):
@@ -61,8 +66,8 @@ def _p(a):
 class RefStretch:
     """Same method names as the reference class (signalsmith-stretch.h:38-491)."""
 
-    def __init__(self, seed=0):
-        self.L = lib()
+    def __init__(self, seed=0, library=None):
+        self.L = lib(library)
         self.h = self.L.smst_ref_create(seed)
         self.channels = 0
 
@@ -160,6 +165,12 @@ class RefStretch:
             self.set_bands(which, other.bands_complex(which))
         self.set_bands(4, other.bands_real(4))
         self.set_output_ring(*other.output_ring())
+
+    def formant_metric(self):
+        """(envelope[bands + 2], freqEstimate) as updateFormants left them (signalsmith-stretch.h:968-1006)."""
+        a = np.zeros(self.bands() + 2, np.float32)
+        est = self.L.smst_ref_get_formant_metric(self.h, _p(a))
+        return a, float(est)
 
     def output_map(self):
         a = np.zeros((self.bands(), 2), np.float32)

@@ -69,5 +69,6 @@ for (const op of job.ops) {
   outPos += op.outLen;
 }
 fs.writeFileSync(job.output, Buffer.from(outAll.buffer));
+if (job.dumpMemory) fs.writeFileSync(job.dumpMemory, Buffer.from(mem.buffer)); // linear memory after the last op (state probes, SURVEY.md App. B)
 info.totalOut = totalOut; info.processMs = procMs;
 console.log(JSON.stringify(info));

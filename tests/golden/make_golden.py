@@ -54,5 +54,80 @@ def main():
     case("stretch_1p5_noise", xn, [dict(op="process", inStart=0, inLen=n, outLen=int(n*1.5))])
 
 
+def formant_revision_fixtures():
+    """tests/golden/wasm_revision/: the WASM on three formant settings, plus probes of its linear memory after the last hop
+    (SURVEY.md App. B technique): the Band array (found by the content of Band.input) and formantMetric (found by
+    log-domain template matching).  The in-tree header does NOT reproduce these outputs -- the WASM was built from another
+    revision of updateFormants; tests/test_oracle_golden.py::test_formant_revision_* measure and explain the difference."""
+    import ref_oracle
+    out_dir = os.path.join(HERE, "wasm_revision")
+    os.makedirs(out_dir, exist_ok=True)
+    sr, n, M = 48000, 14400, 3072
+    x = synth_input(0, 2, n, sr) + 0.5*synth_input(1, 2, n, sr)
+    settings = {
+        "formant_comp": [dict(op="setTransposeSemitones", args=[4, 8000/48000]), dict(op="setFormantFactor", args=[1, 1]),
+                         dict(op="setFormantBase", args=[200/48000])],
+        "formant_shift": [dict(op="setFormantSemitones", args=[3, 0]), dict(op="setFormantBase", args=[200/48000])],
+        "formant_shift_auto": [dict(op="setFormantSemitones", args=[3, 0])],
+    }
+    for name, pre in settings.items():
+        ops = pre + [dict(op="process", inStart=0, inLen=n, outLen=n)]
+        y, info = wasm_oracle.run(x, ops, dump_memory=True)
+        mem = np.nan_to_num(info.pop("memory"), nan=0.0, posinf=0.0, neginf=0.0).astype(np.float64)
+        mem[np.abs(mem) > 1e12] = 0
+        # the native build (in-tree header) gives the content keys: its Band.input equals the WASM's (same L1 arithmetic)
+        r = ref_oracle.RefStretch()
+        r.presetDefault(2, float(sr))
+        scenarios_replay(r, x, ops)
+        rin = r.bands_complex(0)
+        key = rin[0, 1000:1004]
+        hits = [p for p in np.nonzero(np.abs(mem - key[0].real) <= 1e-3*abs(key[0].real))[0]
+                if all(abs(mem[p + 7*j] - key[j].real) <= 1e-3*abs(key[j].real) + 1e-6 and
+                       abs(mem[p + 7*j + 1] - key[j].imag) <= 1e-3*abs(key[j].imag) + 1e-6 for j in range(4))]
+        assert 1 <= len(hits) <= 2 and hits[-1] - hits[0] in (0, 2), hits  # (Band.prevInput == Band.input after a hop: +2 matches too)
+        bands = mem[hits[0] - 7*1000:hits[0] - 7*1000 + 7*M*2].reshape(2, M, 7).astype(np.float32)
+        # formantMetric: bands + 2 floats; template = log of the amplitude spectrum (any smooth function of it correlates)
+        lm = np.where(mem > 1e-20, np.log(np.maximum(mem, 1e-20)), -46.0)
+        t = 0.5*np.log(np.maximum((np.abs(rin)**2).sum(axis=0), 1e-20))
+        t0 = t - t.mean()
+        tails = np.nonzero((mem[M:-1] == 0) & (mem[M + 1:] == 0) & (mem[M - 1:-2] > 0))[0]
+        cand = sorted(((float(np.dot(lm[p:p + M] - lm[p:p + M].mean(), t0)/(np.linalg.norm(lm[p:p + M] - lm[p:p + M].mean())*np.linalg.norm(t0) + 1e-30)), int(p))
+                       for p in tails if np.all(mem[p:p + M] > 0)), reverse=True)
+        assert cand and cand[0][0] > 0.8, cand[:3]
+        cand = [cand[0][1]]
+        metric = mem[cand[0]:cand[0] + M + 2].astype(np.float32)
+        np.savez_compressed(os.path.join(out_dir, name + ".npz"), x=x.astype(np.float32), y=y.astype(np.float32),
+                            ops=json.dumps(ops), cfg=json.dumps({}), info=json.dumps(info), wasm_bands=bands, wasm_formant_metric=metric)
+        print(name, "->", y.shape, "Band array @", hits[0] - 7000, "formantMetric @", cand[0])
+
+
+def seek_rate_fixtures():
+    """tests/golden/wasm_revision_seek/: seek() with playbackRate != 1 followed by process() on the WASM.  The in-tree header
+    differs from it by 2e-4 (rate 0.8) .. 2e-3 (rate 1.25) from the first hop on (rate 1: 6e-7) --
+    tests/test_oracle_golden.py::test_seek_rate_revision_measured records that."""
+    out_dir = os.path.join(HERE, "wasm_revision_seek")
+    os.makedirs(out_dir, exist_ok=True)
+    sr, n = 48000, 14400
+    x = synth_input(0, 2, n, sr) + 0.5*synth_input(1, 2, n, sr)
+    for rate in (1.0, 0.8, 1.25):
+        ops = [dict(op="seek", inStart=0, inLen=7200, rate=rate), dict(op="process", inStart=7200, inLen=int(5760*rate), outLen=5760)]
+        y, info = wasm_oracle.run(x, ops)
+        name = "seek_rate_%s" % str(rate).replace(".", "p")
+        np.savez_compressed(os.path.join(out_dir, name + ".npz"), x=x.astype(np.float32), y=y.astype(np.float32),
+                            ops=json.dumps(ops), cfg=json.dumps({}), info=json.dumps(info))
+        print(name, "->", y.shape)
+
+
+def scenarios_replay(obj, x, ops):
+    import scenarios
+    return scenarios.replay(obj, x, ops)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "formants":
+        formant_revision_fixtures()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "seek":
+        seek_rate_fixtures()
+        sys.exit(0)
     main()
