@@ -83,3 +83,43 @@ def test_cli_gpu(tmp_path):
     exe = os.path.join(os.path.dirname(pkg.LIBRARY_PATH), "stretch_cli")
     assert os.path.exists(exe), "stretch_cli not built (csrc/Makefile)"
     cli_cases(exe, tmp_path)
+
+
+# ---- the reference's OWN caller through the drop-in header ------------------------------------------------------------
+# oracle/Makefile (target dropin) compiles /root/reference/cmd/main.cpp UNMODIFIED, where it lies, with -I<repo>/include, so
+# that its `#include "signalsmith-stretch/signalsmith-stretch.h"` (cmd/main.cpp:5) resolves to the product's drop-in header,
+# and links it against libsmst_hip.so.  The binary travels to the GPU box like oracle/_ref/ref_cli.
+def reference_main_cases(exe, tmp_path):
+    """cmd/main.cpp:44-82 (presetDefault, setTransposeSemitones, setFormant*, outputSeek, process, flush) executed by the
+    reference's own main() on the product, against the same main() on the reference header (oracle/_ref/ref_cli)."""
+    if not os.path.exists(REF_CLI) or not os.path.exists(exe):
+        pytest.skip("oracle/_ref binaries not built (need the reference tree at build time)")
+    cases = [
+        ("config 1", 0.8*synth_input(0, 1, 44100, 44100), 44100, ["--time=1", "--semitones=0"], None),
+        ("stereo 1.25x +3 st", 0.7*synth_input(0, 2, 30000, 48000), 48000, ["--time=1.25", "--semitones=3", "--tonality=8000"], 2e-3),
+        ("stereo 0.8x formants", 0.7*synth_input(3, 2, 30000, 48000), 48000,
+         ["--time=0.8", "--semitones=-2", "--formant=2", "--formant-comp", "--formant-base=150"], 2e-2),
+    ]
+    for i, (label, x, sr, flags, tol) in enumerate(cases):
+        src, dst, ref = (str(tmp_path/("%s_main%d.wav" % (n, i))) for n in ("in", "out", "ref"))
+        write_wav16(src, x, sr)
+        subprocess.run([REF_CLI, src, ref] + flags, check=True, capture_output=True)
+        res = subprocess.run([exe, src, dst] + flags, capture_output=True, text=True)
+        assert res.returncode == 0, (label, res.stderr[-2000:])
+        a, b = read_wav16(dst), read_wav16(ref)
+        assert a.shape == b.shape, label
+        if tol is None:  # 1.0x / 0 st: sample-exact up to the 16-bit rounding, and the input itself
+            assert np.abs(a - b).max() <= 2/32768.0, label
+            assert np.abs(a[:, 1323:-2646] - np.round(x[:, 1323:a.shape[1] - 2646]*32768)/32768).max() <= 2/32768.0
+        else:
+            err = np.sqrt(np.mean((a - b)**2)/np.mean(b**2))
+            assert err < tol, (label, err)
+
+
+def test_reference_main_through_dropin_header_emulated(emu, tmp_path):
+    reference_main_cases(os.path.join(ROOT, "oracle", "_ref", "main_dropin_emu"), tmp_path)
+
+
+@pytest.mark.gpu
+def test_reference_main_through_dropin_header_gpu(tmp_path):
+    reference_main_cases(os.path.join(ROOT, "oracle", "_ref", "main_dropin"), tmp_path)
