@@ -244,6 +244,8 @@ def main():
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()
+    if rank == 0 and not ok:
+        raise SystemExit("bench: output not finite / silent -- the line above is not a valid measurement")
 
 
 if __name__ == "__main__":

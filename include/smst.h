@@ -17,8 +17,9 @@
  *      `memory` selects SMST_MEM_HOST (staged through the library's own device buffers) or SMST_MEM_DEVICE
  *      (pointers are device pointers on the batch's GPU; the call is asynchronous on the batch's stream
  *      except for one 64-byte-per-stream readback inside process -- use smst_batch_synchronize()).
- *      Device inputs must be COMPLETE when the call is made (the library does not order itself after the
- *      caller's streams), and inputs / outputs must stay valid until smst_batch_synchronize() returns; the
+ *      Device inputs must be COMPLETE when the call is made, or the producing stream must be handed to
+ *      smst_batch_wait_for_stream() first; inputs / outputs must stay valid until smst_batch_synchronize() returns (or
+ *      until a stream passed to smst_batch_signal_stream() has caught up); the
  *      host-side part of a call (silence gate, block scheduler) overlaps the kernels of the previous call.
  *
  * Every function returns 0 on success and a negative code on failure (the reference has no error channel:
@@ -136,6 +137,13 @@ int smst_batch_output_seek(smst_batch *b, const float *in, long long inStreamStr
 int smst_batch_synchronize(smst_batch *b);
 /* raw hipStream_t the batch enqueues on (so callers can order their own device work against it) */
 void *smst_batch_hip_stream(smst_batch *b);
+/* Stream ordering for device-memory callers, without a host synchronisation:
+ * wait_for_stream: everything the batch enqueues from now on runs after the work ALREADY enqueued on `hipStream` (the
+ *                  caller's producer of the input tensors); call it before smst_batch_process / _seek / _output_seek.
+ * signal_stream:   work enqueued on `hipStream` from now on runs after everything the batch has enqueued so far (so a
+ *                  consumer of the outputs need not call smst_batch_synchronize). */
+int smst_batch_wait_for_stream(smst_batch *b, void *hipStream);
+int smst_batch_signal_stream(smst_batch *b, void *hipStream);
 
 /* measurement hooks: per-kernel-class device time (hipEvent pairs on the batch's stream) accumulated since the
  * last call.  ms[0..6] = analyse, feed, predict, chain, synth, emit, other; launches[0..4] = analyse, predict,
@@ -155,6 +163,10 @@ int smst_batch_debug_get_carry(smst_batch *b, int stream, float *sums, float *pr
  * the next output sample).  The batch is synchronised first. */
 int smst_batch_debug_set_state(smst_batch *b, int stream, int which, const float *src);
 int smst_batch_debug_set_carry(smst_batch *b, int stream, const float *sums, const float *products);
+/* number of device / pinned allocations and host-table growth events since the batch was created.  process() is
+ * allocation-free in steady state (the reference asserts the same of itself: cmd/main-dev.cpp:158-163, "allocated during
+ * process()"): tests/test_abi.py::test_process_does_not_allocate_in_steady_state checks that this number stands still. */
+long long smst_batch_debug_allocation_events(const smst_batch *b);
 /* output map of the stream's newest hop (2*bands floats: inputBin, freqGrad per bin; signalsmith-stretch.h:587-590,
  * :882-917).  Returns 1 if that hop had a frequency map, 0 if not (dst untouched), negative on error. */
 int smst_batch_debug_get_map(smst_batch *b, int stream, float *dst);

@@ -89,6 +89,9 @@ _SIGNATURES = {
     "smst_batch_debug_set_state": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _fp]),
     "smst_batch_debug_set_carry": (C.c_int, [C.c_void_p, C.c_int, _fp, _fp]),
     "smst_batch_debug_get_map": (C.c_int, [C.c_void_p, C.c_int, _fp]),
+    "smst_batch_debug_allocation_events": (_ll, [C.c_void_p]),
+    "smst_batch_wait_for_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "smst_batch_signal_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 
@@ -218,11 +221,11 @@ class StretchBatch:
         self._inflight = []
 
     def _order_after_torch(self, *tensors):
-        """Device-memory calls are asynchronous on the batch's own HIP stream.  Wait for the producer (torch's current
-        stream), and keep the tensors referenced until the batch's stream has drained, so torch's caching allocator
-        cannot recycle their memory while our kernels still read or write it."""
+        """Device-memory calls are asynchronous on the batch's own HIP streams.  Order them after the producer (torch's
+        current stream) with an event -- no host synchronisation -- and keep the tensors referenced until the batch's
+        stream has drained, so torch's caching allocator cannot recycle their memory while our kernels still use it."""
         import torch
-        torch.cuda.current_stream(tensors[0].device).synchronize()
+        _check(self.lib, self.lib.smst_batch_wait_for_stream(self.h, C.c_void_p(torch.cuda.current_stream(tensors[0].device).cuda_stream)))
         inflight = getattr(self, "_inflight", [])
         if len(inflight) >= 16:
             self.synchronize()
@@ -276,6 +279,9 @@ class StretchBatch:
         if mem == MEM_DEVICE:
             self._order_after_torch(x, out)
         _check(self.lib, self.lib.smst_batch_process(self.h, ptr, ss, cs, pin, optr, oss, ocs, pout, mem))
+        if mem == MEM_DEVICE:  # torch ops on `out` issued from here on are ordered after our kernels (no host sync either)
+            import torch
+            _check(self.lib, self.lib.smst_batch_signal_stream(self.h, C.c_void_p(torch.cuda.current_stream(out.device).cuda_stream)))
         return out
 
     def seek(self, x, rates, in_samples=None):
@@ -345,6 +351,9 @@ class StretchBatch:
         if rc < 0:
             _check(self.lib, rc)
         return a if rc == 1 else None
+
+    def allocation_events(self):
+        return int(self.lib.smst_batch_debug_allocation_events(self.h))
 
     def debug_carry(self, stream):
         n = self.blockSamples() + self.intervalSamples()

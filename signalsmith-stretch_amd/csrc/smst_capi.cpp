@@ -18,6 +18,7 @@ struct smst_batch {
 	// host staging (SMST_MEM_HOST)
 	float *dIn = nullptr, *dOut = nullptr;
 	size_t inCap = 0, outCap = 0;
+	long long stagingAllocs = 0;
 	~smst_batch() {
 		if (engine) hipSetDevice(engine->device());
 		if (dIn) hipFree(dIn);
@@ -40,7 +41,7 @@ struct smst_stretch {
 
 #define SMST_TRY try {
 #define SMST_CATCH \
-	} catch (const smst::Error &e) { g_lastError = e.what(); return (g_lastError.find("hip") != std::string::npos) ? SMST_ERR_DEVICE : SMST_ERR_INVALID; } \
+	} catch (const smst::Error &e) { g_lastError = e.what(); return e.device ? SMST_ERR_DEVICE : SMST_ERR_INVALID; } \
 	catch (const std::exception &e) { g_lastError = e.what(); return SMST_ERR_INVALID; }
 
 static int fail(const char *msg) {
@@ -48,14 +49,15 @@ static int fail(const char *msg) {
 	return SMST_ERR_INVALID;
 }
 
-static void ensureStage(float *&ptr, size_t &cap, size_t need, int device) {
+static void ensureStage(float *&ptr, size_t &cap, size_t need, int device, long long &allocs) {
 	if (need <= cap) return;
+	++allocs;
 	hipSetDevice(device);
 	if (ptr) hipFree(ptr);
 	ptr = nullptr;
 	cap = 0;
 	size_t want = need + need/8 + 1024;
-	if (hipMalloc(reinterpret_cast<void **>(&ptr), want*sizeof(float)) != hipSuccess) throw smst::Error("hipMalloc (staging) failed");
+	if (hipMalloc(reinterpret_cast<void **>(&ptr), want*sizeof(float)) != hipSuccess) throw smst::Error("hipMalloc (staging) failed", true);
 	cap = want;
 }
 
@@ -76,7 +78,7 @@ int smst_batch_create(smst_batch **out, int streams, int channels, int block, in
 	if (!out) return fail("null output pointer");
 	SMST_TRY
 	int n = 0;
-	if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) throw smst::Error("hipGetDeviceCount: no HIP device available (the gfx950 path has no CPU fallback)");
+	if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) throw smst::Error("hipGetDeviceCount: no HIP device available (the gfx950 path has no CPU fallback)", true);
 	if (device < 0 || device >= n) throw smst::Error("device ordinal out of range");
 	std::unique_ptr<smst_batch> b(new smst_batch());
 	b->engine.reset(new Batch(streams, channels, block, interval, split != 0, device, seed));
@@ -129,6 +131,9 @@ int smst_batch_debug_get_state(smst_batch *b, int stream, int which, float *dst)
 int smst_batch_debug_get_carry(smst_batch *b, int stream, float *sums, float *products) { BATCH_CALL(b->engine->debugGetCarry(stream, sums, products)) }
 int smst_batch_debug_set_state(smst_batch *b, int stream, int which, const float *src) { BATCH_CALL(b->engine->debugSetState(stream, which, src)) }
 int smst_batch_debug_set_carry(smst_batch *b, int stream, const float *sums, const float *products) { BATCH_CALL(b->engine->debugSetCarry(stream, sums, products)) }
+long long smst_batch_debug_allocation_events(const smst_batch *b) { if (!b || !b->engine) return fail("null batch"); return (long long)b->engine->allocationEvents() + b->stagingAllocs; }
+int smst_batch_wait_for_stream(smst_batch *b, void *hipStream) { BATCH_CALL(b->engine->waitForStream(static_cast<hipStream_t>(hipStream))) }
+int smst_batch_signal_stream(smst_batch *b, void *hipStream) { BATCH_CALL(b->engine->signalStream(static_cast<hipStream_t>(hipStream))) }
 int smst_batch_debug_get_map(smst_batch *b, int stream, float *dst) {
 	if (!b || !b->engine) return fail("null batch");
 	SMST_TRY
@@ -143,16 +148,16 @@ static const float *stageIn(smst_batch *b, const float *in, long long ss, long l
 	maxLen = 0;
 	for (int s = 0; s < S; ++s) maxLen = std::max(maxLen, n[s]);
 	if (maxLen == 0) maxLen = 1;
-	ensureStage(b->dIn, b->inCap, (size_t)S*C*maxLen, e.device());
+	ensureStage(b->dIn, b->inCap, (size_t)S*C*maxLen, e.device(), b->stagingAllocs);
 	hipSetDevice(e.device());
 	for (int s = 0; s < S; ++s) {
 		for (int c = 0; c < C; ++c) {
 			if (n[s] <= 0) continue;
 			if (hipMemcpyAsync(b->dIn + ((size_t)s*C + c)*maxLen, in + s*ss + c*cs, (size_t)n[s]*sizeof(float), hipMemcpyHostToDevice, e.stream()) != hipSuccess)
-				throw smst::Error("hipMemcpyAsync (H2D) failed");
+				throw smst::Error("hipMemcpyAsync (H2D) failed", true);
 		}
 	}
-	if (hipStreamSynchronize(e.stream()) != hipSuccess) throw smst::Error("hipStreamSynchronize failed");
+	if (hipStreamSynchronize(e.stream()) != hipSuccess) throw smst::Error("hipStreamSynchronize failed", true);
 	return b->dIn;
 }
 static void unstageOut(smst_batch *b, float *out, long long ss, long long cs, const int *n, int maxLen) {
@@ -163,10 +168,10 @@ static void unstageOut(smst_batch *b, float *out, long long ss, long long cs, co
 		for (int c = 0; c < C; ++c) {
 			if (n[s] <= 0) continue;
 			if (hipMemcpyAsync(out + s*ss + c*cs, b->dOut + ((size_t)s*C + c)*maxLen, (size_t)n[s]*sizeof(float), hipMemcpyDeviceToHost, e.stream()) != hipSuccess)
-				throw smst::Error("hipMemcpyAsync (D2H) failed");
+				throw smst::Error("hipMemcpyAsync (D2H) failed", true);
 		}
 	}
-	if (hipStreamSynchronize(e.stream()) != hipSuccess) throw smst::Error("hipStreamSynchronize failed");
+	if (hipStreamSynchronize(e.stream()) != hipSuccess) throw smst::Error("hipStreamSynchronize failed", true);
 }
 static int maxOf(const int *n, int S) {
 	int m = 0;
@@ -198,7 +203,7 @@ int smst_batch_process(smst_batch *b, const float *in, long long iss, long long 
 			int maxIn;
 			const float *dIn = stageIn(b, in, iss, ics, inSamples, maxIn);
 			const int maxOut = maxOf(outSamples, e.streams());
-			ensureStage(b->dOut, b->outCap, (size_t)e.streams()*e.channels()*maxOut, e.device());
+			ensureStage(b->dOut, b->outCap, (size_t)e.streams()*e.channels()*maxOut, e.device(), b->stagingAllocs);
 			e.process(dIn, (long long)e.channels()*maxIn, maxIn, inSamples, b->dOut, (long long)e.channels()*maxOut, maxOut, outSamples);
 			unstageOut(b, out, oss, ocs, outSamples, maxOut);
 		}
@@ -212,7 +217,7 @@ int smst_batch_flush(smst_batch *b, float *out, long long oss, long long ocs, co
 		} else {
 			Batch &e = *b->engine;
 			const int maxOut = maxOf(outSamples, e.streams());
-			ensureStage(b->dOut, b->outCap, (size_t)e.streams()*e.channels()*maxOut, e.device());
+			ensureStage(b->dOut, b->outCap, (size_t)e.streams()*e.channels()*maxOut, e.device(), b->stagingAllocs);
 			e.flush(b->dOut, (long long)e.channels()*maxOut, maxOut, outSamples, rates);
 			unstageOut(b, out, oss, ocs, outSamples, maxOut);
 		}
@@ -239,7 +244,7 @@ int smst_create(smst_stretch **out, long seed, int device) {
 	if (!out) return fail("null output pointer");
 	SMST_TRY
 	int n = 0;
-	if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) throw smst::Error("hipGetDeviceCount: no HIP device available (the gfx950 path has no CPU fallback)");
+	if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) throw smst::Error("hipGetDeviceCount: no HIP device available (the gfx950 path has no CPU fallback)", true);
 	if (device < 0 || device >= n) throw smst::Error("device ordinal out of range");
 	smst_stretch *h = new smst_stretch();
 	h->seed = seed;

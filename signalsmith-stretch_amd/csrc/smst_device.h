@@ -81,6 +81,7 @@ void launchCarryFeed(const DevBatch &d, int sBase, int nStreams, int hopBase, bo
 void launchCarryOut(const DevBatch &d, int sBase, int nStreams, hipStream_t st);
 void launchHistory(const DevBatch &d, const IoArgs &io, hipStream_t st);
 void launchPassThrough(const DevBatch &d, const IoArgs &io, const int *passFlags, int maxOut, hipStream_t st);
+void launchResetStreams(const DevBatch &d, const int *flags, int allBits, const float *seedWp, hipStream_t st); // flags: per-stream bit masks or null = allBits for every stream
 void launchSeekHistory(const DevBatch &d, const IoArgs &io, const int *seekFlags, hipStream_t st);
 void launchAddPreRoll(const DevBatch &d, const float *preRoll, int length, const int *offsets, hipStream_t st);
 void launchFlushTail(const DevBatch &d, const IoArgs &io, const int *tailOffset, const int *outOffset, hipStream_t st);

@@ -9,7 +9,7 @@
 
 namespace smst {
 
-#define SMST_HIP(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) throw Error(std::string(#expr) + ": " + hipGetErrorString(e_)); } while (0)
+#define SMST_HIP(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) throw Error(std::string(#expr) + ": " + hipGetErrorString(e_), true); } while (0)
 
 static constexpr float kNoiseFloor = 1e-15f;     // signalsmith-stretch.h:508
 static constexpr float kMaxCleanStretch = 2.0f;  // :509
@@ -79,7 +79,22 @@ template <typename T> T *Batch::devAlloc(size_t count) {
 	if (count == 0) count = 1;
 	SMST_HIP(hipMalloc(&p, count*sizeof(T)));
 	allocations.push_back(p);
+	++allocEvents;
 	return static_cast<T *>(p);
+}
+template <typename T> T *Batch::pinnedAlloc(size_t count) {
+	void *p = nullptr;
+	if (count == 0) count = 1;
+	SMST_HIP(hipHostMalloc(&p, count*sizeof(T), hipHostMallocDefault));
+	pinned.push_back(p);
+	++allocEvents;
+	return static_cast<T *>(p);
+}
+void Batch::pinnedFree(void *p) {
+	if (!p) return;
+	auto it = std::find(pinned.begin(), pinned.end(), p);
+	if (it != pinned.end()) pinned.erase(it);
+	hipHostFree(p);
 }
 void Batch::devFree(void *p) {
 	if (!p) return;
@@ -90,7 +105,29 @@ void Batch::devFree(void *p) {
 
 Batch::Batch(int streams, int channels, int block, int interval, bool splitComputation, int device, long seed)
 	: S(streams), C(channels), B(block), I(interval), split(splitComputation), dev(device) {
+	// geometry first: nothing below may throw before the HIP objects exist, and everything after is covered by the
+	// clean-up in the catch block (a throwing constructor does not run the destructor)
 	if (S < 1 || C < 1 || C > kMaxChannels || B < 4 || I < 1 || I > B) throw Error("invalid configuration (need 1..8 channels, interval <= block)");
+	N = 2*fastSizeAbove((B + 1)/2);
+	M = N/2;
+	if ((size_t)M*sizeof(float2)*2 > 150*1024) throw Error("block too long for the LDS-resident FFT (bands*16 bytes must fit 150 KiB)");
+	L = int(std::round(float(N)/float(I))); // longVerticalStep, signalsmith-stretch.h:636-637
+	if (L < 1) L = 1;
+	{
+		int ring = 4;
+		while (ring < L + 2) ring *= 2;
+		if (ring > 64) throw Error("interval too small relative to the FFT size (vertical step too long)");
+	}
+	const FftPlan plan = makePlan(M, N);
+	try {
+		construct(plan, seed);
+	} catch (...) {
+		releaseAll();
+		throw;
+	}
+}
+
+void Batch::construct(const FftPlan &plan, long seed) {
 	SMST_HIP(hipSetDevice(dev));
 	SMST_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
 	{ // the recurrence is latency-bound with few waves: give its stream the highest priority so its workgroups are
@@ -102,19 +139,20 @@ Batch::Batch(int streams, int channels, int block, int interval, bool splitCompu
 	}
 	SMST_HIP(hipStreamCreateWithFlags(&stSynth, hipStreamNonBlocking));
 	SMST_HIP(hipStreamCreateWithFlags(&stGate, hipStreamNonBlocking));
-	for (int i = 0; i < 2; ++i) SMST_HIP(hipEventCreateWithFlags(&callSets[i].done, hipEventDisableTiming));
+	for (int i = 0; i < 2; ++i) {
+		SMST_HIP(hipEventCreateWithFlags(&callSets[i].done, hipEventDisableTiming));
+		SMST_HIP(hipEventCreateWithFlags(&callSets[i].tables, hipEventDisableTiming));
+	}
 	SMST_HIP(hipEventCreateWithFlags(&evStart, hipEventDisableTiming));
+	SMST_HIP(hipEventCreateWithFlags(&evOrder, hipEventDisableTiming));
 	for (int i = 0; i < 2; ++i) {
 		SMST_HIP(hipEventCreateWithFlags(&evFeed[i], hipEventDisableTiming));
 		SMST_HIP(hipEventCreateWithFlags(&evChain[i], hipEventDisableTiming));
 		SMST_HIP(hipEventCreateWithFlags(&evSynth[i], hipEventDisableTiming));
 	}
+	// environment switches are read once, here
 	if (const char *env = std::getenv("SMST_NO_OVERLAP")) overlap = atoi(env) == 0;
-	N = 2*fastSizeAbove((B + 1)/2);
-	M = N/2;
-	if ((size_t)M*sizeof(float2)*2 > 150*1024) throw Error("block too long for the LDS-resident FFT (bands*16 bytes must fit 150 KiB)");
-	L = int(std::round(float(N)/float(I))); // longVerticalStep, signalsmith-stretch.h:636-637
-	if (L < 1) L = 1;
+	noFuse = std::getenv("SMST_NO_FUSE") != nullptr;
 
 	d.S = S; d.C = C; d.B = B; d.I = I; d.M = M; d.N = N; d.L = L; d.T = kTileHops;
 	d.histLen = B + I;
@@ -124,8 +162,7 @@ Batch::Batch(int streams, int channels, int block, int interval, bool splitCompu
 	int ring = 4;
 	while (ring < d.lag + 1) ring *= 2;
 	d.ringSlots = ring;
-	if (ring > 64) throw Error("interval too small relative to the FFT size (vertical step too long)");
-	d.plan = makePlan(M, N);
+	d.plan = plan;
 	d.mapTableLen = 0;
 	d.debugMode = 0;
 	if (const char *env = std::getenv("SMST_DEBUG_MODE")) d.debugMode = atoi(env);
@@ -241,12 +278,23 @@ Batch::Batch(int streams, int channels, int block, int interval, bool splitCompu
 		callSets[i].inSamples = devAlloc<int>(S);
 		callSets[i].outSamples = devAlloc<int>(S);
 		callSets[i].flags = devAlloc<int>(S);
+		callSets[i].hInSamples = pinnedAlloc<int>(S);
+		callSets[i].hOutSamples = pinnedAlloc<int>(S);
+		callSets[i].hFlags = pinnedAlloc<int>(S);
+		callSets[i].hEnergy = pinnedAlloc<float>((size_t)S*kEnergyParts);
 	}
+	dSeedWp = devAlloc<float>(d.carryLen);
+	SMST_HIP(hipMemcpy(dSeedWp, seedCarryWp.data(), d.carryLen*sizeof(float), hipMemcpyHostToDevice));
+	hopFirst.assign(S, 0);
+	hopCount.assign(S, 0);
+	passV.assign(S, 0);
 	dInSamples = callSets[0].inSamples;
 	dOutSamples = callSets[0].outSamples;
 	dFlags = callSets[0].flags;
 	dAux0 = devAlloc<int>(S);
 	dAux1 = devAlloc<int>(S);
+	dResetBits = devAlloc<int>(S);
+	resetBitsV.assign(S, 0);
 
 	sched.assign(S, StreamSched());
 	lastHop.assign(S, LastHop());
@@ -261,68 +309,106 @@ Batch::Batch(int streams, int channels, int block, int interval, bool splitCompu
 	reset();
 }
 
-Batch::~Batch() {
+Batch::~Batch() { releaseAll(); }
+
+void Batch::releaseAll() {
 	hipSetDevice(dev);
 	if (st) hipStreamSynchronize(st);
 	if (stChain) hipStreamSynchronize(stChain);
 	if (stSynth) hipStreamSynchronize(stSynth);
 	if (stGate) hipStreamSynchronize(stGate);
+	for (auto &e : liveEvents) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
+	liveEvents.clear();
 	for (void *p : allocations) hipFree(p);
-	for (int i = 0; i < 2; ++i) if (callSets[i].done) hipEventDestroy(callSets[i].done);
-	if (stGate) hipStreamDestroy(stGate);
+	allocations.clear();
+	for (void *p : pinned) hipHostFree(p);
+	pinned.clear();
+	for (int i = 0; i < 2; ++i) {
+		if (callSets[i].done) hipEventDestroy(callSets[i].done);
+		if (callSets[i].tables) hipEventDestroy(callSets[i].tables);
+		callSets[i].done = callSets[i].tables = nullptr;
+	}
 	if (evStart) hipEventDestroy(evStart);
+	if (evOrder) hipEventDestroy(evOrder);
+	evStart = evOrder = nullptr;
 	for (int i = 0; i < 2; ++i) {
 		if (evFeed[i]) hipEventDestroy(evFeed[i]);
 		if (evChain[i]) hipEventDestroy(evChain[i]);
 		if (evSynth[i]) hipEventDestroy(evSynth[i]);
+		evFeed[i] = evChain[i] = evSynth[i] = nullptr;
 	}
+	if (stGate) hipStreamDestroy(stGate);
 	if (stChain) hipStreamDestroy(stChain);
 	if (stSynth) hipStreamDestroy(stSynth);
 	if (st) hipStreamDestroy(st);
+	st = stChain = stSynth = stGate = nullptr;
 }
 
 void Batch::allocateWorkspace() {
-	// Per (stream, hop, channel): 3 complex rows + 1 float4 row of M bins + one B-sample frame, plus the skewed records.
-	// Sub-batch the streams so the tile workspace stays under a budget.  Default: a third of the HBM that is free when the
-	// batch is created, per workspace (there are two), at most 96 GiB -- fewer, larger sub-batches keep the one-wave-per-
-	// stream kernels of the 3-8 channel path at more than one wave per CU (config 5: 2 sub-batches instead of 7).
+	// Per (stream, hop, channel): 3 complex rows + 1 float4 row of M bins + one B-sample frame, plus (3-8 channels only) the
+	// skewed records and (SMST_FEED_SERIAL only) the serial feed's scratch.  Sub-batch the streams so one tile workspace
+	// stays under a budget.  Default: a third of the HBM that is free when the batch is created, per workspace (there are
+	// two), at most 96 GiB and never more than 40 % of what is free -- fewer, larger sub-batches keep the one-wave-per-stream
+	// kernels of the 3-8 channel path at more than one wave per CU (config 5: 2 sub-batches instead of 7).  If an
+	// allocation still fails (another batch or torch took the memory meanwhile) the sub-batch is halved and tried again.
 	double budgetGiB = 24;
 	{
 		size_t freeB = 0, totalB = 0;
-		if (hipMemGetInfo(&freeB, &totalB) == hipSuccess && freeB > 0)
-			budgetGiB = std::min(96.0, std::max(8.0, double(freeB)/(1024.0*1024.0*1024.0)/3.0));
+		if (hipMemGetInfo(&freeB, &totalB) == hipSuccess && freeB > 0) {
+			const double freeGiB = double(freeB)/(1024.0*1024.0*1024.0);
+			budgetGiB = std::min(std::min(96.0, std::max(8.0, freeGiB/3.0)), 0.4*freeGiB);
+		}
 	}
 	if (const char *env = std::getenv("SMST_WORKSPACE_GIB")) budgetGiB = std::max(0.0005, atof(env));
+	const bool needRecords = !fusedSupported(d) || noFuse; // the fused recurrence keeps its records in LDS
 	const size_t recChunks = (9 + 3*(size_t)C + 3)/4;
 	d.recSteps = ((M + d.lag*(d.T - 1) + 63)/64)*64 + 8;
 	d.recPitch = int(recChunks*64 + 16);
 	d.Mp = M + 32;
 	const size_t perStream = (size_t)d.T*((size_t)C*((size_t)d.Mp*(3*sizeof(float2) + sizeof(float4)) + (size_t)B*sizeof(float))
-	                                      + (size_t)M*(sizeof(float2) + 2*sizeof(float)) + 2*sizeof(float))
-	                         + (size_t)d.recSteps*d.recPitch*sizeof(float4);
+	                                      + (size_t)M*(sizeof(float2) + sizeof(float)) + 3*sizeof(float))
+	                         + (size_t)C*64*sizeof(float2)
+	                         + (needRecords ? (size_t)d.recSteps*d.recPitch*sizeof(float4) : 0)
+	                         + (d.feedSerial ? (size_t)M*64*2*sizeof(float) + (size_t)(M/2 + 2)*64*sizeof(float2) : 0);
 	size_t maxStreams = size_t(budgetGiB*1024.0*1024.0*1024.0/double(perStream));
 	if (maxStreams < 1) maxStreams = 1;
 	subS = int(std::min<size_t>(S, maxStreams));
-	const size_t rows = (size_t)subS*d.T*C*d.Mp;
-	// two complete tile workspaces: tile i+1's feed-forward kernels run while tile i is still in the recurrence /
-	// synthesis (the budget above is per workspace)
-	for (int i = 0; i < 2; ++i) {
-		TileBuffers &w = slots[i];
-		w.Xcur = devAlloc<float2>(rows);
-		w.Xprev = devAlloc<float2>(rows);
-		w.PE = devAlloc<float4>(rows);
-		w.OUT = devAlloc<float2>(rows);
-		w.REC = devAlloc<float4>((size_t)subS*d.recSteps*d.recPitch);
-		SMST_HIP(hipMemset(w.REC, 0, (size_t)subS*d.recSteps*d.recPitch*sizeof(float4)));
-		w.dump = devAlloc<float2>((size_t)subS*C*64);
-		w.map = devAlloc<float2>((size_t)subS*d.T*M);
-		w.ratio = devAlloc<float>((size_t)subS*d.T*M);
-		w.energyT = devAlloc<float>((size_t)subS*M*64);
-		w.smoothT = devAlloc<float>((size_t)subS*M*64);
-		w.peaksT = devAlloc<float2>((size_t)subS*(M/2 + 2)*64);
-		w.est = devAlloc<float>((size_t)subS*d.T*2);
-		w.freqEst = devAlloc<float>((size_t)subS*d.T);
-		w.frames = devAlloc<float>((size_t)subS*d.T*C*B);
+	for (;;) {
+		const size_t mark = allocations.size();
+		try {
+			const size_t rows = (size_t)subS*d.T*C*d.Mp;
+			// two complete tile workspaces: tile i+1's feed-forward kernels run while tile i is still in the recurrence /
+			// synthesis (the budget above is per workspace)
+			for (int i = 0; i < 2; ++i) {
+				TileBuffers &w = slots[i];
+				w = TileBuffers{};
+				w.Xcur = devAlloc<float2>(rows);
+				w.Xprev = devAlloc<float2>(rows);
+				w.PE = devAlloc<float4>(rows);
+				w.OUT = devAlloc<float2>(rows);
+				if (needRecords) {
+					w.REC = devAlloc<float4>((size_t)subS*d.recSteps*d.recPitch);
+					SMST_HIP(hipMemset(w.REC, 0, (size_t)subS*d.recSteps*d.recPitch*sizeof(float4)));
+				}
+				w.dump = devAlloc<float2>((size_t)subS*C*64);
+				w.map = devAlloc<float2>((size_t)subS*d.T*M);
+				w.ratio = devAlloc<float>((size_t)subS*d.T*M);
+				if (d.feedSerial) {
+					w.energyT = devAlloc<float>((size_t)subS*M*64);
+					w.smoothT = devAlloc<float>((size_t)subS*M*64);
+					w.peaksT = devAlloc<float2>((size_t)subS*(M/2 + 2)*64);
+				}
+				w.est = devAlloc<float>((size_t)subS*d.T*2);
+				w.freqEst = devAlloc<float>((size_t)subS*d.T);
+				w.frames = devAlloc<float>((size_t)subS*d.T*C*B);
+			}
+			break;
+		} catch (const Error &) {
+			while (allocations.size() > mark) { hipFree(allocations.back()); allocations.pop_back(); }
+			(void)hipGetLastError();
+			if (subS <= 1) throw;
+			subS = (subS + 1)/2;
+		}
 	}
 	wsBytes = 2*perStream*subS;
 }
@@ -334,44 +420,18 @@ void Batch::uploadParams() {
 	paramsDirty = false;
 }
 
-void Batch::writeSeedCarry(const unsigned char *active) {
-	for (int h = 0; h < 2; ++h) {
-		for (int s = 0; s < S; ++s) {
-			if (active && !active[s]) continue;
-			SMST_HIP(hipMemsetAsync(d.carrySum[h] + (size_t)s*C*d.carryLen, 0, (size_t)C*d.carryLen*sizeof(float), st));
-			SMST_HIP(hipMemcpyAsync(d.carryWp[h] + (size_t)s*d.carryLen, seedCarryWp.data(), d.carryLen*sizeof(float), hipMemcpyHostToDevice, st));
-			SMST_HIP(hipMemsetAsync(d.hist[h] + (size_t)s*C*d.histLen, 0, (size_t)C*d.histLen*sizeof(float), st));
-		}
-	}
-	SMST_HIP(hipStreamSynchronize(st)); // seedCarryWp is pageable host memory
-}
-
-void Batch::zeroBandState(int s, bool input, bool prev, bool output) {
-	const size_t off = (size_t)s*C*M, bytes = (size_t)C*M*sizeof(float2);
-	if (input) SMST_HIP(hipMemsetAsync(d.stInput + off, 0, bytes, st));
-	if (prev) SMST_HIP(hipMemsetAsync(d.stPrev + off, 0, bytes, st));
-	if (output) SMST_HIP(hipMemsetAsync(d.stOut + off, 0, bytes, st));
+// stft.reset(0.1) / Band clearing for a set of streams (bit masks, see kResetStreams): one upload + one launch, instead
+// of six API calls per stream.  `bitsHost` == nullptr: `allBits` for every stream.  Not on the steady-state path (reset,
+// flush, first silent block), so the small synchronous upload is fine.
+void Batch::resetStreams(const int *bitsHost, int allBits) {
+	if (bitsHost) SMST_HIP(hipMemcpy(dResetBits, bitsHost, S*sizeof(int), hipMemcpyHostToDevice));
+	launchResetStreams(d, bitsHost ? dResetBits : nullptr, allBits, dSeedWp, st);
 }
 
 void Batch::reset() { // signalsmith-stretch.h:49-60
 	SMST_HIP(hipSetDevice(dev));
-	const size_t bandRows = (size_t)S*C*M;
-	SMST_HIP(hipMemsetAsync(d.stInput, 0, bandRows*sizeof(float2), st));
-	SMST_HIP(hipMemsetAsync(d.stPrev, 0, bandRows*sizeof(float2), st));
-	SMST_HIP(hipMemsetAsync(d.stOut, 0, bandRows*sizeof(float2), st));
 	SMST_HIP(hipMemsetAsync(d.stFreq, 0, (size_t)S*2*sizeof(float), st));
-	if (S <= 64) {
-		writeSeedCarry(nullptr);
-	} else { // bulk path: build the whole seed image once
-		std::vector<float> wpAll((size_t)S*d.carryLen);
-		for (int s = 0; s < S; ++s) std::copy(seedCarryWp.begin(), seedCarryWp.end(), wpAll.begin() + (size_t)s*d.carryLen);
-		for (int h = 0; h < 2; ++h) {
-			SMST_HIP(hipMemsetAsync(d.carrySum[h], 0, (size_t)S*C*d.carryLen*sizeof(float), st));
-			SMST_HIP(hipMemsetAsync(d.hist[h], 0, (size_t)S*C*d.histLen*sizeof(float), st));
-			SMST_HIP(hipMemcpyAsync(d.carryWp[h], wpAll.data(), wpAll.size()*sizeof(float), hipMemcpyHostToDevice, st));
-		}
-		SMST_HIP(hipStreamSynchronize(st));
-	}
+	resetStreams(nullptr, 1 | 2 | 4 | 8);
 	d.histCur = 0;
 	d.carryCur = 0;
 	for (auto &sc : sched) {
@@ -421,21 +481,36 @@ void Batch::setFreqMapTable(int stream, const float *table, int n) { // table fo
 		return;
 	}
 	if (n < 2) throw Error("frequency-map table needs at least 2 points");
+	if (stream >= S) throw Error("stream index out of range");
 	SMST_HIP(hipSetDevice(dev));
-	if (d.mapTableLen != n) {
-		if (dMapTable) { SMST_HIP(hipStreamSynchronize(st)); devFree(dMapTable); }
+	if (d.mapTableLen == 0) { // the first table fixes the batch's resolution; the tables are per stream and independent
 		dMapTable = devAlloc<float>((size_t)S*n);
 		hostMapTable.assign((size_t)S*n, 0.0f);
-		for (auto &p : params) p.hasCustomMap = 0;
 		d.mapTableLen = n;
 		d.mapTable = dMapTable;
 	}
+	const int len = d.mapTableLen;
+	std::vector<float> resampled;
+	const float *src = table;
+	if (n != len) { // another length: evaluate the incoming table (its own interpolation rule) at this batch's sample points
+		resampled.resize(len);
+		for (int i = 0; i < len; ++i) {
+			const float freq = (i + 0.5f)/(2*float(len));
+			float pos = freq*2*float(n) - 0.5f;
+			float v;
+			if (pos <= 0) v = table[0] + (table[1] - table[0])*pos;
+			else if (pos >= n - 1) v = table[n - 1] + (table[n - 1] - table[n - 2])*(pos - (n - 1));
+			else { const int lo = int(std::floor(pos)); v = table[lo] + (table[lo + 1] - table[lo])*(pos - lo); }
+			resampled[i] = v;
+		}
+		src = resampled.data();
+	}
 	forStreams(S, stream, [&](int s) {
-		std::copy(table, table + n, hostMapTable.begin() + (size_t)s*n);
+		std::copy(src, src + len, hostMapTable.begin() + (size_t)s*len);
 		params[s].hasCustomMap = 1;
 	});
-	SMST_HIP(hipMemcpyAsync(dMapTable, hostMapTable.data(), hostMapTable.size()*sizeof(float), hipMemcpyHostToDevice, st));
-	SMST_HIP(hipStreamSynchronize(st));
+	SMST_HIP(hipStreamSynchronize(st)); // kernels of earlier calls may still read the old table
+	SMST_HIP(hipMemcpy(dMapTable, hostMapTable.data(), hostMapTable.size()*sizeof(float), hipMemcpyHostToDevice));
 	paramsDirty = true;
 }
 
@@ -478,20 +553,37 @@ void Batch::synchronize() {
 }
 
 // ---- process ----------------------------------------------------------------------------------------------
+template <typename T> static void ensureSize(std::vector<T> &v, size_t n, long &events) {
+	if (n > v.capacity()) ++events;
+	v.resize(n);
+}
+
+void Batch::waitForStream(hipStream_t other) {
+	SMST_HIP(hipSetDevice(dev));
+	SMST_HIP(hipEventRecord(evOrder, other));
+	SMST_HIP(hipStreamWaitEvent(st, evOrder, 0));
+	SMST_HIP(hipStreamWaitEvent(stGate, evOrder, 0));
+}
+void Batch::signalStream(hipStream_t other) {
+	SMST_HIP(hipSetDevice(dev));
+	SMST_HIP(hipEventRecord(evOrder, st));
+	SMST_HIP(hipStreamWaitEvent(other, evOrder, 0));
+}
+
 void Batch::process(const float *in, long long inSS, long long inCS, const int *inSamples,
                     float *out, long long outSS, long long outCS, const int *outSamples, const unsigned char *active) {
 	SMST_HIP(hipSetDevice(dev));
 	uploadParams();
 	// This call's tables go into the set that the call before the previous one used (its kernels must have finished);
 	// everything up to the first tile launch runs on `stGate`, so the host-side scheduling of this call overlaps the
-	// kernels of the previous call that are still queued on `st`.
+	// kernels of the previous call that are still queued on `st`.  All staging is pinned and owned by the set, so the
+	// uploads are asynchronous and the ONLY host synchronisation of a call is the silence-gate readback.
 	callCur ^= 1;
 	CallSet &cs = callSets[callCur];
 	if (cs.used) SMST_HIP(hipEventSynchronize(cs.done));
 	dInSamples = cs.inSamples; dOutSamples = cs.outSamples; dFlags = cs.flags;
-	dHops = cs.hops; hopsCapacity = cs.hopsCap; dEmit = cs.emit; emitCapacity = cs.emitCap; dTileInfo = cs.tileInfo; tileInfoCapacity = cs.tileInfoCap;
 	const int T = d.T;
-	std::vector<int> nIn(S), nOut(S);
+	int *nIn = cs.hInSamples, *nOut = cs.hOutSamples;
 	int maxOut = 0;
 	for (int s = 0; s < S; ++s) {
 		bool on = !active || active[s];
@@ -500,36 +592,35 @@ void Batch::process(const float *in, long long inSS, long long inCS, const int *
 		if (nIn[s] < 0 || nOut[s] < 0) throw Error("negative sample count");
 		maxOut = std::max(maxOut, nOut[s]);
 	}
-	SMST_HIP(hipMemcpyAsync(dInSamples, nIn.data(), S*sizeof(int), hipMemcpyHostToDevice, stGate));
-	SMST_HIP(hipMemcpyAsync(dOutSamples, nOut.data(), S*sizeof(int), hipMemcpyHostToDevice, stGate));
+	SMST_HIP(hipMemcpyAsync(dInSamples, nIn, S*sizeof(int), hipMemcpyHostToDevice, stGate));
+	SMST_HIP(hipMemcpyAsync(dOutSamples, nOut, S*sizeof(int), hipMemcpyHostToDevice, stGate));
 	IoArgs io{in, out, inSS, inCS, outSS, outCS, dInSamples, dOutSamples};
 
-	// K5: silence gate needs the input energy on the host (one 4-byte-per-stream readback per call)
-	std::vector<float> energy(S), energyParts((size_t)S*kEnergyParts);
+	// K5: silence gate needs the input energy on the host (one 64-byte-per-stream readback per call)
 	launchEnergy(d, io, 0, S, dEnergy, stGate);
-	SMST_HIP(hipMemcpyAsync(energyParts.data(), dEnergy, energyParts.size()*sizeof(float), hipMemcpyDeviceToHost, stGate));
+	SMST_HIP(hipMemcpyAsync(cs.hEnergy, dEnergy, (size_t)S*kEnergyParts*sizeof(float), hipMemcpyDeviceToHost, stGate));
 	SMST_HIP(hipStreamSynchronize(stGate));
-	for (int s = 0; s < S; ++s) {
-		float e = 0;
-		for (int p = 0; p < kEnergyParts; ++p) e += energyParts[(size_t)s*kEnergyParts + p];
-		energy[s] = e;
-	}
 
-	// K0: block scheduler, exactly as signalsmith-stretch.h:231-319 does it per stream
-	std::vector<std::vector<HopDesc>> hopLists(S);
-	std::vector<int> passFlags(S, 0);
-	bool anyPass = false;
+	// K0, pass 1: silence gate (signalsmith-stretch.h:231-278) and the number of hops each stream fires in this call
+	int *passFlags = cs.hFlags;
+	bool anyPass = false, anyClear = false;
 	int maxHops = 0;
 	for (int s = 0; s < S; ++s) {
+		passFlags[s] = 0;
+		hopFirst[s] = 0;
+		hopCount[s] = 0;
+		resetBitsV[s] = 0;
 		if (active && !active[s]) continue;
 		StreamSched &sc = sched[s];
-		const StreamParams &prm = params[s];
-		if (energy[s] < kNoiseFloor) { // :240-278
+		float e = 0;
+		for (int p = 0; p < kEnergyParts; ++p) e += cs.hEnergy[(size_t)s*kEnergyParts + p];
+		if (e < kNoiseFloor) { // :240-278
 			if (sc.silenceCounter >= size_t(2*B)) {
 				if (sc.silenceFirst) {
 					sc.silenceFirst = false;
 					sc.samplesSinceLast = SIZE_MAX; // blockProcess = {}
-					zeroBandState(s, true, true, true);
+					resetBitsV[s] = 2 | 4 | 8;      // Band.input / .prevInput / .output := 0
+					anyClear = true;
 				}
 				passFlags[s] = 1;
 				anyPass = true;
@@ -541,68 +632,96 @@ void Batch::process(const float *in, long long inSS, long long inCS, const int *
 			sc.silenceCounter = 0;
 			sc.silenceFirst = true;
 		}
-		auto &list = hopLists[s];
-		const bool mapped = prm.hasCustomMap || prm.freqMultiplier != 1; // :300
-		const bool formants = prm.formantMultiplier != 1 || (prm.formantCompensation && mapped); // :310
-		int lastNew = -1;
-		int first = (sc.samplesSinceLast >= size_t(I)) ? 0 : int(size_t(I) - sc.samplesSinceLast);
-		int lastHopPos = -1;
-		for (int o = first; o < nOut[s]; o += I) {
-			HopDesc hd{};
-			const int j = int(list.size());
-			int inputOffset = int(std::round(o*float(nIn[s])/nOut[s])); // :288 (fp32 on purpose)
-			int inputInterval = inputOffset - sc.prevInputOffset;
-			sc.prevInputOffset = inputOffset;
-			hd.inputOffset = inputOffset;
-			hd.outPos = o;
-			unsigned flags = HOP_ACTIVE;
-			const bool newSpectrum = sc.didSeek || inputInterval > 0; // :299
-			bool reanalyse = false;
-			if (newSpectrum) {
-				flags |= HOP_NEW_SPECTRUM;
-				reanalyse = sc.didSeek || std::abs(inputInterval - I) > 1; // :303
-				if (reanalyse) flags |= HOP_REANALYSE_PREV;
-			}
-			if (mapped) flags |= HOP_MAPPED;
-			if (formants) flags |= HOP_FORMANTS;
-			float tf = sc.didSeek ? sc.seekTimeFactor : float(I)/std::max<float>(1, float(inputInterval)); // :312
-			sc.didSeek = false;
-			tf = std::max<float>(tf, 1/kMaxCleanStretch); // :638
-			if (tf > kMaxCleanStretch) flags |= HOP_RANDOM_TF; // :639
-			hd.timeFactor = tf;
-			hd.flags = flags;
-			hd.seed = sc.seed ^ (sc.rngCounter++*0x9E3779B1u);
-			const int tile = j/T;
-			const bool lastInTile = lastNew >= 0 && lastNew/T == tile;
-			hd.inSrc = newSpectrum ? j%T : (lastInTile ? lastNew%T : SRC_STATE);
-			if (newSpectrum && reanalyse) hd.prevSrc = SRC_REANALYSED;
-			else hd.prevSrc = lastInTile ? lastNew%T : SRC_STATE;
-			if (newSpectrum) lastNew = j;
-			list.push_back(hd);
-			lastHopPos = o;
-		}
-		if (lastHopPos >= 0) sc.samplesSinceLast = size_t(nOut[s] - lastHopPos);
-		else if (sc.samplesSinceLast != SIZE_MAX) sc.samplesSinceLast += size_t(nOut[s]);
-		sc.prevInputOffset -= nIn[s]; // :419
-		maxHops = std::max(maxHops, int(list.size()));
+		const int first = (sc.samplesSinceLast >= size_t(I)) ? 0 : int(size_t(I) - sc.samplesSinceLast);
+		hopFirst[s] = first;
+		hopCount[s] = (nOut[s] > first) ? (nOut[s] - first + I - 1)/I : 0;
+		maxHops = std::max(maxHops, hopCount[s]);
 	}
+	if (anyClear) resetStreams(resetBitsV.data(), 0);
 	const int nTiles = std::max(1, (maxHops + T - 1)/T);
 	const int hopStride = nTiles*T;
-
-	// per-call tables -> device
-	std::vector<HopDesc> hopsAll((size_t)S*hopStride);
-	std::memset(hopsAll.data(), 0, hopsAll.size()*sizeof(HopDesc));
-	std::vector<EmitDesc> emitAll((size_t)S*nTiles);
 	const int nSub = (S + subS - 1)/subS;
-	// tileInfo layout: [sub][tile][2][subS] (nHops, lastNewHop)
-	std::vector<int> tileInfo((size_t)nSub*nTiles*2*subS, 0);
-	std::vector<int> maxSpan((size_t)nSub*nTiles, 0);
-	std::vector<unsigned char> tileHas((size_t)nSub*nTiles*8, 0); // any hops / any mapped / any formants / any new spectrum / any random time factor
+
+	// per-call tables: pinned staging and device copies grow only when a call needs more hops than any earlier call
+	const size_t needHops = (size_t)S*hopStride, needEmit = (size_t)S*nTiles, needInfo = (size_t)nSub*nTiles*2*subS;
+	if (needHops > cs.hopsCap) {
+		if (cs.hops) { devFree(cs.hops); pinnedFree(cs.hHops); }
+		cs.hopsCap = needHops + needHops/4;
+		cs.hops = devAlloc<HopDesc>(cs.hopsCap);
+		cs.hHops = pinnedAlloc<HopDesc>(cs.hopsCap);
+	}
+	if (needEmit > cs.emitCap) {
+		if (cs.emit) { devFree(cs.emit); pinnedFree(cs.hEmit); }
+		cs.emitCap = needEmit + needEmit/4;
+		cs.emit = devAlloc<EmitDesc>(cs.emitCap);
+		cs.hEmit = pinnedAlloc<EmitDesc>(cs.emitCap);
+	}
+	if (needInfo > cs.tileInfoCap) {
+		if (cs.tileInfo) { devFree(cs.tileInfo); pinnedFree(cs.hTileInfo); }
+		cs.tileInfoCap = needInfo + needInfo/4;
+		cs.tileInfo = devAlloc<int>(cs.tileInfoCap);
+		cs.hTileInfo = pinnedAlloc<int>(cs.tileInfoCap);
+	}
+	dHops = cs.hops; dEmit = cs.emit; dTileInfo = cs.tileInfo;
+	HopDesc *hopsAll = cs.hHops;
+	EmitDesc *emitAll = cs.hEmit;
+	int *tileInfo = cs.hTileInfo; // layout: [sub][tile][2][subS] (nHops, lastNewHop)
+	std::memset(hopsAll, 0, needHops*sizeof(HopDesc));
+	std::memset(tileInfo, 0, needInfo*sizeof(int));
+	ensureSize(maxSpanV, (size_t)nSub*nTiles, allocEvents);
+	ensureSize(tileHasV, (size_t)nSub*nTiles*8, allocEvents); // any hops / any mapped / any formants / any new spectrum / any random time factor
+	std::fill(maxSpanV.begin(), maxSpanV.end(), 0);
+	std::fill(tileHasV.begin(), tileHasV.end(), 0);
+
+	// K0, pass 2: block scheduler, exactly as signalsmith-stretch.h:280-319 does it per stream, straight into the tables
 	for (int s = 0; s < S; ++s) {
-		const auto &list = hopLists[s];
 		const int sub = s/subS, sl = s%subS;
-		std::copy(list.begin(), list.end(), hopsAll.begin() + (size_t)s*hopStride);
-		const int nh = int(list.size());
+		HopDesc *list = hopsAll + (size_t)s*hopStride;
+		const int nh = hopCount[s];
+		if (nh > 0) {
+			StreamSched &sc = sched[s];
+			const StreamParams &prm = params[s];
+			const bool mapped = prm.hasCustomMap || prm.freqMultiplier != 1; // :300
+			const bool formants = prm.formantMultiplier != 1 || (prm.formantCompensation && mapped); // :310
+			int lastNew = -1;
+			int o = hopFirst[s];
+			for (int j = 0; j < nh; ++j, o += I) {
+				HopDesc &hd = list[j];
+				int inputOffset = int(std::round(o*float(nIn[s])/nOut[s])); // :288 (fp32 on purpose)
+				int inputInterval = inputOffset - sc.prevInputOffset;
+				sc.prevInputOffset = inputOffset;
+				hd.inputOffset = inputOffset;
+				hd.outPos = o;
+				unsigned flags = HOP_ACTIVE;
+				const bool newSpectrum = sc.didSeek || inputInterval > 0; // :299
+				bool reanalyse = false;
+				if (newSpectrum) {
+					flags |= HOP_NEW_SPECTRUM;
+					reanalyse = sc.didSeek || std::abs(inputInterval - I) > 1; // :303
+					if (reanalyse) flags |= HOP_REANALYSE_PREV;
+				}
+				if (mapped) flags |= HOP_MAPPED;
+				if (formants) flags |= HOP_FORMANTS;
+				float tf = sc.didSeek ? sc.seekTimeFactor : float(I)/std::max<float>(1, float(inputInterval)); // :312
+				sc.didSeek = false;
+				tf = std::max<float>(tf, 1/kMaxCleanStretch); // :638
+				if (tf > kMaxCleanStretch) flags |= HOP_RANDOM_TF; // :639
+				hd.timeFactor = tf;
+				hd.flags = flags;
+				hd.seed = sc.seed ^ (sc.rngCounter++*0x9E3779B1u);
+				const int tile = j/T;
+				const bool lastInTile = lastNew >= 0 && lastNew/T == tile;
+				hd.inSrc = newSpectrum ? j%T : (lastInTile ? lastNew%T : SRC_STATE);
+				if (newSpectrum && reanalyse) hd.prevSrc = SRC_REANALYSED;
+				else hd.prevSrc = lastInTile ? lastNew%T : SRC_STATE;
+				if (newSpectrum) lastNew = j;
+			}
+			sc.samplesSinceLast = size_t(nOut[s] - (o - I));
+		} else if (!passFlags[s] && !(active && !active[s])) {
+			StreamSched &sc = sched[s];
+			if (sc.samplesSinceLast != SIZE_MAX) sc.samplesSinceLast += size_t(nOut[s]);
+		}
+		if (!(active && !active[s]) && !passFlags[s]) sched[s].prevInputOffset -= nIn[s]; // :419
 		for (int t = 0; t < nTiles; ++t) {
 			const int h0 = t*T, h1 = std::min(nh, h0 + T);
 			const int cnt = std::max(0, h1 - h0);
@@ -614,17 +733,17 @@ void Batch::process(const float *in, long long inSS, long long inCS, const int *
 			ed.firstHopPos = cnt > 0 ? list[h0].outPos : 0;
 			ed.hopCount = cnt;
 			emitAll[(size_t)s*nTiles + t] = ed;
-			int *info = tileInfo.data() + ((size_t)(sub*nTiles + t)*2)*subS;
+			int *info = tileInfo + ((size_t)(sub*nTiles + t)*2)*subS;
 			info[sl] = cnt;
 			int lastNewLocal = -1;
+			unsigned char *th = tileHasV.data() + (size_t)(sub*nTiles + t)*8;
 			for (int h = h0; h < h1; ++h) {
-				if (list[h].flags & HOP_NEW_SPECTRUM) lastNewLocal = h - h0;
-				unsigned char *th = tileHas.data() + (size_t)(sub*nTiles + t)*8;
+				const unsigned f = list[h].flags;
+				if (f & HOP_NEW_SPECTRUM) { lastNewLocal = h - h0; th[3] = 1; }
 				th[0] = 1;
-				if (list[h].flags & HOP_MAPPED) th[1] = 1;
-				if (list[h].flags & HOP_FORMANTS) th[2] = 1;
-				if (list[h].flags & HOP_NEW_SPECTRUM) th[3] = 1;
-				if (list[h].flags & HOP_RANDOM_TF) th[4] = 1;
+				if (f & HOP_MAPPED) th[1] = 1;
+				if (f & HOP_FORMANTS) th[2] = 1;
+				if (f & HOP_RANDOM_TF) th[4] = 1;
 			}
 			info[subS + sl] = lastNewLocal;
 			if (cnt > 0) {
@@ -634,30 +753,17 @@ void Batch::process(const float *in, long long inSS, long long inCS, const int *
 				lh.subLocal = sl;
 				lh.mapped = (list[h1 - 1].flags & HOP_MAPPED) != 0;
 			}
-			maxSpan[(size_t)sub*nTiles + t] = std::max(maxSpan[(size_t)sub*nTiles + t], ed.nHi - ed.nLo);
+			int &span = maxSpanV[(size_t)sub*nTiles + t];
+			span = std::max(span, ed.nHi - ed.nLo);
 		}
 	}
-	if (hopsAll.size() > hopsCapacity) {
-		if (dHops) devFree(dHops);
-		hopsCapacity = hopsAll.size() + hopsAll.size()/4;
-		dHops = devAlloc<HopDesc>(hopsCapacity);
-	}
-	if (emitAll.size() > emitCapacity) {
-		if (dEmit) devFree(dEmit);
-		emitCapacity = emitAll.size() + emitAll.size()/4;
-		dEmit = devAlloc<EmitDesc>(emitCapacity);
-	}
-	if (tileInfo.size() > tileInfoCapacity) {
-		if (dTileInfo) devFree(dTileInfo);
-		tileInfoCapacity = tileInfo.size() + tileInfo.size()/4;
-		dTileInfo = devAlloc<int>(tileInfoCapacity);
-	}
-	SMST_HIP(hipMemcpyAsync(dHops, hopsAll.data(), hopsAll.size()*sizeof(HopDesc), hipMemcpyHostToDevice, stGate));
-	SMST_HIP(hipMemcpyAsync(dEmit, emitAll.data(), emitAll.size()*sizeof(EmitDesc), hipMemcpyHostToDevice, stGate));
-	SMST_HIP(hipMemcpyAsync(dTileInfo, tileInfo.data(), tileInfo.size()*sizeof(int), hipMemcpyHostToDevice, stGate));
-	if (anyPass) SMST_HIP(hipMemcpyAsync(dFlags, passFlags.data(), S*sizeof(int), hipMemcpyHostToDevice, stGate));
-	SMST_HIP(hipStreamSynchronize(stGate)); // the staging vectors are pageable and go out of scope; tables complete before any launch below
-	cs.hops = dHops; cs.hopsCap = hopsCapacity; cs.emit = dEmit; cs.emitCap = emitCapacity; cs.tileInfo = dTileInfo; cs.tileInfoCap = tileInfoCapacity;
+	SMST_HIP(hipMemcpyAsync(dHops, hopsAll, needHops*sizeof(HopDesc), hipMemcpyHostToDevice, stGate));
+	SMST_HIP(hipMemcpyAsync(dEmit, emitAll, needEmit*sizeof(EmitDesc), hipMemcpyHostToDevice, stGate));
+	SMST_HIP(hipMemcpyAsync(dTileInfo, tileInfo, needInfo*sizeof(int), hipMemcpyHostToDevice, stGate));
+	if (anyPass) SMST_HIP(hipMemcpyAsync(dFlags, passFlags, S*sizeof(int), hipMemcpyHostToDevice, stGate));
+	// the kernels below are ordered after the uploads by an event, not by the host
+	SMST_HIP(hipEventRecord(cs.tables, stGate));
+	SMST_HIP(hipStreamWaitEvent(st, cs.tables, 0));
 
 	d.hops = dHops;
 	d.emit = dEmit;
@@ -669,7 +775,6 @@ void Batch::process(const float *in, long long inSS, long long inCS, const int *
 	// hundred waves, instruction-issue bound), `stSynth` synthesis + emission.  Two workspaces alternate, so the bulk
 	// kernels of the next tile fill the machine while the recurrence of the current one is in flight.
 	const bool serial = profiling || !overlap;
-	const bool noFuse = std::getenv("SMST_NO_FUSE") != nullptr;
 	hipStream_t sF = st, sC = serial ? st : stChain, sS = serial ? st : stSynth;
 	if (!serial) {
 		SMST_HIP(hipEventRecord(evStart, st));
@@ -681,7 +786,7 @@ void Batch::process(const float *in, long long inSS, long long inCS, const int *
 		const int sBase = sub*subS;
 		const int ns = std::min(subS, S - sBase);
 		for (int t = 0; t < nTiles; ++t, ++q) {
-			const unsigned char *th = tileHas.data() + (size_t)(sub*nTiles + t)*8;
+			const unsigned char *th = tileHasV.data() + (size_t)(sub*nTiles + t)*8;
 			const int hopBase = t*T;
 			const int tileHops = std::min(T, std::max(1, maxHops - hopBase));
 			const int slot = q & 1;
@@ -743,7 +848,7 @@ void Batch::process(const float *in, long long inSS, long long inCS, const int *
 				SMST_HIP(hipStreamWaitEvent(sS, evChain[slot], 0));
 			}
 			if (th[0]) timed(timings.synthMs, [&] { launchSynth(dd, sBase, ns, hopBase, tileHops, sS); if (profiling) ++timings.synthLaunches; });
-			timed(timings.emitMs, [&] { launchEmit(dd, io, sBase, ns, t, maxSpan[(size_t)sub*nTiles + t], sS); if (profiling) ++timings.emitLaunches; });
+			timed(timings.emitMs, [&] { launchEmit(dd, io, sBase, ns, t, maxSpanV[(size_t)sub*nTiles + t], sS); if (profiling) ++timings.emitLaunches; });
 			if (!serial) SMST_HIP(hipEventRecord(evSynth[slot], sS));
 		}
 	}
@@ -767,39 +872,39 @@ void Batch::process(const float *in, long long inSS, long long inCS, const int *
 // ---- seek -------------------------------------------------------------------------------------------------
 void Batch::seek(const float *in, long long inSS, long long inCS, const int *inSamples, const double *rates, const unsigned char *active) {
 	SMST_HIP(hipSetDevice(dev));
-	std::vector<int> nIn(S, 0), flags(S, 0), start(S, 0);
+	// pinned staging of its own ([S] sample counts, [S] flags, [S] history lengths, energy partials): one host
+	// synchronisation (the energy readback that decides about the silence counter, :159-162)
+	if (!hSeek) {
+		hSeek = pinnedAlloc<int>((size_t)3*S);
+		hSeekEnergy = pinnedAlloc<float>((size_t)S*kEnergyParts);
+	} else {
+		SMST_HIP(hipStreamSynchronize(st)); // an earlier seek's uploads may still be in flight
+	}
+	int *nIn = hSeek, *flags = hSeek + S, *histN = hSeek + 2*S;
 	for (int s = 0; s < S; ++s) {
-		if (active && !active[s]) continue;
-		flags[s] = 1;
-		nIn[s] = inSamples[s];
+		const bool on = !active || active[s];
+		flags[s] = on ? 1 : 0;
+		nIn[s] = on ? inSamples[s] : 0;
+		histN[s] = d.histLen;
 		if (nIn[s] < 0) throw Error("negative sample count");
 	}
-	// energy of the copied part only (:144-154): the last min(n, B+I) samples
-	std::vector<int> nTail(S, 0);
-	for (int s = 0; s < S; ++s) nTail[s] = std::min(nIn[s], B + I);
-	SMST_HIP(hipMemcpyAsync(dInSamples, nIn.data(), S*sizeof(int), hipMemcpyHostToDevice, st));
-	SMST_HIP(hipMemcpyAsync(dFlags, flags.data(), S*sizeof(int), hipMemcpyHostToDevice, st));
-	SMST_HIP(hipStreamSynchronize(st));
+	SMST_HIP(hipMemcpyAsync(dInSamples, nIn, S*sizeof(int), hipMemcpyHostToDevice, st));
+	SMST_HIP(hipMemcpyAsync(dFlags, flags, S*sizeof(int), hipMemcpyHostToDevice, st));
+	SMST_HIP(hipMemcpyAsync(dAux0, histN, S*sizeof(int), hipMemcpyHostToDevice, st));
 	IoArgs io{in, nullptr, inSS, inCS, 0, 0, dInSamples, dOutSamples};
 	launchSeekHistory(d, io, dFlags, st);
 	d.histCur ^= 1;
-	// energy over the new history (zero padding adds nothing)
+	// energy of the copied part only (:144-154) = energy over the new history (the zero padding adds nothing)
 	IoArgs ioE{d.hist[d.histCur], nullptr, (long long)C*d.histLen, (long long)d.histLen, 0, 0, dAux0, dOutSamples};
-	std::vector<int> histN(S, d.histLen);
-	SMST_HIP(hipMemcpyAsync(dAux0, histN.data(), S*sizeof(int), hipMemcpyHostToDevice, st));
-	std::vector<float> energy(S), energyParts((size_t)S*kEnergyParts);
 	launchEnergy(d, ioE, 0, S, dEnergy, st);
-	SMST_HIP(hipMemcpyAsync(energyParts.data(), dEnergy, energyParts.size()*sizeof(float), hipMemcpyDeviceToHost, st));
+	SMST_HIP(hipMemcpyAsync(hSeekEnergy, dEnergy, (size_t)S*kEnergyParts*sizeof(float), hipMemcpyDeviceToHost, st));
 	SMST_HIP(hipStreamSynchronize(st));
 	for (int s = 0; s < S; ++s) {
-		float e = 0;
-		for (int p = 0; p < kEnergyParts; ++p) e += energyParts[(size_t)s*kEnergyParts + p];
-		energy[s] = e;
-	}
-	for (int s = 0; s < S; ++s) {
 		if (!flags[s]) continue;
+		float e = 0;
+		for (int p = 0; p < kEnergyParts; ++p) e += hSeekEnergy[(size_t)s*kEnergyParts + p];
 		StreamSched &sc = sched[s];
-		if (energy[s] >= kNoiseFloor) { // :159-162
+		if (e >= kNoiseFloor) { // :159-162
 			sc.silenceCounter = 0;
 			sc.silenceFirst = true;
 		}
@@ -838,7 +943,9 @@ void Batch::flush(float *out, long long outSS, long long outCS, const int *outSa
 			if (dZeros) { SMST_HIP(hipStreamSynchronize(st)); devFree(dZeros); }
 			zerosCapacity = (size_t)maxIn + 1 + 4096;
 			dZeros = devAlloc<float>(zerosCapacity);
+			// process() reads this on another stream (the silence gate runs on stGate): complete the fill before going on
 			SMST_HIP(hipMemsetAsync(dZeros, 0, zerosCapacity*sizeof(float), st));
+			SMST_HIP(hipStreamSynchronize(st));
 		}
 		process(dZeros, 0, 0, blockIn.data(), out, outSS, outCS, blockOut.data(), runBlock.data());
 	}
@@ -855,8 +962,8 @@ void Batch::flush(float *out, long long outSS, long long outCS, const int *outSa
 	IoArgs io{nullptr, out, 0, 0, outSS, outCS, dInSamples, dOutSamples};
 	launchFlushTail(d, io, dAux0, dAux1, st);
 	// stft.reset(0.1) + zero prevInput/output (:456-463)
-	writeSeedCarry(active ? on.data() : nullptr);
-	for (int s = 0; s < S; ++s) if (on[s]) zeroBandState(s, false, true, true);
+	for (int s = 0; s < S; ++s) resetBitsV[s] = on[s] ? (1 | 4 | 8) : 0;
+	resetStreams(resetBitsV.data(), 0);
 	SMST_HIP(hipGetLastError());
 }
 

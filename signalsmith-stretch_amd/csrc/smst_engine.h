@@ -74,6 +74,10 @@ public:
 	void enableProfiling(int mode) { profiling = mode == 1; liveTiming = mode == 2; } // 1: every kernel class, serialised; 2: recurrence kernel in place
 	BatchTimings takeTimings();
 	size_t workspaceBytes() const { return wsBytes; }
+	long allocationEvents() const { return allocEvents; } // test hook: must not move across steady-state process() calls
+	// order the batch's work after everything already enqueued on `other` / make `other` wait for the batch's work so far
+	void waitForStream(hipStream_t other);
+	void signalStream(hipStream_t other);
 	int subBatchStreams() const { return subS; }
 
 	// test hooks: copy state rows to the host (which: 0 input, 1 prevInput, 2 output -> 2*C*M floats; 3 energy -> C*M)
@@ -95,12 +99,23 @@ private:
 	hipStream_t stSynth = nullptr;  // synthesis + emission of the previous tile
 	hipStream_t stGate = nullptr;   // silence-gate reduction + table uploads of the NEXT call, while the previous call still runs
 	// Per-call device tables exist twice: a call fills one set on `stGate` while kernels of the previous call read the other
-	struct CallSet { int *inSamples, *outSamples, *flags, *tileInfo; HopDesc *hops; EmitDesc *emit; size_t hopsCap, emitCap, tileInfoCap; hipEvent_t done; bool used; } callSets[2]{};
+	// ... and so does their PINNED host staging (h*): nothing pageable is handed to an async copy, so the only host
+	// synchronisation of a call is the silence-gate readback
+	struct CallSet {
+		int *inSamples, *outSamples, *flags, *tileInfo; HopDesc *hops; EmitDesc *emit;
+		int *hInSamples, *hOutSamples, *hFlags, *hTileInfo; HopDesc *hHops; EmitDesc *hEmit; float *hEnergy;
+		size_t hopsCap, emitCap, tileInfoCap;
+		hipEvent_t done, tables; bool used;
+	} callSets[2]{};
 	int callCur = 0;
 	hipEvent_t evStart = nullptr, evFeed[2] = {nullptr, nullptr}, evChain[2] = {nullptr, nullptr}, evSynth[2] = {nullptr, nullptr};
 	struct TileBuffers { float2 *Xcur, *Xprev, *OUT, *dump, *map, *peaksT; float4 *REC, *PE; float *ratio, *energyT, *smoothT, *est, *freqEst, *frames; } slots[2]{};
-	bool overlap = true;
+	bool overlap = true, noFuse = false;
 	int subS = 0;
+	// per-call host scratch, kept between calls (no heap traffic in steady state); growth events are counted
+	std::vector<int> hopFirst, hopCount, maxSpanV;
+	std::vector<unsigned char> tileHasV, passV;
+	long allocEvents = 0; // device allocations + pinned allocations + host table growth since construction
 	size_t wsBytes = 0;
 	DevBatch d{};
 	std::vector<StreamSched> sched;
@@ -116,11 +131,19 @@ private:
 	float *dEnergy = nullptr;
 	int *dInSamples = nullptr, *dOutSamples = nullptr, *dFlags = nullptr, *dAux0 = nullptr, *dAux1 = nullptr;
 	HopDesc *dHops = nullptr;
-	size_t hopsCapacity = 0;
 	EmitDesc *dEmit = nullptr;
-	size_t emitCapacity = 0;
 	int *dTileInfo = nullptr;
-	size_t tileInfoCapacity = 0;
+	int *hSeek = nullptr;          // pinned staging of seek()
+	float *hSeekEnergy = nullptr;
+	float *dSeedWp = nullptr; // reset(0.1) window-product seed, device copy
+	hipEvent_t evOrder = nullptr;
+	std::vector<void *> pinned;
+	template <typename T> T *pinnedAlloc(size_t count);
+	void pinnedFree(void *p);
+	void releaseAll();
+	void resetStreams(const int *bitsHost, int allBits); // per-stream bit masks (kResetStreams) or null = allBits for all
+	int *dResetBits = nullptr;
+	std::vector<int> resetBitsV;
 	float *dZeros = nullptr;
 	size_t zerosCapacity = 0;
 	float *dScratchOut = nullptr;
@@ -132,17 +155,17 @@ private:
 
 	template <typename T> T *devAlloc(size_t count);
 	void devFree(void *p);
+	void construct(const FftPlan &plan, long seed);
 	void uploadParams();
 	void allocateWorkspace();
-	void writeSeedCarry(const unsigned char *active);
-	void zeroBandState(int stream, bool input, bool prev, bool output);
 	template <typename F> void timed(double &acc, F &&f);
 };
 
 // error plumbing for the C ABI
 struct Error : std::exception {
 	std::string msg;
-	explicit Error(std::string m) : msg(std::move(m)) {}
+	bool device; // true: a HIP runtime call failed (SMST_ERR_DEVICE); false: a bad argument / state (SMST_ERR_INVALID)
+	explicit Error(std::string m, bool deviceError = false) : msg(std::move(m)), device(deviceError) {}
 	const char *what() const noexcept override { return msg.c_str(); }
 };
 

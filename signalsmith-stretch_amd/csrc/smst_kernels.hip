@@ -2090,6 +2090,43 @@ __global__ __launch_bounds__(256) void kPassThrough(DevBatch d, IoArgs io, const
 	}
 }
 
+// reset() / flush() / first silent block (signalsmith-stretch.h:49-60, :456-463, :244-251) for the selected streams in ONE
+// launch.  Per-stream bit mask: 1 = stft.reset(0.1) (overlap-add sums and input history cleared, window products re-seeded,
+// both halves of the double buffers), 2 / 4 / 8 = clear Band.input / .prevInput / .output.
+__global__ __launch_bounds__(256) void kResetStreams(DevBatch d, const int *__restrict__ flags, int allBits, const float *__restrict__ seedWp) {
+	const int sg = blockIdx.y;
+	const int bits = flags ? flags[sg] : allBits;
+	if (!bits) return;
+	const int i = blockIdx.x*blockDim.x + threadIdx.x;
+	const int CL = d.carryLen, HL = d.histLen, M = d.M, C = d.C;
+	if (bits & 1) {
+		if (i < CL) {
+			const float w = seedWp[i];
+			d.carryWp[0][(size_t)sg*CL + i] = w;
+			d.carryWp[1][(size_t)sg*CL + i] = w;
+		}
+		for (int c = 0; c < C; ++c) {
+			if (i < CL) {
+				d.carrySum[0][((size_t)sg*C + c)*CL + i] = 0.0f;
+				d.carrySum[1][((size_t)sg*C + c)*CL + i] = 0.0f;
+			}
+			if (i < HL) {
+				d.hist[0][((size_t)sg*C + c)*HL + i] = 0.0f;
+				d.hist[1][((size_t)sg*C + c)*HL + i] = 0.0f;
+			}
+		}
+	}
+	if (i < M && (bits & 14)) {
+		const float2 zero = make_float2(0.f, 0.f);
+		for (int c = 0; c < C; ++c) {
+			const size_t o = stateRow(d, sg, c) + i;
+			if (bits & 2) d.stInput[o] = zero;
+			if (bits & 4) d.stPrev[o] = zero;
+			if (bits & 8) d.stOut[o] = zero;
+		}
+	}
+}
+
 // seek(): history = the last B+I samples of the (zero-padded) pre-roll  (signalsmith-stretch.h:140-158)
 __global__ __launch_bounds__(256) void kSeekHistory(DevBatch d, IoArgs io, const int *__restrict__ seekFlags) {
 	const int sg = blockIdx.z, c = blockIdx.y;
@@ -2284,6 +2321,10 @@ void launchPassThrough(const DevBatch &d, const IoArgs &io, const int *passFlags
 	if (bx > 64) bx = 64;
 	if (bx < 1) bx = 1;
 	hipLaunchKernelGGL(kPassThrough, dim3(bx, d.C, d.S), dim3(256), 0, st, d, io, passFlags);
+}
+void launchResetStreams(const DevBatch &d, const int *flags, int allBits, const float *seedWp, hipStream_t st) {
+	const int span = d.carryLen > d.M ? (d.carryLen > d.histLen ? d.carryLen : d.histLen) : (d.M > d.histLen ? d.M : d.histLen);
+	hipLaunchKernelGGL(kResetStreams, dim3(divUp(span, 256), d.S), dim3(256), 0, st, d, flags, allBits, seedWp);
 }
 void launchSeekHistory(const DevBatch &d, const IoArgs &io, const int *seekFlags, hipStream_t st) {
 	hipLaunchKernelGGL(kSeekHistory, dim3(divUp(d.histLen, 256), d.C, d.S), dim3(256), 0, st, d, io, seekFlags);

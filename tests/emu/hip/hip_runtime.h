@@ -83,6 +83,9 @@ static inline hipError_t hipStreamDestroy(hipStream_t) { return 0; }
 static inline hipError_t hipMemGetInfo(size_t *freeB, size_t *totalB) { *freeB = *totalB = (size_t)24 << 30; return 0; }
 static inline hipError_t hipMalloc(void **p, size_t n) { *p = std::calloc(n ? n : 1, 1); return *p ? 0 : 2; }
 static inline hipError_t hipFree(void *p) { std::free(p); return 0; }
+#define hipHostMallocDefault 0
+static inline hipError_t hipHostMalloc(void **p, size_t n, unsigned) { *p = std::calloc(n ? n : 1, 1); return *p ? 0 : 2; }
+static inline hipError_t hipHostFree(void *p) { std::free(p); return 0; }
 static inline hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind) { std::memcpy(d, s, n); return 0; }
 static inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind, hipStream_t) { std::memcpy(d, s, n); return 0; }
 static inline hipError_t hipMemset(void *d, int v, size_t n) { std::memset(d, v, n); return 0; }

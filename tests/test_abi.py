@@ -39,3 +39,39 @@ def test_no_gpu_fails_loudly():
     assert rc != 0 and b"no HIP device" in lib.smst_last_error()
     rc = lib.smst_create(ctypes.byref(h), 0, 0)
     assert rc != 0
+
+
+def _steady_state_allocations(lib, geometry, S=3, C=2, calls=6):
+    """process() must not allocate once it has seen the call pattern (the reference asserts the same of itself:
+    cmd/main-dev.cpp:158-163 "allocated during process()"): device / pinned allocations and host-table growth are counted by
+    the engine; after two warm-up calls (one per double-buffered table set) the count has to stand still."""
+    import numpy as np
+    from conftest import synth_input
+    pkg = package()
+    b = pkg.StretchBatch(S, C, lib=lib, **geometry)
+    I = b.intervalSamples()
+    n = I*10
+    x = np.stack([synth_input(s, C, n*(calls + 2), 48000) for s in range(S)])
+    for k in range(2):
+        b.process(x[:, :, k*n:(k + 1)*n], int(n*1.25))
+    before = b.allocation_events()
+    for k in range(2, 2 + calls):
+        b.process(x[:, :, k*n:(k + 1)*n], int(n*1.25))
+    after = b.allocation_events()
+    b.close()
+    assert after == before, (before, after)
+    assert before > 0
+
+
+def test_process_does_not_allocate_in_steady_state(emu):
+    _steady_state_allocations(emu, dict(block=512, interval=128, split=False))
+
+
+def test_error_codes_distinguish_device_from_argument_errors(emu):
+    """SMST_ERR_INVALID for bad arguments, SMST_ERR_DEVICE for HIP failures -- decided by the error's own kind, not by the text."""
+    h = ctypes.c_void_p()
+    assert emu.smst_batch_create(ctypes.byref(h), 1, 99, 512, 128, 0, 0, 0) == -1   # 99 channels: invalid argument
+    assert emu.smst_batch_create(ctypes.byref(h), 1, 1, 512, 1, 0, 0, 0) == -1      # interval too small for the FFT size
+    assert emu.smst_batch_create(ctypes.byref(h), 1, 2, 512, 128, 0, 0, 0) == 0
+    assert emu.smst_batch_set_transpose_factor(h, 5, 1.0, 0.0) == -1               # stream index out of range
+    emu.smst_batch_destroy(h)

@@ -421,3 +421,8 @@ def test_hop_decisions(hip, ref):
     _report("hop_decisions/config4b", r)
     r = pc.case_hop_magnitudes(hip, ref, CHEAPER96, 8, 1.2, "decisions 8ch", setup=lambda o: o.setTransposeSemitones(-5, 0), hops=40, streams=(0, 2))
     _report("hop_decisions/config5-8ch", r)
+
+
+def test_process_does_not_allocate_in_steady_state_gpu(hip):
+    from test_abi import _steady_state_allocations
+    _steady_state_allocations(hip, dict(preset="default", sample_rate=48000.0), S=16, C=2, calls=4)
