@@ -151,6 +151,11 @@ float smst_ref_get_formant_metric(void *h, float *dst) {
 	std::copy(S.formantMetric.begin(), S.formantMetric.end(), dst);
 	return S.freqEstimate;
 }
+// channel-summed energy and its smoothed version as findPeaks saw them (signalsmith-stretch.h:818-848)
+void smst_ref_get_energy(void *h, float *energy, float *smoothed) {
+	std::copy(S.energy.begin(), S.energy.end(), energy);
+	std::copy(S.smoothedEnergy.begin(), S.smoothedEnergy.end(), smoothed);
+}
 void smst_ref_get_output_map(void *h, float *dst) {
 	for (int b = 0; b < S.bands; ++b) {
 		dst[2*b] = S.outputMap[b].inputBin;

@@ -40,7 +40,7 @@ def lib(path=None):
             smst_ref_flush=[_fp, C.c_long, C.c_int, C.c_float],
             smst_ref_get_bands=[C.c_int, _fp], smst_ref_get_output_map=[_fp], smst_ref_get_window=[_fp],
             smst_ref_get_output_ring=[_fp, _fp], smst_ref_analyse_block=[_fp, _fp],
-            smst_ref_set_bands=[C.c_int, _fp], smst_ref_set_output_ring=[_fp, _fp],
+            smst_ref_set_bands=[C.c_int, _fp], smst_ref_set_output_ring=[_fp, _fp], smst_ref_get_energy=[_fp, _fp],
         ).items():
             f = getattr(L, name)
             f.restype = None
@@ -171,6 +171,12 @@ class RefStretch:
         a = np.zeros(self.bands() + 2, np.float32)
         est = self.L.smst_ref_get_formant_metric(self.h, _p(a))
         return a, float(est)
+
+    def energy(self):
+        """(channel-summed energy, smoothed energy) as findPeaks saw them (signalsmith-stretch.h:818-880)."""
+        e, sm = np.zeros(self.bands(), np.float32), np.zeros(self.bands(), np.float32)
+        self.L.smst_ref_get_energy(self.h, _p(e), _p(sm))
+        return e, sm
 
     def output_map(self):
         a = np.zeros((self.bands(), 2), np.float32)

@@ -77,7 +77,7 @@ def _batch_vs_ref(hip, ref, S, C, sr, n, nout, cfg, preset, label, setup=None, p
         r = pc.make("ref", hip, ref, C, cfg, one)
         o = r.process(xs[s], nouts[s])
         o2 = [pc.make("ref", hip, ref, C, cfg, one).process(pc.perturbed(xs[s], seed), nouts[s]) for seed in pc.SELF_SEEDS]
-        pc.assert_parity(y[s][:, :nouts[s]], o, o2, r.intervalSamples(), "%s stream %d" % (label, s), cap=cap)
+        pc.assert_parity(y[s][:, :nouts[s]], o, o2, r.intervalSamples(), "%s stream %d" % (label, s), cap=cap, require_informative=False)
         # phase-free check that survives decorrelation (SURVEY App. D.2 iv): output energy within 1 %
         ra, rb = np.sqrt(np.mean(y[s][:, :nouts[s]]**2)), np.sqrt(np.mean(o**2))
         assert abs(ra/rb - 1) < 0.01, (label, s, ra, rb)
@@ -220,7 +220,7 @@ def test_staged_producers_equal_gathered(hip, monkeypatch):
 @pytest.mark.gpu
 def test_realtime_quanta(hip, ref):
     pc.case_realtime_quanta(hip, ref)
-    pc.case_realtime_quanta(hip, ref, cfg=D48, quanta=40)
+    pc.case_realtime_quanta(hip, ref, cfg=D48, quanta=120)  # 10.7 hops: past the 5760-sample latency, where there is output to compare
 
 
 @pytest.mark.gpu
@@ -398,7 +398,7 @@ def test_teacher_forced(hip, ref, label, cfg, C, stretch, setup):
     sine / chirp / noise streams of the bench (0, 1, 2).  Also the committed measurement behind PERTURBATION: the
     analysis spectra of the two implementations differ by `analysis` rel-RMS, which an input perturbation of
     sqrt(3)*analysis would produce."""
-    w = pc.case_teacher_forced(hip, ref, cfg, C, stretch, "forced " + label, setup=setup, warm_hops=10, forced_hops=4)
+    w = pc.case_teacher_forced(hip, ref, cfg, C, stretch, "forced " + label, setup=setup, warm_hops=10, forced_hops=8)
     w["equivalent_perturbation"] = 3**0.5*w["analysis"]
     _report("teacher_forced/" + label, w)
     assert w["equivalent_perturbation"] <= pc.PERTURBATION, w
@@ -417,7 +417,7 @@ def test_hop_decisions(hip, ref):
     mapped configs (sine, chirp and noise streams)."""
     r = pc.case_hop_magnitudes(hip, ref, D48, 2, 1.0, "decisions config3", setup=_cfg3, hops=80, streams=(0, 1, 2))
     _report("hop_decisions/config3", r)
-    r = pc.case_hop_magnitudes(hip, ref, D48, 2, 0.75, "decisions config4b", setup=_cfg4b, hops=80, streams=(0, 1, 2), tol=1e-3)
+    r = pc.case_hop_magnitudes(hip, ref, D48, 2, 0.75, "decisions config4b", setup=_cfg4b, hops=80, streams=(0, 1, 2))
     _report("hop_decisions/config4b", r)
     r = pc.case_hop_magnitudes(hip, ref, CHEAPER96, 8, 1.2, "decisions 8ch", setup=lambda o: o.setTransposeSemitones(-5, 0), hops=40, streams=(0, 2))
     _report("hop_decisions/config5-8ch", r)
