@@ -335,6 +335,7 @@ def _crel_trimmed(a, b, drop=0.01):
     return float(np.sqrt(np.sum(keep)/max(np.sum(np.abs(b)**2), 1e-300)))
 
 
+MAP_AGREE = 2e-3    # output-map entries (fractional input bins, up to 3072: ulp 2.4e-4) count as equal within this many bins
 MARGIN_FLIP = 2e-3  # a peak-run boundary decided by less than this (relative) is within reach of the arithmetic difference
 
 
@@ -348,7 +349,7 @@ def _flip_margin(batch, stream, r):
     if m is None:
         return None
     mr = r.output_map()
-    bad = np.nonzero(np.abs(m[:, 0] - mr[:, 0]) > 1e-3*np.maximum(1.0, np.abs(mr[:, 0])))[0]
+    bad = np.nonzero(np.abs(m[:, 0] - mr[:, 0]) > MAP_AGREE)[0]
     if len(bad) == 0:
         return None
     en, sm = r.energy()
@@ -446,6 +447,10 @@ def case_teacher_forced(lib, ref, cfg, channels, stretch, label, setup=None, war
         a = a[~explained]
         if len(a) == 0:
             continue
+        # typical hop against typical hop as well (one pathological hop of the checker must not widen everything: the chirp
+        # stream under formant compensation has one-hop sensitivities from 4e-3 to 1.7 -- amplified near-silent bins)
+        assert np.median(a[:, 0]) <= max(TOL_FORCED_SAMPLES, SELF_FACTOR*np.median(a[:, 1])), (label, streams[i], "median samples", np.median(a[:, 0]), np.median(a[:, 1]))
+        assert np.median(a[:, 2]) <= max(TOL_FORCED_SPECTRUM, SELF_FACTOR*np.median(a[:, 3])), (label, streams[i], "median spectrum", np.median(a[:, 2]), np.median(a[:, 3]))
         tol_samp, tol_spec = max(TOL_FORCED_SAMPLES, SELF_FACTOR*a[:, 1].max()), max(TOL_FORCED_SPECTRUM, SELF_FACTOR*a[:, 3].max())
         assert a[:, 0].max() <= tol_samp, "%s: stream %d: emitted samples rel-RMS %.3e > %.1e (checker's one-hop sensitivity %.1e)" % (label, streams[i], a[:, 0].max(), tol_samp, a[:, 1].max())
         assert a[:, 2].max() <= tol_spec, "%s: stream %d: Band.output rel-RMS %.3e > %.1e (checker's one-hop sensitivity %.1e)" % (label, streams[i], a[:, 2].max(), tol_spec, a[:, 3].max())
@@ -509,7 +514,7 @@ def case_hop_magnitudes(lib, ref, cfg, channels, stretch, label, setup=None, hop
             m = b.debug_map(i)
             if m is not None:
                 mr2 = r.output_map()
-                map_ok += int(np.sum(np.abs(m[:, 0] - mr2[:, 0]) <= 1e-3*np.maximum(1.0, np.abs(mr2[:, 0]))))
+                map_ok += int(np.sum(np.abs(m[:, 0] - mr2[:, 0]) <= MAP_AGREE))
                 map_cells += m.shape[0]
     b.close()
     worst_mag, worst_self = float(errs.max()), float(owns.max())
