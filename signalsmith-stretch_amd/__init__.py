@@ -220,12 +220,13 @@ class StretchBatch:
         _check(self.lib, self.lib.smst_batch_synchronize(self.h))
         self._inflight = []
 
-    def _order_after_torch(self, *tensors):
+    def _order_after_torch(self, *tensors, wait=True):
         """Device-memory calls are asynchronous on the batch's own HIP streams.  Order them after the producer (torch's
         current stream) with an event -- no host synchronisation -- and keep the tensors referenced until the batch's
         stream has drained, so torch's caching allocator cannot recycle their memory while our kernels still use it."""
         import torch
-        _check(self.lib, self.lib.smst_batch_wait_for_stream(self.h, C.c_void_p(torch.cuda.current_stream(tensors[0].device).cuda_stream)))
+        if wait:
+            _check(self.lib, self.lib.smst_batch_wait_for_stream(self.h, C.c_void_p(torch.cuda.current_stream(tensors[0].device).cuda_stream)))
         inflight = getattr(self, "_inflight", [])
         if len(inflight) >= 16:
             self.synchronize()
@@ -258,8 +259,14 @@ class StretchBatch:
         a = np.ascontiguousarray(a)
         return C.c_void_p(a.ctypes.data), a.shape[1]*a.shape[2], a.shape[2], a.shape[2], MEM_HOST, a
 
-    def process(self, x, out_samples, in_samples=None, out=None):
-        """process(inputs, inputSamples, outputs, outputSamples) for every stream (signalsmith-stretch.h:210)."""
+    def process(self, x, out_samples, in_samples=None, out=None, ordered=True):
+        """process(inputs, inputSamples, outputs, outputSamples) for every stream (signalsmith-stretch.h:210).
+
+        Device tensors: with ``ordered`` (default) the call is ordered after torch's current stream (the producer of ``x``) and
+        torch's current stream is ordered after it (consumers of the result) -- by events, without a host synchronisation.
+        That makes consecutive calls wait for each other through torch's stream.  A caller whose inputs are already
+        complete and who synchronises the batch itself before touching the outputs (``bench.py``) passes
+        ``ordered=False`` and keeps the overlap of call n+1's host scheduling with call n's kernels."""
         S, Cn = self.streams, self.channels
         ptr, ss, cs, n, mem, keep = self._describe(x, "input")
         nin, pin = _int_array(n if in_samples is None else in_samples, S)
@@ -277,9 +284,9 @@ class StretchBatch:
         if on < max_out or int(nin.max()) > n:
             raise StretchError("buffer shorter than the requested sample count")
         if mem == MEM_DEVICE:
-            self._order_after_torch(x, out)
+            self._order_after_torch(x, out, wait=ordered)
         _check(self.lib, self.lib.smst_batch_process(self.h, ptr, ss, cs, pin, optr, oss, ocs, pout, mem))
-        if mem == MEM_DEVICE:  # torch ops on `out` issued from here on are ordered after our kernels (no host sync either)
+        if mem == MEM_DEVICE and ordered:  # torch ops on `out` issued from here on are ordered after our kernels (no host sync either)
             import torch
             _check(self.lib, self.lib.smst_batch_signal_stream(self.h, C.c_void_p(torch.cuda.current_stream(out.device).cuda_stream)))
         return out

@@ -1216,7 +1216,7 @@ __device__ __forceinline__ float2 twistAt(const RecordSource<CH, PLAIN> &src, in
 	const float den = fmaxf(ePrev, eNow) + 1e-15f; // :716
 	const float2 down = cmulc(Px, lerpBand(in, lerpIndex(mp.x - stepMul*tfDown), M));
 	const float2 r = cmulc(TW, down);
-	const float inv = 1.0f/den;
+	const float inv = __builtin_amdgcn_rcpf(den); // 1-ulp hardware reciprocal (an IEEE division costs ten instructions per record)
 	return make_float2(r.x*inv, r.y*inv);
 }
 
@@ -1300,7 +1300,7 @@ __device__ __forceinline__ void computeRecord(const DevBatch &d, const HopDesc &
 #pragma unroll
 	for (int c = 0; c < CH; ++c) {
 		f[9 + PC*c] = p[c].x; f[10 + PC*c] = p[c].y;
-		f[11 + PC*c] = sqrtf(e[c]);
+		f[11 + PC*c] = __builtin_amdgcn_sqrtf(e[c]); // 1-ulp hardware square root, no denormal fix-up sequence
 		if (LOCK) {
 			float2 lock = cmulc(p[c], Pm);
 			f[12 + PC*c] = lock.x; f[13 + PC*c] = lock.y;
@@ -1574,7 +1574,23 @@ __device__ __forceinline__ void vocoderProduceStaged(const DevBatch &d, int s, i
 	static_assert(64*(G::LOADS - 1) <= 8*G::ROW_PIECES, "pieces of the row above sit in the last load slot");
 	float4 v[G::LOADS];
 	float2 ve = make_float2(0.f, 0.f);
+	// A block whose windows all lie strictly inside [0, M-2] (nine blocks in ten) needs no clamping on the way in and no
+	// edge selects on the way to LDS.  The bins a wave touches in block n span rows 8*it-1 .. 8*it+7 and window offsets
+	// -2L .. 7+L, so the test is wave-uniform: a scalar branch, no vote.
+	auto interior = [&](int n) {
+		const int lo = BS*n - 2*L - lag*(8*it + 7), hi = BS*n + 7 + L + 1 - lag*(8*it - 1);
+		return lo >= 0 && hi <= M - 2;
+	};
 	auto issue = [&](int n) {
+		if (interior(n)) {
+#pragma unroll
+			for (int i = 0; i < G::LOADS; ++i) {
+				const int sb = BS*n + pbin[i];
+				v[i] = *reinterpret_cast<const float4 *>(psrc[i] + sb); // 8-byte aligned; dword alignment suffices on gfx9
+				if (i == G::LOADS - 1 && pen[i]) ve = *reinterpret_cast<const float2 *>(penergy + sb);
+			}
+			return;
+		}
 #pragma unroll
 		for (int i = 0; i < G::LOADS; ++i) {
 			const int sb = BS*n + pbin[i];
@@ -1586,6 +1602,14 @@ __device__ __forceinline__ void vocoderProduceStaged(const DevBatch &d, int s, i
 		}
 	};
 	auto park = [&](int n) {
+		if (interior(n)) {
+#pragma unroll
+			for (int i = 0; i < G::LOADS; ++i) {
+				const bool en = (i == G::LOADS - 1) && pen[i];
+				if (pok[i]) *reinterpret_cast<float4 *>(sbuf + plds[i]) = en ? make_float4(ve.x, 0.f, ve.y, 0.f) : v[i];
+			}
+			return;
+		}
 #pragma unroll
 		for (int i = 0; i < G::LOADS; ++i) {
 			const int sb = BS*n + pbin[i];
@@ -1654,7 +1678,7 @@ __device__ __forceinline__ void vocoderProduceStaged(const DevBatch &d, int s, i
 				const float den = fmaxf(ePrev, eNow) + 1e-15f;
 				const float2 down = cmulc(Px, lerpIN(mc, lerpIndex(float(bc) - stepMul*tf)));
 				const float2 rr = cmulc(TW, down);
-				const float inv = 1.0f/den;
+				const float inv = __builtin_amdgcn_rcpf(den); // 1-ulp hardware reciprocal (an IEEE division costs ten instructions per record)
 				return make_float2(rr.x*inv, rr.y*inv);
 			};
 			float2 Cc = twist(b + 1, 1.0f), Dc = twist(b + L, float(L));
@@ -1666,7 +1690,7 @@ __device__ __forceinline__ void vocoderProduceStaged(const DevBatch &d, int s, i
 			f[0] = A.x; f[1] = A.y; f[2] = B.x; f[3] = B.y; f[4] = Cc.x; f[5] = Cc.y; f[6] = Dc.x; f[7] = Dc.y;
 			f[8] = __int_as_float(mc);
 #pragma unroll
-			for (int c = 0; c < CH; ++c) { f[9 + 3*c] = p[c].x; f[10 + 3*c] = p[c].y; f[11 + 3*c] = sqrtf(e[c]); }
+			for (int c = 0; c < CH; ++c) { f[9 + 3*c] = p[c].x; f[10 + 3*c] = p[c].y; f[11 + 3*c] = __builtin_amdgcn_sqrtf(e[c]); }
 		}
 #pragma unroll
 		for (int j = 0; j < NCH; ++j) recs[((slot*BS + st)*NCH + j)*64 + ((row + 2*st) & 63)] = make_float4(f[4*j], f[4*j + 1], f[4*j + 2], f[4*j + 3]);

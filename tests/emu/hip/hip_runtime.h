@@ -46,6 +46,7 @@ static inline float __fmul_rn(float a, float b) { return a*b; }
 static inline float __fadd_rn(float a, float b) { return a + b; }
 static inline float __builtin_amdgcn_rsqf(float x) { return 1.0f/std::sqrt(x); }
 static inline float __builtin_amdgcn_rcpf(float x) { return 1.0f/x; }
+static inline float __builtin_amdgcn_sqrtf(float x) { return std::sqrt(x); }
 
 typedef int hipError_t;
 #define hipSuccess 0
