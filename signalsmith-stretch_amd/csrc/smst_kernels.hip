@@ -1373,7 +1373,7 @@ __device__ __forceinline__ float2 makeOutput(float2 phase, float2 input, float s
 template <int CH>
 __global__ __launch_bounds__(64) void kChain(DevBatch d, int sBase, int hopBase) {
 	constexpr int NF = 9 + 3*CH, NCH = (NF + 3)/4;
-	constexpr int PD = (CH <= 2) ? 4 : ((CH <= 4) ? 2 : 1); // prefetch depth (register budget)
+	constexpr int PD = 4; // prefetch depth (one wave per SIMD slot: the register file is not the limit)
 	extern __shared__ __attribute__((aligned(16))) unsigned char smemRaw[];
 	const int R = d.ringSlots, Rm = R - 1;
 	float2 *lds = reinterpret_cast<float2 *>(smemRaw); // ring [CH][R][64], then stage [CH][128]
@@ -1917,6 +1917,185 @@ __global__ __launch_bounds__(64*kVocWaves) __attribute__((amdgpu_waves_per_eu(4,
 }
 
 // ------------------------------------------------------------------------------------------------------
+// K3 fused, 3-8 channels (signalsmith-stretch.h:722-803 for any channel count).  Same organisation as kVocoder -- producer
+// waves compute the records into an LDS ring, wave 0 runs the skewed wavefront, wave 4 drains the results with
+// row-coalesced stores -- with three differences that the channel count forces:
+//   * a record is 9 + 3*CH floats (36 for 8 channels), so a block is 4 steps instead of 8 (2 x 4 x 9 KiB of LDS);
+//   * the consumer's history cannot live in registers (8 steps x CH complex values): each lane keeps its last output per
+//     channel in registers (the b-1 tap) and everything else in an LDS ring [CH][16 bins][64 lanes] indexed by the bin,
+//     which the next lane (the b+1 / b+L taps of the previous hop) and the writer read as well -- so there is no
+//     separate result buffer;
+//   * the producers gather (computeRecord), as the un-fused kPredictB does: same arithmetic, bit-identical results.
+// It replaces kPredictB + kChain, whose records went through HBM (14 MB per stream and tile) and whose recurrence
+// issued CH scattered 8-byte stores per lane and step -- every record prefetch then waited behind those stores
+// (vmcnt counts both on gfx9): 4.4 us per step for 8 channels.
+// ------------------------------------------------------------------------------------------------------
+constexpr int kVocNBlockSteps = 4, kVocNBlocks = 2, kVocNRing = 16;
+
+template <int CH, bool PLAIN, int L>
+__global__ __launch_bounds__(64*kVocWaves) __attribute__((amdgpu_waves_per_eu(4, 4))) void kVocoderN(DevBatch d, int sBase, int hopBase) {
+	constexpr int NF = 9 + 3*CH, NCH = (NF + 3)/4, BS = kVocNBlockSteps, NB = kVocNBlocks, R = kVocNRing, Rm = R - 1;
+	constexpr int NP = kVocWaves - 2;
+	constexpr int lag = L + 1;
+	static_assert(CH >= 3 && CH <= kMaxChannels && L >= 1 && L + BS < R, "ring depth: a slot is rewritten R bins later, the oldest tap is L bins back");
+	extern __shared__ __attribute__((aligned(16))) unsigned char smemRaw[];
+	float4 *recs = reinterpret_cast<float4 *>(smemRaw);                  // [(slot*BS + st)*NCH + j][64 lanes]
+	float2 *ring = reinterpret_cast<float2 *>(recs + NB*BS*NCH*64);      // [CH][R bins][64 lanes]: Band.output of the last R bins of every hop
+	float2 *stage = ring + CH*R*64;                                      // [CH][128]: carried Band.output, 128-bin window
+	volatile int *sync = reinterpret_cast<volatile int *>(stage + CH*128); // [0..NB) units produced, [NB] blocks consumed, [NB+1] result blocks ready, [NB+2] written
+	HopDesc *hopsLds = reinterpret_cast<HopDesc *>(const_cast<int *>(sync) + 16);
+
+	const int s = blockIdx.x, sg = sBase + s;
+	const int nh = d.nHops[s];
+	if (nh == 0) return;
+	const int wave = threadIdx.x >> 6, k = threadIdx.x & 63;
+	const int M = d.M;
+	const int steps = M + lag*(nh - 1);
+	const int chunks = (steps + 63) >> 6;
+	const int totalBlocks = chunks*(64/BS);
+	const float2 *stOut = d.stOut + stateRow(d, sg, 0);
+
+	for (int i = threadIdx.x; i < CH*128; i += blockDim.x) {
+		const int c = i >> 7, bb = i & 127;
+		stage[i] = (bb < M) ? stOut[(size_t)c*M + bb] : make_float2(0.f, 0.f);
+	}
+	for (int i = threadIdx.x; i < CH*R*64; i += blockDim.x) ring[i] = make_float2(0.f, 0.f);
+	if (threadIdx.x <= NB + 2) sync[threadIdx.x] = 0;
+	if (threadIdx.x < 64) hopsLds[threadIdx.x] = d.hops[(size_t)sg*d.hopStride + hopBase + threadIdx.x];
+	__syncthreads();
+
+	if (wave > 0) {
+		if (wave == 4) {
+			// ---------------- writer: 4 consecutive bins of a row = 32 contiguous bytes per channel, two lanes per row
+			const int g = k >> 1, part = k & 1;
+			for (int n = 0; n < totalBlocks; ++n) {
+				while (ldsPeek(&sync[NB + 1]) <= n) __builtin_amdgcn_s_sleep(2);
+				asm volatile("" ::: "memory");
+#pragma unroll
+				for (int pass = 0; pass < 2; ++pass) {
+					const int row = 32*pass + g;
+					const int b0 = BS*n - lag*row + 2*part;
+					const bool ok = row < nh && b0 + 1 >= 0 && b0 < M;
+#pragma unroll
+					for (int c = 0; c < CH; ++c) {
+						const float2 v0 = ring[(c*R + (b0 & Rm))*64 + row], v1 = ring[(c*R + ((b0 + 1) & Rm))*64 + row];
+						if (ok) { // bins outside [0, M) of an active row land in the rows' padding (row pitch M + 32)
+							float2 *dst = d.OUT + rowOf(d, s, row, c) + b0;
+							dst[0] = v0;
+							dst[1] = v1;
+						}
+					}
+				}
+				asm volatile("" ::: "memory");
+				if (k == 0) ldsPost(&sync[NB + 2], n + 1);
+			}
+			return;
+		}
+		// ---------------- producers: 16 rows x 4 steps per wave-pass
+		const int pIndex = wave - 1 - (wave > 4);
+		const int st = k & (BS - 1), r = k/BS;
+		constexpr int ROWS = 64/BS, UNITS = 64/ROWS; // passes per block
+		for (int u = pIndex; u < totalBlocks*UNITS; u += NP) {
+			const int n = u/UNITS, it = u - n*UNITS;
+			const int slot = n%NB;
+			while (n - ldsPeek(&sync[NB]) >= NB) __builtin_amdgcn_s_sleep(2); // slot still being read
+			asm volatile("" ::: "memory");
+			const int row = ROWS*it + r;
+			const int b = BS*n + st - lag*row;
+			float f[NCH*4];
+#pragma unroll
+			for (int j = 0; j < NCH*4; ++j) f[j] = 0.0f;
+			if (row < nh && b >= 0 && b < M && d.debugMode != 1) computeRecord<CH, PLAIN, false, false>(d, hopsLds[row], hopsLds[row > 0 ? row - 1 : 0], s, sg, row, b, f);
+#pragma unroll
+			for (int j = 0; j < NCH; ++j) recs[((slot*BS + st)*NCH + j)*64 + ((row + 2*st) & 63)] = make_float4(f[4*j], f[4*j + 1], f[4*j + 2], f[4*j + 3]);
+			asm volatile("" ::: "memory");
+			if (k == 0) ldsCount(&sync[slot]); // LDS ops of a wave are in order: data first, then the count
+		}
+		return;
+	}
+
+	// ---------------- consumer (wave 0) ----------------
+	__builtin_amdgcn_s_setprio(3);
+	const int kLag = lag*k;
+	float2 pf[CH], own1[CH];
+#pragma unroll
+	for (int c = 0; c < CH; ++c) { pf[c] = make_float2(0.f, 0.f); own1[c] = make_float2(0.f, 0.f); }
+	constexpr int UNITS = BS;
+	for (int ch = 0; ch < chunks; ++ch) {
+		const int tb = ch << 6;
+		if (ch > 0) {
+#pragma unroll
+			for (int c = 0; c < CH; ++c) stage[c*128 + ((tb + 64 + k) & 127)] = pf[c];
+		}
+		{
+			const int bb = tb + 128 + k;
+			const int bc = (bb < M) ? bb : M - 1;
+#pragma unroll
+			for (int c = 0; c < CH; ++c) {
+				float2 v = stOut[(size_t)c*M + bc];
+				pf[c] = (bb < M) ? v : make_float2(0.f, 0.f);
+			}
+		}
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+		for (int blk = 0; blk < 64/BS; ++blk) {
+			const int n = ch*(64/BS) + blk;
+			const int slot = n%NB;
+			const int need = UNITS*(n/NB + 1);
+			while (ldsPeek(&sync[slot]) < need) __builtin_amdgcn_s_sleep(1);
+			// the ring slots this block overwrites (bins 4n .. 4n+3 of every row) last held block n - R/BS: it must be on its way to HBM
+			while (n - ldsPeek(&sync[NB + 2]) >= R/BS) __builtin_amdgcn_s_sleep(1);
+			asm volatile("" ::: "memory");
+			const float4 *blockRecs = recs + (size_t)slot*BS*NCH*64;
+#pragma unroll
+			for (int i = 0; i < BS; ++i) {
+				if (d.debugMode == 2) break; // experiment: consumer only acknowledges blocks
+				const int t = tb + blk*BS + i;
+				float f[NCH*4];
+#pragma unroll
+				for (int j = 0; j < NCH; ++j) {
+					const float4 q = blockRecs[(i*NCH + j)*64 + ((k + 2*i) & 63)];
+					f[4*j] = q.x; f[4*j + 1] = q.y; f[4*j + 2] = q.z; f[4*j + 3] = q.w;
+				}
+				const int b = t - kLag;
+				int mc = __float_as_int(f[8]);
+				mc = (mc < 0) ? 0 : ((mc > CH - 1) ? CH - 1 : mc);
+				float2 o1 = own1[0], pm = make_float2(f[9], f[10]);
+				float sm = f[11];
+#pragma unroll
+				for (int c = 1; c < CH; ++c) {
+					if (c == mc) { o1 = own1[c]; pm = make_float2(f[9 + 3*c], f[10 + 3*c]); sm = f[11 + 3*c]; }
+				}
+				const int ringRow = mc*R;
+				const float2 oL = ring[(ringRow + ((b - L) & Rm))*64 + k];
+				const float2 p1 = (k == 0) ? stage[mc*128 + ((b + 1) & 127)] : ring[(ringRow + ((b + 1) & Rm))*64 + k - 1];
+				const float2 pL = (k == 0) ? stage[mc*128 + ((b + L) & 127)] : ring[(ringRow + ((b + L) & Rm))*64 + k - 1];
+				float2 phi = cmul(oL, make_float2(f[2], f[3]));
+				phi = cadd(phi, cmul(p1, make_float2(f[4], f[5])));
+				phi = cadd(phi, cmul(pL, make_float2(f[6], f[7])));
+				phi = cadd(phi, cmul(o1, make_float2(f[0], f[1])));
+				const float2 om = makeOutput(phi, pm, sm); // :788
+#pragma unroll
+				for (int c = 0; c < CH; ++c) {
+					const float2 pc = make_float2(f[9 + 3*c], f[10 + 3*c]);
+					float2 oc = makeOutput(cmul(om, cmulc(pc, pm)), pc, f[11 + 3*c]); // channel lock, :791-800
+					if (c == mc) oc = om;
+					// cells outside the tile (inactive hop, bin outside [0, M)) have all-zero records, which give exactly zero here
+					own1[c] = oc;
+					ring[(c*R + (b & Rm))*64 + k] = oc;
+				}
+				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+				__builtin_amdgcn_wave_barrier(); // lane k+1 reads what lane k wrote lag-1 .. lag+L-1 steps ago
+				__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+			}
+			asm volatile("" ::: "memory");
+			if (k == 0) { ldsPost(&sync[NB], n + 1); ldsPost(&sync[NB + 1], n + 1); }
+		}
+	}
+}
+
+// ------------------------------------------------------------------------------------------------------
 // K4a: synthesis.  One workgroup per (hop, channel, stream): inverse half-bin-shifted real FFT (gain N),
 // multiply by the synthesis window, store the B-sample frame.  Replaces the copy at
 // signalsmith-stretch.h:384-394 + stft.synthesiseStep (:397-399).
@@ -2286,10 +2465,37 @@ static void launchVocoderT(const DevBatch &d, int sBase, int nStreams, int hopBa
 	default: launchVocoderTL<CH, 7>(d, sBase, nStreams, hopBase, plain, bounded, st); break; // only reached with L == 7 (see fusedSupported)
 	}
 }
-bool fusedSupported(const DevBatch &d) { return d.C <= 2 && d.L >= 2 && d.L <= 7 && d.lag == d.L + 1; }
+template <int CH, int L>
+static void launchVocoderNL(const DevBatch &d, int sBase, int nStreams, int hopBase, bool plain, hipStream_t st) {
+	constexpr int NCH = (9 + 3*CH + 3)/4;
+	const size_t lds = (size_t)kVocNBlocks*kVocNBlockSteps*NCH*64*sizeof(float4) + (size_t)CH*kVocNRing*64*sizeof(float2)
+	                   + (size_t)CH*128*sizeof(float2) + 64 + 64*sizeof(HopDesc);
+	if (plain) hipLaunchKernelGGL((kVocoderN<CH, true, L>), dim3(nStreams), dim3(64*kVocWaves), lds, st, d, sBase, hopBase);
+	else hipLaunchKernelGGL((kVocoderN<CH, false, L>), dim3(nStreams), dim3(64*kVocWaves), lds, st, d, sBase, hopBase);
+}
+template <int CH>
+static void launchVocoderN(const DevBatch &d, int sBase, int nStreams, int hopBase, bool plain, hipStream_t st) {
+	switch (d.L) { // longVerticalStep: 3 (presetCheaper), 4 / 5 (presetDefault at 48 / 44.1 kHz); fusedSupported(): 2 <= L <= 5 here
+	case 2: launchVocoderNL<CH, 2>(d, sBase, nStreams, hopBase, plain, st); break;
+	case 3: launchVocoderNL<CH, 3>(d, sBase, nStreams, hopBase, plain, st); break;
+	case 4: launchVocoderNL<CH, 4>(d, sBase, nStreams, hopBase, plain, st); break;
+	default: launchVocoderNL<CH, 5>(d, sBase, nStreams, hopBase, plain, st); break;
+	}
+}
+bool fusedSupported(const DevBatch &d) {
+	return d.lag == d.L + 1 && d.L >= 2 && d.L <= (d.C <= 2 ? 7 : 5); // other geometries: kPredictB + kChain (records through HBM)
+}
 void launchVocoder(const DevBatch &d, int sBase, int nStreams, int hopBase, bool plain, bool bounded, hipStream_t st) {
-	if (d.C == 1) launchVocoderT<1>(d, sBase, nStreams, hopBase, plain, bounded, st);
-	else launchVocoderT<2>(d, sBase, nStreams, hopBase, plain, bounded, st);
+	switch (d.C) {
+	case 1: launchVocoderT<1>(d, sBase, nStreams, hopBase, plain, bounded, st); return;
+	case 2: launchVocoderT<2>(d, sBase, nStreams, hopBase, plain, bounded, st); return;
+	case 3: launchVocoderN<3>(d, sBase, nStreams, hopBase, plain, st); return;
+	case 4: launchVocoderN<4>(d, sBase, nStreams, hopBase, plain, st); return;
+	case 5: launchVocoderN<5>(d, sBase, nStreams, hopBase, plain, st); return;
+	case 6: launchVocoderN<6>(d, sBase, nStreams, hopBase, plain, st); return;
+	case 7: launchVocoderN<7>(d, sBase, nStreams, hopBase, plain, st); return;
+	default: launchVocoderN<8>(d, sBase, nStreams, hopBase, plain, st); return;
+	}
 }
 void launchPredict(const DevBatch &d, int sBase, int nStreams, int hopBase, int tileHops, bool plain, hipStream_t st) {
 	switch (d.C) {

@@ -220,6 +220,32 @@ def case_channels(lib, ref, channel_counts=(1, 3, 8)):
                        setup=lambda o: o.setTransposeSemitones(2, 0.2))
 
 
+def case_fused_equals_unfused(lib, monkeypatch, channel_counts=(3, 8), geometry=None, n=9000):
+    """The fused recurrence (kVocoder / kVocoderN: records in LDS) against the un-fused one (kPredictB + kChain: records
+    through HBM, SMST_NO_FUSE=1): the same arithmetic in the same order, so bit-identical -- over two calls (carried state)
+    and with a frequency map on half of the streams."""
+    pkg = package()
+    geometry = geometry or dict(block=512, interval=128, split=False)
+    for C in channel_counts:
+        xs = np.stack([synth_input(s, C, n, 48000)*(1 + 0.2*np.arange(C))[:, None].astype(np.float32) for s in range(4)])
+        outs = []
+        for unfused in (False, True):
+            if unfused:
+                monkeypatch.setenv("SMST_NO_FUSE", "1")
+            else:
+                monkeypatch.delenv("SMST_NO_FUSE", raising=False)
+            b = pkg.StretchBatch(4, C, lib=lib, **geometry)
+            b.setTransposeSemitones(3.0, 0.2, stream=1)
+            b.setTransposeSemitones(-4.0, 0.0, stream=3)
+            y1 = np.array(b.process(xs[:, :, :n//3], int(n//3*1.3)), copy=True)
+            y2 = np.array(b.process(xs[:, :, n//3:], int((n - n//3)*1.3)), copy=True)
+            b.close()
+            outs.append(np.concatenate([y1, y2], axis=2))
+        monkeypatch.delenv("SMST_NO_FUSE", raising=False)
+        assert np.abs(outs[0]).max() > 0.05
+        assert np.array_equal(outs[0], outs[1]), (C, float(np.abs(outs[0] - outs[1]).max()))
+
+
 def case_batch_ragged(lib, ref, cfg=SMALL, S=5, n=6000):
     """Batch API: per-stream parameters and ragged lengths; every stream equals its own single-stream reference run."""
     pkg = package()

@@ -426,3 +426,9 @@ def test_hop_decisions(hip, ref):
 def test_process_does_not_allocate_in_steady_state_gpu(hip):
     from test_abi import _steady_state_allocations
     _steady_state_allocations(hip, dict(preset="default", sample_rate=48000.0), S=16, C=2, calls=4)
+
+
+def test_fused_equals_unfused(hip, monkeypatch):
+    """3-8 channels: kVocoderN (records in LDS) is bit-identical to kPredictB + kChain (records through HBM)."""
+    pc.case_fused_equals_unfused(hip, monkeypatch, channel_counts=(1, 2, 3, 4, 5, 6, 7, 8))
+    pc.case_fused_equals_unfused(hip, monkeypatch, channel_counts=(8,), geometry=dict(preset="cheaper", sample_rate=96000.0), n=96000)
