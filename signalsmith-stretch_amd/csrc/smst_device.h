@@ -75,6 +75,8 @@ void launchChain(const DevBatch &d, int sBase, int nStreams, int hopBase, hipStr
 void launchPredictFused(const DevBatch &d, int sBase, int nStreams, int hopBase, int tileHops, bool plain, hipStream_t st);
 void launchVocoder(const DevBatch &d, int sBase, int nStreams, int hopBase, bool plain, bool bounded, hipStream_t st); // bounded: no random time factors in the tile
 bool fusedSupported(const DevBatch &d);
+bool singleHopSupported(const DevBatch &d);
+void launchVocoderOne(const DevBatch &d, int sBase, int nStreams, int hopBase, bool plain, hipStream_t st); // tiles in which no stream has more than one hop
 void launchSynth(const DevBatch &d, int sBase, int nStreams, int hopBase, int tileHops, hipStream_t st);
 void launchEmit(const DevBatch &d, const IoArgs &io, int sBase, int nStreams, int tileIndex, int maxSpan, hipStream_t st);
 void launchCarryFeed(const DevBatch &d, int sBase, int nStreams, int hopBase, bool anyFormants, hipStream_t st);

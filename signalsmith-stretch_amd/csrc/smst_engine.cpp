@@ -153,6 +153,7 @@ void Batch::construct(const FftPlan &plan, long seed) {
 	// environment switches are read once, here
 	if (const char *env = std::getenv("SMST_NO_OVERLAP")) overlap = atoi(env) == 0;
 	noFuse = std::getenv("SMST_NO_FUSE") != nullptr;
+	noSingleHop = std::getenv("SMST_NO_SINGLE_HOP") != nullptr;
 
 	d.S = S; d.C = C; d.B = B; d.I = I; d.M = M; d.N = N; d.L = L; d.T = kTileHops;
 	d.histLen = B + I;
@@ -775,6 +776,7 @@ void Batch::process(const float *in, long long inSS, long long inCS, const int *
 	// hundred waves, instruction-issue bound), `stSynth` synthesis + emission.  Two workspaces alternate, so the bulk
 	// kernels of the next tile fill the machine while the recurrence of the current one is in flight.
 	const bool serial = profiling || !overlap;
+	const bool singleHop = singleHopSupported(d) && !noSingleHop;
 	hipStream_t sF = st, sC = serial ? st : stChain, sS = serial ? st : stSynth;
 	if (!serial) {
 		SMST_HIP(hipEventRecord(evStart, st));
@@ -830,7 +832,8 @@ void Batch::process(const float *in, long long inSS, long long inCS, const int *
 					SMST_HIP(hipEventRecord(liveA, sC));
 				}
 				timed(timings.chainMs, [&] {
-					if (fused) launchVocoder(dd, sBase, ns, hopBase, plain, !th[4], sC);
+					if (fused && tileHops == 1 && singleHop) launchVocoderOne(dd, sBase, ns, hopBase, plain, sC);
+					else if (fused) launchVocoder(dd, sBase, ns, hopBase, plain, !th[4], sC);
 					else launchChain(dd, sBase, ns, hopBase, sC);
 					if (profiling) ++timings.chainLaunches;
 				});

@@ -2096,6 +2096,149 @@ __global__ __launch_bounds__(64*kVocWaves) __attribute__((amdgpu_waves_per_eu(4,
 }
 
 // ------------------------------------------------------------------------------------------------------
+// K3 for single-hop tiles: the real-time calling pattern (one process() per 128-frame render quantum, web/web-wrapper.js:
+// 255-315) fires at most ONE hop per stream and call.  The skewed wavefront then has one active lane per wave, and a
+// 16-wave workgroup holding 127 KB of LDS per stream serialises the streams in rounds of 256 (4.4 ms for 1024 streams).
+// Here a stream costs two waves and 12-30 KB: wave 1 computes the records of 64 consecutive bins per pass (lane = bin:
+// every load is one contiguous row segment) and stores the finished results; wave 0 runs the bin recurrence of the single
+// hop with its history in registers (every lane computes the same chain; lane 0 publishes).  All streams of a call are
+// resident at once (1024 stereo streams: 12 waves per CU), so the latency of the hop is the length of ONE chain.
+// Same records (computeRecord), same order of operations as kVocoder / kVocoderN: bit-identical results.
+// ------------------------------------------------------------------------------------------------------
+constexpr int kVocOneBlock = 64;
+
+template <int CH, bool PLAIN, int L>
+__global__ __launch_bounds__(128) void kVocoderOne(DevBatch d, int sBase, int hopBase) {
+	constexpr int NF = 9 + 3*CH, NCH = (NF + 3)/4, BS = kVocOneBlock, NB = 2;
+	extern __shared__ __attribute__((aligned(16))) unsigned char smemRaw[];
+	float4 *recs = reinterpret_cast<float4 *>(smemRaw);                  // [slot][step][NCH]
+	float2 *outRing = reinterpret_cast<float2 *>(recs + NB*BS*NCH);      // [2 blocks][CH][BS]: results on their way to HBM
+	float2 *stage = outRing + 2*CH*BS;                                   // [CH][128]: carried Band.output, 128-bin window
+	volatile int *sync = reinterpret_cast<volatile int *>(stage + CH*128); // [0] blocks produced, [1] blocks consumed (= result blocks ready)
+	HopDesc *hopLds = reinterpret_cast<HopDesc *>(const_cast<int *>(sync) + 4);
+
+	const int s = blockIdx.x, sg = sBase + s;
+	if (d.nHops[s] == 0) return;
+	const int wave = threadIdx.x >> 6, k = threadIdx.x & 63;
+	const int M = d.M;
+	const int totalBlocks = (M + BS - 1)/BS;
+	const float2 *stOut = d.stOut + stateRow(d, sg, 0);
+	for (int i = threadIdx.x; i < CH*128; i += blockDim.x) {
+		const int c = i >> 7, bb = i & 127;
+		stage[i] = (bb < M) ? stOut[(size_t)c*M + bb] : make_float2(0.f, 0.f);
+	}
+	if (threadIdx.x < 2) sync[threadIdx.x] = 0;
+	if (threadIdx.x == 0) hopLds[0] = d.hops[(size_t)sg*d.hopStride + hopBase];
+	__syncthreads();
+
+	if (wave == 1) {
+		// ---------------- producer + writer ----------------
+		auto writeBlock = [&](int n) {
+			while (ldsPeek(&sync[1]) <= n) __builtin_amdgcn_s_sleep(2);
+			asm volatile("" ::: "memory");
+			const int b = BS*n + k;
+#pragma unroll
+			for (int c = 0; c < CH; ++c) {
+				const float2 v = outRing[((n & 1)*CH + c)*BS + k];
+				if (b < M) d.OUT[rowOf(d, s, 0, c) + b] = v;
+			}
+		};
+		for (int n = 0; n < totalBlocks; ++n) {
+			// slot n % 2 last held block n - 2, which the consumer has finished once block n - 1's results could be written
+			const int b = BS*n + k;
+			float f[NCH*4];
+#pragma unroll
+			for (int j = 0; j < NCH*4; ++j) f[j] = 0.0f;
+			if (b < M) computeRecord<CH, PLAIN, false, false>(d, hopLds[0], hopLds[0], s, sg, 0, b, f);
+			float4 *dst = recs + ((size_t)(n % NB)*BS + k)*NCH;
+#pragma unroll
+			for (int j = 0; j < NCH; ++j) dst[j] = make_float4(f[4*j], f[4*j + 1], f[4*j + 2], f[4*j + 3]);
+			asm volatile("" ::: "memory");
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+			__builtin_amdgcn_wave_barrier();
+			if (k == 0) ldsPost(&sync[0], n + 1);
+			if (n > 0) writeBlock(n - 1);
+		}
+		writeBlock(totalBlocks - 1);
+		return;
+	}
+
+	// ---------------- consumer (wave 0): every lane runs the chain of hop 0; lane 0 publishes ----------------
+	__builtin_amdgcn_s_setprio(3);
+	float2 pf[CH];
+	float2 h[8][CH];
+#pragma unroll
+	for (int c = 0; c < CH; ++c) {
+		pf[c] = make_float2(0.f, 0.f);
+#pragma unroll
+		for (int i = 0; i < 8; ++i) h[i][c] = make_float2(0.f, 0.f);
+	}
+	for (int n = 0; n < totalBlocks; ++n) {
+		const int tb = n*BS;
+		if (n > 0) {
+#pragma unroll
+			for (int c = 0; c < CH; ++c) stage[c*128 + ((tb + 64 + k) & 127)] = pf[c];
+		}
+		{
+			const int bb = tb + 128 + k;
+			const int bc = (bb < M) ? bb : M - 1;
+#pragma unroll
+			for (int c = 0; c < CH; ++c) {
+				float2 v = stOut[(size_t)c*M + bc];
+				pf[c] = (bb < M) ? v : make_float2(0.f, 0.f);
+			}
+		}
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+		while (ldsPeek(&sync[0]) <= n) __builtin_amdgcn_s_sleep(1);
+		asm volatile("" ::: "memory");
+		const float4 *blockRecs = recs + (size_t)(n % NB)*BS*NCH;
+		float2 *blockOut = outRing + (size_t)(n & 1)*CH*BS;
+		for (int i8 = 0; i8 < BS/8; ++i8) {
+#pragma unroll
+			for (int i = 0; i < 8; ++i) {
+				const int step = i8*8 + i, b = tb + step;
+				float f[NCH*4];
+#pragma unroll
+				for (int j = 0; j < NCH; ++j) {
+					const float4 q = blockRecs[step*NCH + j];
+					f[4*j] = q.x; f[4*j + 1] = q.y; f[4*j + 2] = q.z; f[4*j + 3] = q.w;
+				}
+				int mc = __float_as_int(f[8]);
+				mc = (mc < 0) ? 0 : ((mc > CH - 1) ? CH - 1 : mc);
+				float2 o1 = h[(i + 7) & 7][0], oL = h[(i + 8 - L) & 7][0];
+				float2 p1 = stage[(b + 1) & 127], pL = stage[(b + L) & 127];
+				float2 pm = make_float2(f[9], f[10]);
+				float sm = f[11];
+#pragma unroll
+				for (int c = 1; c < CH; ++c) {
+					const float2 p1c = stage[c*128 + ((b + 1) & 127)], pLc = stage[c*128 + ((b + L) & 127)];
+					if (c == mc) { o1 = h[(i + 7) & 7][c]; oL = h[(i + 8 - L) & 7][c]; p1 = p1c; pL = pLc; pm = make_float2(f[9 + 3*c], f[10 + 3*c]); sm = f[11 + 3*c]; }
+				}
+				float2 phi = cmul(oL, make_float2(f[2], f[3]));
+				phi = cadd(phi, cmul(p1, make_float2(f[4], f[5])));
+				phi = cadd(phi, cmul(pL, make_float2(f[6], f[7])));
+				phi = cadd(phi, cmul(o1, make_float2(f[0], f[1])));
+				const float2 om = makeOutput(phi, pm, sm); // :788
+#pragma unroll
+				for (int c = 0; c < CH; ++c) {
+					const float2 pc = make_float2(f[9 + 3*c], f[10 + 3*c]);
+					float2 oc = makeOutput(cmul(om, cmulc(pc, pm)), pc, f[11 + 3*c]); // channel lock, :791-800
+					if (c == mc) oc = om;
+					h[i][c] = oc; // bins past the last one have all-zero records, which give exactly zero
+					if (k == 0) blockOut[c*BS + step] = oc;
+				}
+			}
+		}
+		asm volatile("" ::: "memory");
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		if (k == 0) ldsPost(&sync[1], n + 1);
+	}
+}
+
+// ------------------------------------------------------------------------------------------------------
 // K4a: synthesis.  One workgroup per (hop, channel, stream): inverse half-bin-shifted real FFT (gain N),
 // multiply by the synthesis window, store the B-sample frame.  Replaces the copy at
 // signalsmith-stretch.h:384-394 + stft.synthesiseStep (:397-399).
@@ -2480,6 +2623,36 @@ static void launchVocoderN(const DevBatch &d, int sBase, int nStreams, int hopBa
 	case 3: launchVocoderNL<CH, 3>(d, sBase, nStreams, hopBase, plain, st); break;
 	case 4: launchVocoderNL<CH, 4>(d, sBase, nStreams, hopBase, plain, st); break;
 	default: launchVocoderNL<CH, 5>(d, sBase, nStreams, hopBase, plain, st); break;
+	}
+}
+template <int CH, int L>
+static void launchVocoderOneL(const DevBatch &d, int sBase, int nStreams, int hopBase, bool plain, hipStream_t st) {
+	constexpr int NCH = (9 + 3*CH + 3)/4;
+	const size_t lds = (size_t)2*kVocOneBlock*NCH*sizeof(float4) + (size_t)2*CH*kVocOneBlock*sizeof(float2) + (size_t)CH*128*sizeof(float2) + 16 + sizeof(HopDesc);
+	if (plain) hipLaunchKernelGGL((kVocoderOne<CH, true, L>), dim3(nStreams), dim3(128), lds, st, d, sBase, hopBase);
+	else hipLaunchKernelGGL((kVocoderOne<CH, false, L>), dim3(nStreams), dim3(128), lds, st, d, sBase, hopBase);
+}
+template <int CH>
+static void launchVocoderOneT(const DevBatch &d, int sBase, int nStreams, int hopBase, bool plain, hipStream_t st) {
+	switch (d.L) {
+	case 2: launchVocoderOneL<CH, 2>(d, sBase, nStreams, hopBase, plain, st); break;
+	case 3: launchVocoderOneL<CH, 3>(d, sBase, nStreams, hopBase, plain, st); break;
+	case 4: launchVocoderOneL<CH, 4>(d, sBase, nStreams, hopBase, plain, st); break;
+	default: launchVocoderOneL<CH, 5>(d, sBase, nStreams, hopBase, plain, st); break;
+	}
+}
+// single-hop tiles (every stream fires at most one hop): see kVocoderOne.  Same geometries as the fused 3-8 channel kernel.
+bool singleHopSupported(const DevBatch &d) { return d.lag == d.L + 1 && d.L >= 2 && d.L <= 5; }
+void launchVocoderOne(const DevBatch &d, int sBase, int nStreams, int hopBase, bool plain, hipStream_t st) {
+	switch (d.C) {
+	case 1: launchVocoderOneT<1>(d, sBase, nStreams, hopBase, plain, st); return;
+	case 2: launchVocoderOneT<2>(d, sBase, nStreams, hopBase, plain, st); return;
+	case 3: launchVocoderOneT<3>(d, sBase, nStreams, hopBase, plain, st); return;
+	case 4: launchVocoderOneT<4>(d, sBase, nStreams, hopBase, plain, st); return;
+	case 5: launchVocoderOneT<5>(d, sBase, nStreams, hopBase, plain, st); return;
+	case 6: launchVocoderOneT<6>(d, sBase, nStreams, hopBase, plain, st); return;
+	case 7: launchVocoderOneT<7>(d, sBase, nStreams, hopBase, plain, st); return;
+	default: launchVocoderOneT<8>(d, sBase, nStreams, hopBase, plain, st); return;
 	}
 }
 bool fusedSupported(const DevBatch &d) {

@@ -246,6 +246,31 @@ def case_fused_equals_unfused(lib, monkeypatch, channel_counts=(3, 8), geometry=
         assert np.array_equal(outs[0], outs[1]), (C, float(np.abs(outs[0] - outs[1]).max()))
 
 
+def case_single_hop_chunks(lib, geometry=None, channel_counts=(1, 2, 3), hops=15, setup=None):
+    """Calls that fire ONE hop each (the real-time pattern) run the single-hop recurrence kernel (kVocoderOne); one call with
+    all the hops runs the skewed-wavefront kernels.  Same records, same order of operations: bit-identical outputs."""
+    pkg = package()
+    geometry = geometry or dict(block=512, interval=128, split=False)
+    for C in channel_counts:
+        b = pkg.StretchBatch(3, C, lib=lib, **geometry)
+        if setup:
+            setup(b)
+        I = b.intervalSamples()
+        n_out, n_in = hops*I, (hops*I*4)//5
+        assert n_in*5 == n_out*4  # an exact ratio, so that chunk boundaries fall on the one-call time map (no .5 roundings)
+        xs = np.stack([synth_input(s, C, n_in, 48000)*(1 + 0.3*np.arange(C))[:, None].astype(np.float32) for s in range(3)])
+        whole = np.array(b.process(xs, n_out), copy=True)
+        b.reset()
+        parts = []
+        for k in range(hops):  # the same time map as the single call: input chunk k ends where hop k+1's window ends
+            lo, hi = int(round(k*I*float(n_in)/n_out)), int(round((k + 1)*I*float(n_in)/n_out))
+            parts.append(np.array(b.process(xs[:, :, lo:hi], I, in_samples=hi - lo), copy=True))
+        b.close()
+        chunked = np.concatenate(parts, axis=2)
+        assert np.abs(whole).max() > 0.05
+        assert np.array_equal(whole, chunked), (C, float(np.abs(whole - chunked).max()))
+
+
 def case_batch_ragged(lib, ref, cfg=SMALL, S=5, n=6000):
     """Batch API: per-stream parameters and ragged lengths; every stream equals its own single-stream reference run."""
     pkg = package()

@@ -68,3 +68,8 @@ def test_hop_magnitudes_small(emu, ref):
 
 def test_fused_equals_unfused(emu, monkeypatch):
     pc.case_fused_equals_unfused(emu, monkeypatch, channel_counts=(2, 3, 5))
+
+
+def test_single_hop_chunks(emu):
+    pc.case_single_hop_chunks(emu)
+    pc.case_single_hop_chunks(emu, channel_counts=(2,), setup=lambda b: b.setTransposeSemitones(5, 0.2))

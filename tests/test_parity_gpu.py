@@ -432,3 +432,12 @@ def test_fused_equals_unfused(hip, monkeypatch):
     """3-8 channels: kVocoderN (records in LDS) is bit-identical to kPredictB + kChain (records through HBM)."""
     pc.case_fused_equals_unfused(hip, monkeypatch, channel_counts=(1, 2, 3, 4, 5, 6, 7, 8))
     pc.case_fused_equals_unfused(hip, monkeypatch, channel_counts=(8,), geometry=dict(preset="cheaper", sample_rate=96000.0), n=96000)
+
+
+def test_single_hop_chunks(hip):
+    """kVocoderOne (single-hop tiles, the real-time pattern) is bit-identical to the skewed-wavefront kernels."""
+    pc.case_single_hop_chunks(hip, channel_counts=(1, 2, 3, 8))
+    pc.case_single_hop_chunks(hip, geometry=dict(preset="default", sample_rate=48000.0), channel_counts=(2,), hops=10)
+    pc.case_single_hop_chunks(hip, geometry=dict(preset="default", sample_rate=48000.0), channel_counts=(2,), hops=10,
+                              setup=lambda b: (b.setTransposeSemitones(4, 8000/48000), b.setFormantFactor(1, True), b.setFormantBase(200/48000)))
+    pc.case_single_hop_chunks(hip, geometry=dict(preset="cheaper", sample_rate=96000.0), channel_counts=(8,), hops=5)

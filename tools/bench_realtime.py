@@ -29,7 +29,7 @@ def main():
         for q in range(args.quanta + 50):
             xin = x[:, :, q*n_in:(q + 1)*n_in]
             t0 = time.perf_counter()
-            b.process(xin, Q, out=y)
+            b.process(xin, Q, out=y, ordered=False)  # inputs complete, the batch is synchronised right below
             b.synchronize()
             if q >= 50:
                 times.append(time.perf_counter() - t0)
