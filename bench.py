@@ -83,6 +83,7 @@ def main():
     ap.add_argument("--stretch", type=float, default=1.5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-serial-pass", action="store_true", help="skip the extra, serialised per-kernel-class profiling call (used under rocprofv3, so that every launch it sees is an in-place one)")
+    ap.add_argument("--half-state", action="store_true", help="BASELINE config 5 'fp16 internal': carried state and overlap-add sums stored in fp16 (SMST_FLAG_HALF_STATE)")
     ap.add_argument("--config", default="2", choices=["2", "3", "4", "4b", "5"],
                     help="BASELINE.json config (default 2 = the one the headline metric is quoted on; the others are "
                          "reported in DESIGN.md, they are not the bench line)")
@@ -121,7 +122,7 @@ def main():
     S = args.streams
     n_in = int(args.seconds*sr_cfg)
     n_out = int(round(n_in*args.stretch))
-    batch = pkg.StretchBatch(S, C, preset=preset, sample_rate=sr_cfg, device=local_rank, seed=rank)
+    batch = pkg.StretchBatch(S, C, preset=preset, sample_rate=sr_cfg, device=local_rank, seed=rank, half_state=args.half_state)
     if setup:
         setup(batch)
     if per_stream:  # config 5: per-stream random stretch 0.75-1.5x and +-12 st
@@ -231,7 +232,7 @@ def main():
             "metric": "Msamples/sec (in+out) at 48kHz stereo presetDefault",
             "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed/args.steps*1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "f32", "data": "synthetic", "state_storage": "f16" if args.half_state else "f32",
             "config": {"workload": ("BASELINE configs[1]: %d stereo streams per GPU, 48 kHz, presetDefault, %.2fx stretch, fp32, "
                                     "%.0f s input per stream per step, device-resident I/O" % (S, args.stretch, args.seconds))
                        if args.config == "2" else "BASELINE config %s (not the headline): %d streams x %d ch per GPU, %d Hz, preset %s, %.0f s per step"

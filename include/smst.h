@@ -38,6 +38,13 @@ extern "C" {
 #define SMST_ERR_DEVICE (-2)   /* HIP runtime error (no GPU, out of memory, launch failure) */
 #define SMST_ERR_SHORT (-3)    /* exact(): input shorter than outputSeekLength (signalsmith-stretch.h:471-480) */
 
+/* creation flags (smst_batch_create_ex / smst_batch_create_preset_ex) */
+#define SMST_FLAG_HALF_STATE 1u /* BASELINE config 5 "fp16 internal": the state that outlives a tile -- Band.output (as half2),
+                                 * Prediction.energy (as the half of its square root) and the overlap-add partial sums (as half) -- is
+                                 * STORED in fp16; every computation stays fp32.  The reference has no such mode (Sample is float or
+                                 * double, signalsmith-stretch.h:34): results agree with it in the magnitude domain to ~1e-3 and are
+                                 * no longer bit-identical across different chunkings of the same audio. */
+
 #define SMST_MEM_HOST 0
 #define SMST_MEM_DEVICE 1
 
@@ -101,6 +108,10 @@ int smst_batch_create(smst_batch **out, int streams, int channels, int blockSamp
 /* preset: 0 = presetDefault (block = 0.12 sr, interval = 0.03 sr), 1 = presetCheaper (0.1 sr, 0.04 sr) */
 int smst_batch_create_preset(smst_batch **out, int streams, int channels, int preset, float sampleRate,
                              int split, int device, long seed);
+int smst_batch_create_ex(smst_batch **out, int streams, int channels, int blockSamples, int intervalSamples,
+                         int split, int device, long seed, unsigned flags);
+int smst_batch_create_preset_ex(smst_batch **out, int streams, int channels, int preset, float sampleRate,
+                                int split, int device, long seed, unsigned flags);
 void smst_batch_destroy(smst_batch *b);
 
 int smst_batch_streams(const smst_batch *b);
@@ -112,6 +123,7 @@ int smst_batch_bands(const smst_batch *b);
 int smst_batch_input_latency(const smst_batch *b);
 int smst_batch_output_latency(const smst_batch *b);
 int smst_batch_seek_length(const smst_batch *b);
+int smst_batch_half_state(const smst_batch *b); /* 1 if created with SMST_FLAG_HALF_STATE */
 int smst_batch_output_seek_length(const smst_batch *b, float playbackRate);
 long long smst_batch_workspace_bytes(const smst_batch *b);
 

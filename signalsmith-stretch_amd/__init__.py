@@ -57,6 +57,8 @@ _SIGNATURES = {
     # batch
     "smst_batch_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_long]),
     "smst_batch_create_preset": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_long]),
+    "smst_batch_create_ex": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_long, C.c_uint]),
+    "smst_batch_create_preset_ex": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_long, C.c_uint]),
     "smst_batch_destroy": (None, [C.c_void_p]),
     "smst_batch_streams": (C.c_int, [C.c_void_p]),
     "smst_batch_channels": (C.c_int, [C.c_void_p]),
@@ -67,6 +69,7 @@ _SIGNATURES = {
     "smst_batch_input_latency": (C.c_int, [C.c_void_p]),
     "smst_batch_output_latency": (C.c_int, [C.c_void_p]),
     "smst_batch_seek_length": (C.c_int, [C.c_void_p]),
+    "smst_batch_half_state": (C.c_int, [C.c_void_p]),
     "smst_batch_output_seek_length": (C.c_int, [C.c_void_p, C.c_float]),
     "smst_batch_workspace_bytes": (_ll, [C.c_void_p]),
     "smst_batch_reset": (C.c_int, [C.c_void_p]),
@@ -167,15 +170,17 @@ class StretchBatch:
     """
 
     def __init__(self, streams, channels, block=None, interval=None, split=None, preset=None, sample_rate=None,
-                 device=0, seed=0, lib=None):
+                 device=0, seed=0, lib=None, half_state=False):
+        """half_state: store the carried per-bin state and the overlap-add sums in fp16 (SMST_FLAG_HALF_STATE, include/smst.h)."""
         self.lib = lib if lib is not None else load_library()
         h = C.c_void_p()
+        flags = 1 if half_state else 0
         if preset is not None:
             code = {"default": 0, "cheaper": 1}[preset]
-            rc = self.lib.smst_batch_create_preset(C.byref(h), streams, channels, code, float(sample_rate),
-                                                   -1 if split is None else int(split), device, seed)
+            rc = self.lib.smst_batch_create_preset_ex(C.byref(h), streams, channels, code, float(sample_rate),
+                                                      -1 if split is None else int(split), device, seed, flags)
         else:
-            rc = self.lib.smst_batch_create(C.byref(h), streams, channels, int(block), int(interval), int(bool(split)), device, seed)
+            rc = self.lib.smst_batch_create_ex(C.byref(h), streams, channels, int(block), int(interval), int(bool(split)), device, seed, flags)
         _check(self.lib, rc)
         self.h = h
         self.streams, self.channels, self.device = streams, channels, device

@@ -74,17 +74,27 @@ int smst_device_count(void) {
 // ---------------------------------------------------------------------------------------------------------
 // batch API
 // ---------------------------------------------------------------------------------------------------------
-int smst_batch_create(smst_batch **out, int streams, int channels, int block, int interval, int split, int device, long seed) {
+int smst_batch_create_ex(smst_batch **out, int streams, int channels, int block, int interval, int split, int device, long seed, unsigned flags) {
 	if (!out) return fail("null output pointer");
 	SMST_TRY
+	if (flags & ~unsigned(SMST_FLAG_HALF_STATE)) throw smst::Error("unknown creation flag");
 	int n = 0;
 	if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) throw smst::Error("hipGetDeviceCount: no HIP device available (the gfx950 path has no CPU fallback)", true);
 	if (device < 0 || device >= n) throw smst::Error("device ordinal out of range");
 	std::unique_ptr<smst_batch> b(new smst_batch());
-	b->engine.reset(new Batch(streams, channels, block, interval, split != 0, device, seed));
+	b->engine.reset(new Batch(streams, channels, block, interval, split != 0, device, seed, (flags & SMST_FLAG_HALF_STATE) != 0));
 	*out = b.release();
 	return SMST_OK;
 	SMST_CATCH
+}
+int smst_batch_create(smst_batch **out, int streams, int channels, int block, int interval, int split, int device, long seed) {
+	return smst_batch_create_ex(out, streams, channels, block, interval, split, device, seed, 0u);
+}
+int smst_batch_create_preset_ex(smst_batch **out, int streams, int channels, int preset, float sampleRate, int split, int device, long seed, unsigned flags) {
+	// signalsmith-stretch.h:63-68 (float products truncated to int by configure's int parameters)
+	if (preset == 0) return smst_batch_create_ex(out, streams, channels, int(sampleRate*0.12), int(sampleRate*0.03), split < 0 ? 0 : split, device, seed, flags);
+	if (preset == 1) return smst_batch_create_ex(out, streams, channels, int(sampleRate*0.1), int(sampleRate*0.04), split < 0 ? 1 : split, device, seed, flags);
+	return fail("unknown preset");
 }
 int smst_batch_create_preset(smst_batch **out, int streams, int channels, int preset, float sampleRate, int split, int device, long seed) {
 	// signalsmith-stretch.h:63-68 (float products truncated to int by configure's int parameters)
@@ -104,6 +114,7 @@ BATCH_Q(smst_batch_bands, b->engine->bands())
 BATCH_Q(smst_batch_input_latency, b->engine->inputLatency())
 BATCH_Q(smst_batch_output_latency, b->engine->outputLatency())
 BATCH_Q(smst_batch_seek_length, b->engine->seekLength())
+BATCH_Q(smst_batch_half_state, b->engine->halfPrecisionState() ? 1 : 0)
 int smst_batch_output_seek_length(const smst_batch *b, float rate) { if (!b || !b->engine) return fail("null batch"); return b->engine->outputSeekLength(rate); }
 long long smst_batch_workspace_bytes(const smst_batch *b) { if (!b || !b->engine) return fail("null batch"); return (long long)b->engine->workspaceBytes(); }
 

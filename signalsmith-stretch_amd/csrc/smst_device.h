@@ -18,6 +18,7 @@ struct DevBatch {
 	int histCur, carryCur;        // which half of the double buffers is current
 	int debugMode;                // SMST_DEBUG_MODE experiments (0 = product behaviour)
 	int feedSerial;               // SMST_FEED_SERIAL: bin-by-bin feed recurrences (kFeedSerial) instead of the scan form
+	int halfState;                // carried Band.output / Prediction.energy / overlap-add sums stored in fp16 (BASELINE config 5 "fp16 internal")
 	int noStage;                  // SMST_NO_STAGE: producers of the fused kernel gather from HBM even where staging applies
 	FftPlan plan;
 	// constant tables

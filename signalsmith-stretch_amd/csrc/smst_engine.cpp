@@ -103,8 +103,8 @@ void Batch::devFree(void *p) {
 	hipFree(p);
 }
 
-Batch::Batch(int streams, int channels, int block, int interval, bool splitComputation, int device, long seed)
-	: S(streams), C(channels), B(block), I(interval), split(splitComputation), dev(device) {
+Batch::Batch(int streams, int channels, int block, int interval, bool splitComputation, int device, long seed, bool halfPrecisionState)
+	: S(streams), C(channels), B(block), I(interval), split(splitComputation), halfState(halfPrecisionState), dev(device) {
 	// geometry first: nothing below may throw before the HIP objects exist, and everything after is covered by the
 	// clean-up in the catch block (a throwing constructor does not run the destructor)
 	if (S < 1 || C < 1 || C > kMaxChannels || B < 4 || I < 1 || I > B) throw Error("invalid configuration (need 1..8 channels, interval <= block)");
@@ -165,6 +165,7 @@ void Batch::construct(const FftPlan &plan, long seed) {
 	d.ringSlots = ring;
 	d.plan = plan;
 	d.mapTableLen = 0;
+	d.halfState = halfState ? 1 : 0;
 	d.debugMode = 0;
 	if (const char *env = std::getenv("SMST_DEBUG_MODE")) d.debugMode = atoi(env);
 	d.noStage = std::getenv("SMST_NO_STAGE") != nullptr;
@@ -263,12 +264,15 @@ void Batch::construct(const FftPlan &plan, long seed) {
 	const size_t bandRows = (size_t)S*C*M;
 	d.stInput = devAlloc<float2>(bandRows);
 	d.stPrev = devAlloc<float2>(bandRows);
-	d.stOut = devAlloc<float2>(bandRows);
-	d.stEnergy = devAlloc<float>(bandRows);
-	SMST_HIP(hipMemset(d.stEnergy, 0, bandRows*sizeof(float)));
+	// carried state that the fp16 option narrows (the typed pointers then address half-sized allocations; every access goes
+	// through the accessors at the top of smst_kernels.hip)
+	const size_t stateScale = halfState ? 2 : 1;
+	d.stOut = reinterpret_cast<float2 *>(devAlloc<unsigned char>(bandRows*sizeof(float2)/stateScale));
+	d.stEnergy = reinterpret_cast<float *>(devAlloc<unsigned char>(bandRows*sizeof(float)/stateScale));
+	SMST_HIP(hipMemset(d.stEnergy, 0, bandRows*sizeof(float)/stateScale));
 	for (int h = 0; h < 2; ++h) {
 		d.hist[h] = devAlloc<float>((size_t)S*C*d.histLen);
-		d.carrySum[h] = devAlloc<float>((size_t)S*C*d.carryLen);
+		d.carrySum[h] = reinterpret_cast<float *>(devAlloc<unsigned char>((size_t)S*C*d.carryLen*sizeof(float)/stateScale));
 		d.carryWp[h] = devAlloc<float>((size_t)S*d.carryLen);
 	}
 	d.stFreq = devAlloc<float>((size_t)S*2);
@@ -1019,31 +1023,54 @@ void Batch::outputSeek(const float *in, long long inSS, long long inCS, const in
 void Batch::debugGetState(int stream, int which, float *dst) {
 	SMST_HIP(hipSetDevice(dev));
 	SMST_HIP(hipStreamSynchronize(st));
-	const size_t off = (size_t)stream*C*M;
+	const size_t off = (size_t)stream*C*M, n = (size_t)C*M;
+	if (halfState && (which == 2 || which == 3)) { // fp16 storage: widen on the host (energy is stored as its square root)
+		const size_t count = which == 2 ? 2*n : n;
+		std::vector<half_t> tmp(count);
+		const half_t *src = which == 2 ? reinterpret_cast<const half_t *>(d.stOut) + 2*off : reinterpret_cast<const half_t *>(d.stEnergy) + off;
+		SMST_HIP(hipMemcpy(tmp.data(), src, count*sizeof(half_t), hipMemcpyDeviceToHost));
+		for (size_t i = 0; i < count; ++i) { const float v = float(tmp[i]); dst[i] = which == 3 ? v*v : v; }
+		return;
+	}
 	if (which == 3) {
-		SMST_HIP(hipMemcpy(dst, d.stEnergy + off, (size_t)C*M*sizeof(float), hipMemcpyDeviceToHost));
+		SMST_HIP(hipMemcpy(dst, d.stEnergy + off, n*sizeof(float), hipMemcpyDeviceToHost));
 		return;
 	}
 	const float2 *src = which == 0 ? d.stInput : (which == 1 ? d.stPrev : d.stOut);
-	SMST_HIP(hipMemcpy(dst, src + off, (size_t)C*M*sizeof(float2), hipMemcpyDeviceToHost));
+	SMST_HIP(hipMemcpy(dst, src + off, n*sizeof(float2), hipMemcpyDeviceToHost));
 }
 void Batch::debugSetState(int stream, int which, const float *src) {
 	if (stream < 0 || stream >= S || which < 0 || which > 3) throw Error("debugSetState: bad stream / selector");
 	SMST_HIP(hipSetDevice(dev));
 	SMST_HIP(hipStreamSynchronize(st));
-	const size_t off = (size_t)stream*C*M;
+	const size_t off = (size_t)stream*C*M, n = (size_t)C*M;
+	if (halfState && (which == 2 || which == 3)) {
+		const size_t count = which == 2 ? 2*n : n;
+		std::vector<half_t> tmp(count);
+		for (size_t i = 0; i < count; ++i) tmp[i] = half_t(which == 3 ? std::sqrt(std::max(src[i], 0.0f)) : src[i]);
+		half_t *dst = which == 2 ? reinterpret_cast<half_t *>(d.stOut) + 2*off : reinterpret_cast<half_t *>(d.stEnergy) + off;
+		SMST_HIP(hipMemcpy(dst, tmp.data(), count*sizeof(half_t), hipMemcpyHostToDevice));
+		return;
+	}
 	if (which == 3) {
-		SMST_HIP(hipMemcpy(d.stEnergy + off, src, (size_t)C*M*sizeof(float), hipMemcpyHostToDevice));
+		SMST_HIP(hipMemcpy(d.stEnergy + off, src, n*sizeof(float), hipMemcpyHostToDevice));
 		return;
 	}
 	float2 *dst = which == 0 ? d.stInput : (which == 1 ? d.stPrev : d.stOut);
-	SMST_HIP(hipMemcpy(dst + off, src, (size_t)C*M*sizeof(float2), hipMemcpyHostToDevice));
+	SMST_HIP(hipMemcpy(dst + off, src, n*sizeof(float2), hipMemcpyHostToDevice));
 }
 void Batch::debugSetCarry(int stream, const float *sums, const float *products) {
 	if (stream < 0 || stream >= S) throw Error("debugSetCarry: bad stream");
 	SMST_HIP(hipSetDevice(dev));
 	SMST_HIP(hipStreamSynchronize(st));
-	SMST_HIP(hipMemcpy(d.carrySum[d.carryCur] + (size_t)stream*C*d.carryLen, sums, (size_t)C*d.carryLen*sizeof(float), hipMemcpyHostToDevice));
+	const size_t n = (size_t)C*d.carryLen, off = (size_t)stream*n;
+	if (halfState) {
+		std::vector<half_t> tmp(n);
+		for (size_t i = 0; i < n; ++i) tmp[i] = half_t(sums[i]);
+		SMST_HIP(hipMemcpy(reinterpret_cast<half_t *>(d.carrySum[d.carryCur]) + off, tmp.data(), n*sizeof(half_t), hipMemcpyHostToDevice));
+	} else {
+		SMST_HIP(hipMemcpy(d.carrySum[d.carryCur] + off, sums, n*sizeof(float), hipMemcpyHostToDevice));
+	}
 	SMST_HIP(hipMemcpy(d.carryWp[d.carryCur] + (size_t)stream*d.carryLen, products, (size_t)d.carryLen*sizeof(float), hipMemcpyHostToDevice));
 }
 bool Batch::debugGetMap(int stream, float *dst) {
@@ -1058,7 +1085,14 @@ bool Batch::debugGetMap(int stream, float *dst) {
 void Batch::debugGetCarry(int stream, float *sums, float *products) {
 	SMST_HIP(hipSetDevice(dev));
 	SMST_HIP(hipStreamSynchronize(st));
-	SMST_HIP(hipMemcpy(sums, d.carrySum[d.carryCur] + (size_t)stream*C*d.carryLen, (size_t)C*d.carryLen*sizeof(float), hipMemcpyDeviceToHost));
+	const size_t n = (size_t)C*d.carryLen, off = (size_t)stream*n;
+	if (halfState) {
+		std::vector<half_t> tmp(n);
+		SMST_HIP(hipMemcpy(tmp.data(), reinterpret_cast<const half_t *>(d.carrySum[d.carryCur]) + off, n*sizeof(half_t), hipMemcpyDeviceToHost));
+		for (size_t i = 0; i < n; ++i) sums[i] = float(tmp[i]);
+	} else {
+		SMST_HIP(hipMemcpy(sums, d.carrySum[d.carryCur] + off, n*sizeof(float), hipMemcpyDeviceToHost));
+	}
 	SMST_HIP(hipMemcpy(products, d.carryWp[d.carryCur] + (size_t)stream*d.carryLen, (size_t)d.carryLen*sizeof(float), hipMemcpyDeviceToHost));
 }
 

@@ -30,7 +30,7 @@ struct BatchTimings { // filled when profiling is enabled (hipEvent pairs around
 
 class Batch {
 public:
-	Batch(int streams, int channels, int block, int interval, bool split, int device, long seed);
+	Batch(int streams, int channels, int block, int interval, bool split, int device, long seed, bool halfState = false);
 	~Batch();
 	Batch(const Batch &) = delete;
 	Batch &operator=(const Batch &) = delete;
@@ -43,6 +43,7 @@ public:
 	int fftSamples() const { return N; }
 	int bands() const { return M; }
 	bool splitComputation() const { return split; }
+	bool halfPrecisionState() const { return halfState; }
 	int inputLatency() const { return B - B/2; }
 	int outputLatency() const { return B/2 + (split ? I : 0); }
 	int seekLength() const { return B + I; }
@@ -93,6 +94,7 @@ public:
 private:
 	int S, C, B, I, N, M, L;
 	bool split;
+	bool halfState = false; // carried Band.output / Prediction.energy / overlap-add sums in fp16 (fp32 arithmetic throughout)
 	int dev;
 	hipStream_t st = nullptr;       // feed-forward kernels + everything the caller synchronises on
 	hipStream_t stChain = nullptr;  // the bin recurrence (few waves, latency-bound): overlaps with the bulk kernels

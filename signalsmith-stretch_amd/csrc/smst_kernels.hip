@@ -35,6 +35,47 @@ __device__ __forceinline__ float2 cconj(float2 a) { return make_float2(a.x, -a.y
 __device__ __forceinline__ float2 mulI(float2 a) { return make_float2(-a.y, a.x); }
 __device__ __forceinline__ float2 mulNegI(float2 a) { return make_float2(a.y, -a.x); }
 
+// ------------------------------------------------------------------------------------------------------
+// Carried per-stream state in fp32 or -- opt-in per batch (BASELINE config 5 "fp16 internal") -- in fp16: Band.output as
+// half2, Prediction.energy as the half of its SQUARE ROOT (energies reach 1e6 and would overflow fp16; amplitudes do
+// not), overlap-add partial sums as half.  All arithmetic stays fp32: these accessors convert at the load / store.
+// d.halfState is uniform over the launch, so the branches below never diverge.
+// ------------------------------------------------------------------------------------------------------
+struct CarriedOutput { // Band.output after the previous tile's last hop, rows [C][M] of one stream
+	const void *base;
+	bool half;
+	__device__ __forceinline__ float2 operator[](size_t i) const {
+		if (half) { const Half2 h = static_cast<const Half2 *>(base)[i]; return make_float2(float(h.x), float(h.y)); }
+		return static_cast<const float2 *>(base)[i];
+	}
+};
+__device__ __forceinline__ CarriedOutput carriedOutput(const DevBatch &d, int sGlobal) {
+	const size_t row = ((size_t)sGlobal*d.C)*(size_t)d.M;
+	CarriedOutput r;
+	r.half = d.halfState != 0;
+	r.base = r.half ? static_cast<const void *>(reinterpret_cast<const Half2 *>(d.stOut) + row) : static_cast<const void *>(d.stOut + row);
+	return r;
+}
+__device__ __forceinline__ void storeCarriedOutput(const DevBatch &d, size_t i, float2 v) {
+	if (d.halfState) { Half2 h; h.x = half_t(v.x); h.y = half_t(v.y); reinterpret_cast<Half2 *>(d.stOut)[i] = h; }
+	else d.stOut[i] = v;
+}
+__device__ __forceinline__ float loadCarriedEnergy(const DevBatch &d, size_t i) { // Prediction.energy of the previous tile's last hop
+	if (d.halfState) { const float a = float(reinterpret_cast<const half_t *>(d.stEnergy)[i]); return a*a; }
+	return d.stEnergy[i];
+}
+__device__ __forceinline__ void storeCarriedEnergy(const DevBatch &d, size_t i, float e) {
+	if (d.halfState) reinterpret_cast<half_t *>(d.stEnergy)[i] = half_t(__builtin_amdgcn_sqrtf(e));
+	else d.stEnergy[i] = e;
+}
+__device__ __forceinline__ float loadCarrySum(const DevBatch &d, int buf, size_t i) {
+	return d.halfState ? float(reinterpret_cast<const half_t *>(d.carrySum[buf])[i]) : d.carrySum[buf][i];
+}
+__device__ __forceinline__ void storeCarrySum(const DevBatch &d, int buf, size_t i, float v) {
+	if (d.halfState) reinterpret_cast<half_t *>(d.carrySum[buf])[i] = half_t(v);
+	else d.carrySum[buf][i] = v;
+}
+
 __device__ __forceinline__ size_t rowOf(const DevBatch &d, int s, int k, int c) {
 	return ((size_t)((size_t)s*d.T + k)*d.C + c)*(size_t)d.Mp; // Mp: padded row pitch (keeps lane strides off powers of two)
 }
@@ -1212,7 +1253,10 @@ __device__ __forceinline__ float2 twistAt(const RecordSource<CH, PLAIN> &src, in
 	const float2 Px = make_float2(pe.x, pe.y);
 	const float2 TW = cmul(rotB, cmulc(Px, Q));
 	const float eNow = pe.z;
-	const float ePrev = (PLAIN && inPrevHop) ? cnorm(inPrevHop[bc]) : EprevRow[(size_t)bc*eprevStride];
+	float ePrev;
+	if (PLAIN && inPrevHop) ePrev = cnorm(inPrevHop[bc]);
+	else if (d.halfState && eprevStride == 1) ePrev = loadCarriedEnergy(d, (size_t)(EprevRow - d.stEnergy) + bc); // the tile's first hop: carried fp16 state
+	else ePrev = EprevRow[(size_t)bc*eprevStride];
 	const float den = fmaxf(ePrev, eNow) + 1e-15f; // :716
 	const float2 down = cmulc(Px, lerpBand(in, lerpIndex(mp.x - stepMul*tfDown), M));
 	const float2 r = cmulc(TW, down);
@@ -1389,7 +1433,7 @@ __global__ __launch_bounds__(64) void kChain(DevBatch d, int sBase, int hopBase)
 	const size_t recPitch = d.recPitch;
 	float2 *OUT = d.OUT + rowOf(d, s, active ? k : 0, 0);
 	float2 *dump = d.dump + (size_t)s*CH*64 + k; // where lanes outside their bin range park their stores
-	const float2 *stOut = d.stOut + stateRow(d, sg, 0);
+	const CarriedOutput stOut = carriedOutput(d, sg);
 
 	for (int i = k; i < CH*R*64; i += 64) lds[i] = make_float2(0.f, 0.f);
 	for (int c = 0; c < CH; ++c) { // prologue: stage bins [0,128) of the carried output
@@ -1522,6 +1566,15 @@ struct StageGeom {
 	static constexpr int ROWS = 9; // local rows -1..7
 };
 
+// two adjacent entries of a carried Prediction.energy row (`row` points into d.stEnergy as if it were fp32; element index i)
+__device__ __forceinline__ float2 loadEnergyPair(const DevBatch &d, const float *row, int i) {
+	if (d.halfState) {
+		const size_t e = (size_t)(row - d.stEnergy) + i;
+		return make_float2(loadCarriedEnergy(d, e), loadCarriedEnergy(d, e + 1));
+	}
+	return *reinterpret_cast<const float2 *>(row + i);
+}
+
 template <int CH, int L, int NB, int NP>
 __device__ __forceinline__ void vocoderProduceStaged(const DevBatch &d, int s, int sg, int nh, int pIndex, int k, int totalBlocks,
                                                      float4 *recs, volatile int *sync, const HopDesc *hopsLds, float2 *sbuf) {
@@ -1587,7 +1640,7 @@ __device__ __forceinline__ void vocoderProduceStaged(const DevBatch &d, int s, i
 			for (int i = 0; i < G::LOADS; ++i) {
 				const int sb = BS*n + pbin[i];
 				v[i] = *reinterpret_cast<const float4 *>(psrc[i] + sb); // 8-byte aligned; dword alignment suffices on gfx9
-				if (i == G::LOADS - 1 && pen[i]) ve = *reinterpret_cast<const float2 *>(penergy + sb);
+				if (i == G::LOADS - 1 && pen[i]) ve = loadEnergyPair(d, penergy, sb);
 			}
 			return;
 		}
@@ -1598,7 +1651,7 @@ __device__ __forceinline__ void vocoderProduceStaged(const DevBatch &d, int s, i
 			v[i] = *reinterpret_cast<const float4 *>(psrc[i] + cb); // 8-byte aligned; dword alignment suffices on gfx9
 			// pieces of the carried energy (row above hop 0; only the last slot can hold them) are 2 floats: kept in their own
 			// registers until park(), so that no select waits for the loads here
-			if (i == G::LOADS - 1 && pen[i]) ve = *reinterpret_cast<const float2 *>(penergy + cb);
+			if (i == G::LOADS - 1 && pen[i]) ve = loadEnergyPair(d, penergy, cb);
 		}
 	};
 	auto park = [&](int n) {
@@ -1733,7 +1786,7 @@ __global__ __launch_bounds__(64*kVocWaves) __attribute__((amdgpu_waves_per_eu(4,
 	const int steps = M + lag*(nh - 1);
 	const int chunks = (steps + 63) >> 6;
 	const int totalBlocks = chunks*(64/BS);
-	const float2 *stOut = d.stOut + stateRow(d, sg, 0);
+	const CarriedOutput stOut = carriedOutput(d, sg);
 
 	// prologue (all waves): stage bins [0,128) of the carried Band.output, clear the hand-off words, cache the hop table
 	for (int i = threadIdx.x; i < CH*128; i += blockDim.x) {
@@ -1953,7 +2006,7 @@ __global__ __launch_bounds__(64*kVocWaves) __attribute__((amdgpu_waves_per_eu(4,
 	const int steps = M + lag*(nh - 1);
 	const int chunks = (steps + 63) >> 6;
 	const int totalBlocks = chunks*(64/BS);
-	const float2 *stOut = d.stOut + stateRow(d, sg, 0);
+	const CarriedOutput stOut = carriedOutput(d, sg);
 
 	for (int i = threadIdx.x; i < CH*128; i += blockDim.x) {
 		const int c = i >> 7, bb = i & 127;
@@ -2122,7 +2175,7 @@ __global__ __launch_bounds__(128) void kVocoderOne(DevBatch d, int sBase, int ho
 	const int wave = threadIdx.x >> 6, k = threadIdx.x & 63;
 	const int M = d.M;
 	const int totalBlocks = (M + BS - 1)/BS;
-	const float2 *stOut = d.stOut + stateRow(d, sg, 0);
+	const CarriedOutput stOut = carriedOutput(d, sg);
 	for (int i = threadIdx.x; i < CH*128; i += blockDim.x) {
 		const int c = i >> 7, bb = i & 127;
 		stage[i] = (bb < M) ? stOut[(size_t)c*M + bb] : make_float2(0.f, 0.f);
@@ -2290,18 +2343,17 @@ __global__ __launch_bounds__(256) void kEmit(DevBatch d, IoArgs io, int sBase, i
 	if (i0 >= total) return;
 	const int B = d.B, I = d.I;
 	const size_t carryRow = ((size_t)sg*d.C + c)*(size_t)CL;
-	const float *carrySumOld = d.carrySum[d.carryCur] + carryRow;
 	const float *carryWpOld = d.carryWp[d.carryCur] + (size_t)sg*CL;
 	float sum[4], wp[4];
-	if (i0 + 3 < CL) {
-		const float4 a = *reinterpret_cast<const float4 *>(carrySumOld + i0), b = *reinterpret_cast<const float4 *>(carryWpOld + i0);
+	if (i0 + 3 < CL && !d.halfState) {
+		const float4 a = *reinterpret_cast<const float4 *>(d.carrySum[d.carryCur] + carryRow + i0), b = *reinterpret_cast<const float4 *>(carryWpOld + i0);
 		sum[0] = a.x; sum[1] = a.y; sum[2] = a.z; sum[3] = a.w;
 		wp[0] = b.x; wp[1] = b.y; wp[2] = b.z; wp[3] = b.w;
 	} else {
 #pragma unroll
 		for (int j = 0; j < 4; ++j) {
 			const int i = i0 + j;
-			sum[j] = (i < CL) ? carrySumOld[i] : 0.0f;
+			sum[j] = (i < CL) ? loadCarrySum(d, d.carryCur, carryRow + i) : 0.0f;
 			wp[j] = (i < CL) ? carryWpOld[i] : 1e-30f;
 		}
 	}
@@ -2359,7 +2411,7 @@ __global__ __launch_bounds__(256) void kEmit(DevBatch d, IoArgs io, int sBase, i
 			if (i < span) {
 				out[i] = sum[j]/wp[j];
 			} else if (i < total) {
-				d.carrySum[d.carryCur ^ 1][carryRow + (i - span)] = sum[j];
+				storeCarrySum(d, d.carryCur ^ 1, carryRow + (i - span), sum[j]);
 				if (c == 0) d.carryWp[d.carryCur ^ 1][(size_t)sg*CL + (i - span)] = wp[j];
 			}
 		}
@@ -2384,7 +2436,7 @@ __global__ __launch_bounds__(256) void kCarryFeed(DevBatch d, int sBase, int hop
 	{
 		const HopDesc hl = d.hops[(size_t)sg*d.hopStride + hopBase + nh - 1];
 		const bool plain = !(hl.flags & (HOP_MAPPED | HOP_FORMANTS));
-		d.stEnergy[stateRow(d, sg, c) + b] = plain ? cnorm(inputRow(d, hl, s, sg, c)[b]) : d.PE[rowOf(d, s, nh - 1, c) + b].z;
+		storeCarriedEnergy(d, stateRow(d, sg, c) + b, plain ? cnorm(inputRow(d, hl, s, sg, c)[b]) : d.PE[rowOf(d, s, nh - 1, c) + b].z);
 	}
 	if (anyFormants && b == 0 && c == 0) { // a serial walk over the tile's hops: skipped for tiles without formant processing
 		float w = d.stFreq[2*sg], wt = d.stFreq[2*sg + 1];
@@ -2406,7 +2458,7 @@ __global__ __launch_bounds__(256) void kCarryOut(DevBatch d, int sBase) {
 	const int b = blockIdx.x*blockDim.x + threadIdx.x;
 	const int nh = d.nHops[s];
 	if (nh == 0 || b >= d.M) return;
-	d.stOut[stateRow(d, sg, c) + b] = d.OUT[rowOf(d, s, nh - 1, c) + b];
+	storeCarriedOutput(d, stateRow(d, sg, c) + b, d.OUT[rowOf(d, s, nh - 1, c) + b]);
 }
 
 // Input history for the next call: the last B+I samples of (history ++ this call's input)  (copyInput, :215-229,:418)
@@ -2453,8 +2505,8 @@ __global__ __launch_bounds__(256) void kResetStreams(DevBatch d, const int *__re
 		}
 		for (int c = 0; c < C; ++c) {
 			if (i < CL) {
-				d.carrySum[0][((size_t)sg*C + c)*CL + i] = 0.0f;
-				d.carrySum[1][((size_t)sg*C + c)*CL + i] = 0.0f;
+				storeCarrySum(d, 0, ((size_t)sg*C + c)*CL + i, 0.0f);
+				storeCarrySum(d, 1, ((size_t)sg*C + c)*CL + i, 0.0f);
 			}
 			if (i < HL) {
 				d.hist[0][((size_t)sg*C + c)*HL + i] = 0.0f;
@@ -2468,7 +2520,7 @@ __global__ __launch_bounds__(256) void kResetStreams(DevBatch d, const int *__re
 			const size_t o = stateRow(d, sg, c) + i;
 			if (bits & 2) d.stInput[o] = zero;
 			if (bits & 4) d.stPrev[o] = zero;
-			if (bits & 8) d.stOut[o] = zero;
+			if (bits & 8) storeCarriedOutput(d, o, zero);
 		}
 	}
 }
@@ -2512,12 +2564,12 @@ __global__ __launch_bounds__(64) void kFlushTail(DevBatch d, IoArgs io, const in
 	}
 	__syncthreads();
 	for (int c = 0; c < d.C; ++c) {
-		const float *sumRow = d.carrySum[d.carryCur] + ((size_t)sg*d.C + c)*(size_t)CL;
+		const size_t sumRow = ((size_t)sg*d.C + c)*(size_t)CL;
 		float *y = io.out + (size_t)sg*io.outStreamStride + (size_t)c*io.outChannelStride + outOffset[sg];
 		for (int i = threadIdx.x; i < tail; i += blockDim.x) {
 			int a = off + i, r = off + 2*tail - 1 - i;
-			float va = (a < CL) ? sumRow[a]/wpRow[a] : 0.0f;
-			float vr = (r < CL) ? sumRow[r]/wpRow[r] : 0.0f;
+			float va = (a < CL) ? loadCarrySum(d, d.carryCur, sumRow + a)/wpRow[a] : 0.0f;
+			float vr = (r < CL) ? loadCarrySum(d, d.carryCur, sumRow + r)/wpRow[r] : 0.0f;
 			y[i] = va - vr;
 		}
 	}
@@ -2532,7 +2584,8 @@ __global__ __launch_bounds__(256) void kAddPreRoll(DevBatch d, const float *__re
 	const int idx = offsets[sg] + i;
 	if (idx >= CL) return;
 	const float v = -preRoll[((size_t)sg*d.C + c)*(size_t)length + (length - 1 - i)];
-	d.carrySum[d.carryCur][((size_t)sg*d.C + c)*(size_t)CL + idx] += v*d.carryWp[d.carryCur][(size_t)sg*CL + idx];
+	const size_t e = ((size_t)sg*d.C + c)*(size_t)CL + idx;
+	storeCarrySum(d, d.carryCur, e, loadCarrySum(d, d.carryCur, e) + v*d.carryWp[d.carryCur][(size_t)sg*CL + idx]);
 }
 
 // ------------------------------------------------------------------------------------------------------

@@ -54,6 +54,10 @@ struct StreamParams {
 	int pad;
 };
 
+// fp16 storage of the carried state (opt-in per batch): fp32 <-> half conversions only, no half arithmetic
+typedef _Float16 half_t;
+struct Half2 { half_t x, y; };
+
 struct FftPlan {
 	int H;      // complex FFT length = fftSamples/2 = bands
 	int N;      // fftSamples

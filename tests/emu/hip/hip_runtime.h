@@ -48,6 +48,45 @@ static inline float __builtin_amdgcn_rsqf(float x) { return 1.0f/std::sqrt(x); }
 static inline float __builtin_amdgcn_rcpf(float x) { return 1.0f/x; }
 static inline float __builtin_amdgcn_sqrtf(float x) { return std::sqrt(x); }
 
+// IEEE binary16 storage type (round to nearest even), standing in for the compiler's _Float16 (g++ 11 has none on x86)
+struct EmuHalf {
+	uint16_t bits;
+	EmuHalf() : bits(0) {}
+	explicit EmuHalf(float f) {
+		uint32_t x; std::memcpy(&x, &f, 4);
+		const uint32_t sign = (x >> 16) & 0x8000u;
+		const int32_t exp = int32_t((x >> 23) & 0xff) - 127 + 15;
+		uint32_t man = x & 0x7fffffu;
+		if (((x >> 23) & 0xff) == 0xff) { bits = uint16_t(sign | 0x7c00u | (man ? 0x200u : 0)); return; }
+		if (exp >= 31) { bits = uint16_t(sign | 0x7c00u); return; }
+		if (exp <= 0) {
+			if (exp < -10) { bits = uint16_t(sign); return; }
+			man |= 0x800000u;
+			const int shift = 14 - exp;
+			uint32_t h = man >> shift;
+			const uint32_t rem = man & ((1u << shift) - 1), halfway = 1u << (shift - 1);
+			if (rem > halfway || (rem == halfway && (h & 1))) ++h;
+			bits = uint16_t(sign | h);
+			return;
+		}
+		uint32_t h = (uint32_t(exp) << 10) | (man >> 13);
+		const uint32_t rem = man & 0x1fffu;
+		if (rem > 0x1000u || (rem == 0x1000u && (h & 1))) ++h;
+		bits = uint16_t(sign | h);
+	}
+	operator float() const {
+		const uint32_t sign = uint32_t(bits & 0x8000u) << 16;
+		uint32_t exp = (bits >> 10) & 0x1f, man = bits & 0x3ffu, x;
+		if (exp == 0) {
+			if (man == 0) x = sign;
+			else { int e = -1; do { ++e; man <<= 1; } while (!(man & 0x400u)); x = sign | uint32_t(127 - 15 - e) << 23 | (man & 0x3ffu) << 13; }
+		} else if (exp == 31) x = sign | 0x7f800000u | (man << 13);
+		else x = sign | (exp + 127 - 15) << 23 | (man << 13);
+		float f; std::memcpy(&f, &x, 4); return f;
+	}
+};
+#define _Float16 EmuHalf
+
 typedef int hipError_t;
 #define hipSuccess 0
 typedef struct EmuStream *hipStream_t;

@@ -271,6 +271,53 @@ def case_single_hop_chunks(lib, geometry=None, channel_counts=(1, 2, 3), hops=15
         assert np.array_equal(whole, chunked), (C, float(np.abs(whole - chunked).max()))
 
 
+TOL_HALF_MAGNITUDE = 2e-3  # fp16 state: |output| per hop vs the fp32 checker (half has 11 significant bits: 4.9e-4 per value)
+
+
+def case_half_state(lib, ref, cfg, channels, stretch, label, setup=None, hops=30, streams=(0, 1, 2)):
+    """BASELINE config 5 "fp16 internal" (SMST_FLAG_HALF_STATE): Band.output, Prediction.energy and the overlap-add sums that
+    outlive a tile are stored in fp16, arithmetic stays fp32.  The reference has no such mode, so the comparison is against
+    the fp32 checker in the magnitude domain: hop by hop (every call fires one hop, so the state
+    goes through fp16 between ALL hops -- the worst case) |output| within TOL_HALF_MAGNITUDE, the output level within 1 %,
+    and the samples of the first ten hops (phase errors of 5e-4 rad per hop, amplified by the recurrence) within 5 %."""
+    pkg = package()
+    sr = int(cfg.get("sample_rate", 48000))
+    S = len(streams)
+    kw = dict(preset=cfg["preset"], sample_rate=cfg.get("sample_rate", 48000.0)) if cfg.get("preset") in ("default", "cheaper") else \
+        dict(block=cfg["block"], interval=cfg["interval"], split=cfg.get("split", False))
+    b = pkg.StretchBatch(S, channels, lib=lib, half_state=True, **kw)
+    assert b.lib.smst_batch_half_state(b.h) == 1
+    refs = [make("ref", lib, ref, channels, cfg, setup) for _ in streams]
+    if setup:
+        setup(b)
+    I = b.intervalSamples()
+    n_in = _hop_io(I, stretch, hops)[1] + 8
+    xs = np.stack([synth_input(s, channels, n_in, sr) for s in streams])
+    ys, os_ = [], []
+    worst = 0.0
+    for k in range(hops):
+        lo, hi = _hop_io(I, stretch, k)
+        ys.append(np.array(b.process(xs[:, :, lo:hi] if hi > lo else np.zeros((S, channels, 1), np.float32), I, in_samples=hi - lo), copy=True))
+        outs = [r.process(xs[i][:, lo:hi], I) for i, r in enumerate(refs)]
+        os_.append(np.stack(outs))
+        if k >= 4:
+            for i, r in enumerate(refs):
+                e = rel_rms(np.abs(b.debug_state(i, 2)), np.abs(r.bands_complex(2)))
+                worst = max(worst, e)
+                assert e <= TOL_HALF_MAGNITUDE, "%s: stream %d hop %d: |output| rel-RMS %.3e" % (label, streams[i], k, e)
+    b.close()
+    y, o = np.concatenate(ys, axis=2), np.concatenate(os_, axis=2)
+    early = slice(0, min(hops, 10)*I)
+    figures = dict(magnitude=worst, level=0.0, early_samples=0.0)
+    for i in range(S):
+        ra, rb = np.sqrt(np.mean(y[i]**2)), np.sqrt(np.mean(o[i]**2))
+        figures["level"] = max(figures["level"], abs(ra/rb - 1))
+        figures["early_samples"] = max(figures["early_samples"], rel_rms(y[i][:, early], o[i][:, early]))
+        assert abs(ra/rb - 1) < 0.01, (label, streams[i], ra, rb)
+    assert figures["early_samples"] < 5e-2, (label, figures)
+    return figures
+
+
 def case_batch_ragged(lib, ref, cfg=SMALL, S=5, n=6000):
     """Batch API: per-stream parameters and ragged lengths; every stream equals its own single-stream reference run."""
     pkg = package()

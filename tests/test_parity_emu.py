@@ -73,3 +73,8 @@ def test_fused_equals_unfused(emu, monkeypatch):
 def test_single_hop_chunks(emu):
     pc.case_single_hop_chunks(emu)
     pc.case_single_hop_chunks(emu, channel_counts=(2,), setup=lambda b: b.setTransposeSemitones(5, 0.2))
+
+
+def test_half_state(emu, ref):
+    print(pc.case_half_state(emu, ref, pc.SMALL, 2, 1.5, "half plain"))
+    print(pc.case_half_state(emu, ref, pc.SMALL_SPLIT, 3, 1.2, "half 3ch split pitch", setup=lambda o: o.setTransposeSemitones(-5, 0)))

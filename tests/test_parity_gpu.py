@@ -441,3 +441,27 @@ def test_single_hop_chunks(hip):
     pc.case_single_hop_chunks(hip, geometry=dict(preset="default", sample_rate=48000.0), channel_counts=(2,), hops=10,
                               setup=lambda b: (b.setTransposeSemitones(4, 8000/48000), b.setFormantFactor(1, True), b.setFormantBase(200/48000)))
     pc.case_single_hop_chunks(hip, geometry=dict(preset="cheaper", sample_rate=96000.0), channel_counts=(8,), hops=5)
+
+
+def test_half_state(hip, ref):
+    """BASELINE config 5 "fp16 internal": carried state in fp16 against the fp32 checker, magnitude domain."""
+    r = pc.case_half_state(hip, ref, D48, 2, 1.5, "half config2")
+    _report("half_state/config2", r)
+    r = pc.case_half_state(hip, ref, CHEAPER96, 8, 1.2, "half config5-8ch", setup=lambda o: o.setTransposeSemitones(-5, 0), hops=20, streams=(0, 2))
+    _report("half_state/config5-8ch", r)
+    # the bulk path (64 hops per tile: the state is narrowed once per tile) against the fp32 product itself
+    import torch
+    pkg = package()
+    S, C, sr, n = 8, 8, 96000, 192000
+    x = torch.from_numpy(np.stack([synth_input(s, C, n, sr) for s in range(S)])).cuda()
+    outs = []
+    for half in (False, True):
+        b = pkg.StretchBatch(S, C, preset="cheaper", sample_rate=sr, lib=hip, half_state=half)
+        b.setTransposeSemitones(3.0, 0.0)
+        y = b.process(x, int(n*1.2))
+        b.synchronize()
+        outs.append(y.clone())
+        b.close()
+    lvl = float((outs[1].pow(2).mean().sqrt()/outs[0].pow(2).mean().sqrt() - 1).abs())
+    assert lvl < 0.01, lvl
+    assert bool(torch.isfinite(outs[1]).all())
