@@ -50,27 +50,83 @@ def make_inputs(torch, S, C, n, device, first_stream=0, sr=SR):
     return x
 
 
+def host_topology():
+    """(physical core count, one logical CPU per physical core, logical CPU count) from sysfs thread-sibling lists."""
+    logical = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else list(range(os.cpu_count() or 1))
+    firsts = {}
+    for cpu in logical:
+        path = "/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list" % cpu
+        try:
+            sib = open(path).read().strip()
+            first = int(sib.replace("-", ",").split(",")[0])
+        except (OSError, ValueError):
+            first = cpu
+        firsts.setdefault(first, cpu)
+    per_core = sorted(firsts.values())
+    return len(per_core), per_core, len(logical)
+
+
 def cpu_baseline(budget_s=6.0):
-    """The CPU reference (oracle/_ref) on this box's host cores: one process per core, each rendering 10 s stereo
-    streams at 1.5x back to back for `budget_s` seconds of process() time (bounded sample)."""
+    """The CPU reference (oracle/_ref) on this box's host cores: ONE PROCESS PER PHYSICAL CORE, each pinned to its core and
+    rendering 10 s stereo streams at 1.5x back to back for `budget_s` seconds of process() time (bounded sample).  The
+    earlier one-process-per-LOGICAL-core figure swung by 2x between boxes (SMT siblings + unpinned processes contending);
+    `single_core` is the same binary on one otherwise idle core, measured first."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import ref_oracle
     if not ref_oracle.available():
         return None
-    cores = os.cpu_count() or 1
+    physical, cpus, logical = host_topology()
     script = os.path.join(ROOT, "oracle", "cpu_baseline.py")
+
+    def launch(cpu, budget, first):
+        def pin():
+            try:
+                os.sched_setaffinity(0, {cpu})
+            except OSError:
+                pass
+        return subprocess.Popen([sys.executable, script, str(budget), "10", "1.5", str(first)], stdout=subprocess.PIPE, text=True, preexec_fn=pin)
+    one = json.loads(launch(cpus[0], 1.5, 0).communicate()[0].strip().splitlines()[-1])
+    single = one["samples"]/one["process_s"]
     t0 = time.perf_counter()
-    procs = [subprocess.Popen([sys.executable, script, str(budget_s), "10", "1.5", str(3*i)], stdout=subprocess.PIPE, text=True)
-             for i in range(cores)]
+    procs = [launch(cpu, budget_s, 3*i) for i, cpu in enumerate(cpus)]
     outs = [json.loads(p.communicate()[0].strip().splitlines()[-1]) for p in procs]
     wall = time.perf_counter() - t0
     rate = sum(o["samples"]/o["process_s"] for o in outs)  # all cores busy concurrently: sum of per-core rates
     streams = sum(o["streams"] for o in outs)
-    return dict(value=rate/1e6, unit="Msamples/s", cores=cores, kind="reference",
-                sample="%d processes (one per host core) x ~%.0f s of process() each = %d stereo 48 kHz presetDefault streams of 10 s "
-                       "at 1.5x; unmodified reference header, g++ -O3, L1 (signalsmith-linear) restated in oracle/linear_shim; "
-                       "wall %.1f s" % (cores, budget_s, streams, wall),
+    return dict(value=rate/1e6, unit="Msamples/s", cores=physical, kind="reference",
+                sample="%d pinned processes (one per PHYSICAL core; %d logical CPUs) x ~%.0f s of process() each = %d stereo 48 kHz "
+                       "presetDefault streams of 10 s at 1.5x; unmodified reference header, g++ -O3, L1 (signalsmith-linear) restated "
+                       "in oracle/linear_shim; wall %.1f s" % (physical, logical, budget_s, streams, wall),
+                logical_cpus=logical, single_core_Msamples_s=single/1e6, per_core_when_all_busy_Msamples_s=rate/1e6/max(physical, 1),
                 realtime_x=rate/(2*2.5*SR))
+
+
+def pin_rank_to_numa_node(local_rank, world):
+    """Multi-GPU runs: keep each rank's host scheduler (the block scheduler of process() is single-threaded host code) on
+    the CPUs of the NUMA node its GPU hangs off; ranks that share a node split its CPUs.  Best effort, silent when sysfs
+    has no answer."""
+    try:
+        import torch
+        bus = torch.cuda.get_device_properties(local_rank).pci_bus_id if hasattr(torch.cuda.get_device_properties(local_rank), "pci_bus_id") else None
+        node = None
+        if bus is not None:
+            for cand in ("/sys/bus/pci/devices/0000:%02x:00.0/numa_node" % bus,):
+                if os.path.exists(cand):
+                    node = int(open(cand).read().strip())
+        cpus = sorted(os.sched_getaffinity(0))
+        if node is not None and node >= 0:
+            spec = open("/sys/devices/system/node/node%d/cpulist" % node).read().strip()
+            node_cpus = []
+            for part in spec.split(","):
+                a, _, b = part.partition("-")
+                node_cpus += list(range(int(a), int(b or a) + 1))
+            cpus = [c for c in cpus if c in set(node_cpus)] or cpus
+        share = max(1, len(cpus)//max(world, 1))
+        mine = cpus[(local_rank*share) % len(cpus):][:share] or cpus
+        os.sched_setaffinity(0, set(mine))
+        return mine
+    except Exception:
+        return None
 
 
 def main():
@@ -118,6 +174,7 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
+    affinity = pin_rank_to_numa_node(local_rank, world) if world > 1 else None
     pkg = importlib.import_module("signalsmith-stretch_amd")
     S = args.streams
     n_in = int(args.seconds*sr_cfg)
@@ -238,7 +295,8 @@ def main():
                        if args.config == "2" else "BASELINE config %s (not the headline): %d streams x %d ch per GPU, %d Hz, preset %s, %.0f s per step"
                        % (args.config, S, C, sr_cfg, preset, args.seconds),
                        "streams_total": world*S, "channels": C, "block": B, "interval": I, "fft": batch.fftSamples(),
-                       "hops_per_stream_per_step": hops_per_stream, "sharding": "streams/%d, no collective" % world},
+                       "hops_per_stream_per_step": hops_per_stream, "sharding": "streams/%d, no collective" % world,
+                       "rank0_cpu_affinity": ("%d CPUs from %d" % (len(affinity), affinity[0])) if affinity else None},
             "realtime_x": world*S*args.seconds*args.steps/elapsed,
             "channels": C,
             "output_finite_nonzero": ok,
