@@ -139,6 +139,7 @@ def main():
     ap.add_argument("--stretch", type=float, default=1.5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-serial-pass", action="store_true", help="skip the extra, serialised per-kernel-class profiling call (used under rocprofv3, so that every launch it sees is an in-place one)")
+    ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (RCCL) even with one rank: exercises the barrier / max-over-ranks path of the N>1 runs on a 1-GPU box")
     ap.add_argument("--half-state", action="store_true", help="BASELINE config 5 'fp16 internal': carried state and overlap-add sums stored in fp16 (SMST_FLAG_HALF_STATE)")
     ap.add_argument("--config", default="2", choices=["2", "3", "4", "4b", "5"],
                     help="BASELINE.json config (default 2 = the one the headline metric is quoted on; the others are "
@@ -170,8 +171,10 @@ def main():
         raise SystemExit("WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus))
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     affinity = pin_rank_to_numa_node(local_rank, world) if world > 1 else None
@@ -196,7 +199,7 @@ def main():
     torch.cuda.synchronize()
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
 
     for _ in range(args.warmup):
@@ -218,7 +221,7 @@ def main():
     elapsed = time.perf_counter() - t0
     live_ms, live_launches = batch.takeTimings()
     batch.enableProfiling(0)
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -226,7 +229,7 @@ def main():
 
     total_out = sum(n_out) if per_stream else S*n_out
     samples_local = C*(S*n_in + total_out)
-    if world > 1:  # per-stream stretch factors differ between ranks (config 5): add up what every rank really processed
+    if use_dist:  # per-stream stretch factors differ between ranks (config 5): add up what every rank really processed
         tot = torch.tensor([samples_local], dtype=torch.float64, device=device)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         samples_per_step = int(tot.item())
@@ -303,7 +306,7 @@ def main():
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(line))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
     if rank == 0 and not ok:
         raise SystemExit("bench: output not finite / silent -- the line above is not a valid measurement")
