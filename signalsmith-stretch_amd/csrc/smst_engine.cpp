@@ -647,25 +647,39 @@ void Batch::process(const float *in, long long inSS, long long inCS, const int *
 	const int hopStride = nTiles*T;
 	const int nSub = (S + subS - 1)/subS;
 
-	// per-call tables: pinned staging and device copies grow only when a call needs more hops than any earlier call
+	// per-call tables: pinned staging and device copies grow only when a call needs more hops than any earlier call -- and
+	// then BOTH sets grow, so that the call after this one (which uses the other set) does not allocate either.  The other
+	// set's old tables may still be read by the previous call's kernels: they are retired and freed when that set is next used.
+	for (void *q : cs.retiredDevice) devFree(q);
+	for (void *q : cs.retiredPinned) pinnedFree(q);
+	cs.retiredDevice.clear();
+	cs.retiredPinned.clear();
 	const size_t needHops = (size_t)S*hopStride, needEmit = (size_t)S*nTiles, needInfo = (size_t)nSub*nTiles*2*subS;
-	if (needHops > cs.hopsCap) {
-		if (cs.hops) { devFree(cs.hops); pinnedFree(cs.hHops); }
-		cs.hopsCap = needHops + needHops/4;
-		cs.hops = devAlloc<HopDesc>(cs.hopsCap);
-		cs.hHops = pinnedAlloc<HopDesc>(cs.hopsCap);
-	}
-	if (needEmit > cs.emitCap) {
-		if (cs.emit) { devFree(cs.emit); pinnedFree(cs.hEmit); }
-		cs.emitCap = needEmit + needEmit/4;
-		cs.emit = devAlloc<EmitDesc>(cs.emitCap);
-		cs.hEmit = pinnedAlloc<EmitDesc>(cs.emitCap);
-	}
-	if (needInfo > cs.tileInfoCap) {
-		if (cs.tileInfo) { devFree(cs.tileInfo); pinnedFree(cs.hTileInfo); }
-		cs.tileInfoCap = needInfo + needInfo/4;
-		cs.tileInfo = devAlloc<int>(cs.tileInfoCap);
-		cs.hTileInfo = pinnedAlloc<int>(cs.tileInfoCap);
+	for (int which = 0; which < 2; ++which) {
+		CallSet &t = callSets[which ? callCur ^ 1 : callCur];
+		const bool mine = which == 0;
+		auto retire = [&](void *dev, void *host) {
+			if (mine) { devFree(dev); pinnedFree(host); }
+			else { if (dev) t.retiredDevice.push_back(dev); if (host) t.retiredPinned.push_back(host); }
+		};
+		if (needHops > t.hopsCap) {
+			retire(t.hops, t.hHops);
+			t.hopsCap = needHops + needHops/4;
+			t.hops = devAlloc<HopDesc>(t.hopsCap);
+			t.hHops = pinnedAlloc<HopDesc>(t.hopsCap);
+		}
+		if (needEmit > t.emitCap) {
+			retire(t.emit, t.hEmit);
+			t.emitCap = needEmit + needEmit/4;
+			t.emit = devAlloc<EmitDesc>(t.emitCap);
+			t.hEmit = pinnedAlloc<EmitDesc>(t.emitCap);
+		}
+		if (needInfo > t.tileInfoCap) {
+			retire(t.tileInfo, t.hTileInfo);
+			t.tileInfoCap = needInfo + needInfo/4;
+			t.tileInfo = devAlloc<int>(t.tileInfoCap);
+			t.hTileInfo = pinnedAlloc<int>(t.tileInfoCap);
+		}
 	}
 	dHops = cs.hops; dEmit = cs.emit; dTileInfo = cs.tileInfo;
 	HopDesc *hopsAll = cs.hHops;

@@ -108,6 +108,7 @@ private:
 		int *hInSamples, *hOutSamples, *hFlags, *hTileInfo; HopDesc *hHops; EmitDesc *hEmit; float *hEnergy;
 		size_t hopsCap, emitCap, tileInfoCap;
 		hipEvent_t done, tables; bool used;
+		std::vector<void *> retiredDevice, retiredPinned; // outgrown tables that the previous call may still read
 	} callSets[2]{};
 	int callCur = 0;
 	hipEvent_t evStart = nullptr, evFeed[2] = {nullptr, nullptr}, evChain[2] = {nullptr, nullptr}, evSynth[2] = {nullptr, nullptr};

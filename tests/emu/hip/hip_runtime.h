@@ -42,6 +42,7 @@ void emuSyncThreads();
 #define __syncthreads() emuSyncThreads()
 #define __builtin_amdgcn_wave_barrier() emuSyncThreads()
 #define __builtin_amdgcn_fence(order, scope) ((void)0)
+static inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((uint64_t)a*(uint64_t)b) >> 32); }
 static inline float __fmul_rn(float a, float b) { return a*b; }
 static inline float __fadd_rn(float a, float b) { return a + b; }
 static inline float __builtin_amdgcn_rsqf(float x) { return 1.0f/std::sqrt(x); }
