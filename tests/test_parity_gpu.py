@@ -90,8 +90,8 @@ def test_config2_subset(hip, ref):
 
 
 def test_config3_subset(hip, ref):
-    """config 3: +12 semitones with 8 kHz tonality limit, stretch 1.0."""
-    _batch_vs_ref(hip, ref, 6, 2, 48000, 72000, 72000, D48, "default", "config3",
+    """config 3: +12 semitones with 8 kHz tonality limit, stretch 1.0; first 6 streams at the bench's own length (10 s)."""
+    _batch_vs_ref(hip, ref, 6, 2, 48000, 480000, 480000, D48, "default", "config3",
                   setup=lambda o: o.setTransposeSemitones(12, 8000/48000))
 
 
@@ -103,13 +103,13 @@ def test_config4_subset(hip, ref):
                 o.setTransposeSemitones(semis, 8000/48000)
             o.setFormantFactor(1, True)
             o.setFormantBase(200/48000)
-        _batch_vs_ref(hip, ref, 6, 2, 48000, 72000, 54000, D48, "default", "config4 (+%g st)" % semis, setup=setup,
+        _batch_vs_ref(hip, ref, 6, 2, 48000, 480000, 360000, D48, "default", "config4 (+%g st)" % semis, setup=setup,  # 10 s, as the bench
                       cap=pc.CAP_FORMANT if semis else pc.CAP_TONAL)
 
 
 def test_config5_subset(hip, ref):
-    """config 5 flavour: 8-channel streams, 96 kHz, presetCheaper (split), per-stream random stretch and transpose."""
-    S, n = 4, 96000
+    """config 5 flavour: 8-channel streams, 96 kHz, presetCheaper (split), per-stream random stretch and transpose; 2 s as the bench."""
+    S, n = 4, 192000
     g = np.random.Generator(np.random.PCG64(5))
     stretch = g.uniform(0.75, 1.5, S)
     semis = g.uniform(-12, 12, S)
