@@ -78,3 +78,34 @@ def test_single_hop_chunks(emu):
 def test_half_state(emu, ref):
     print(pc.case_half_state(emu, ref, pc.SMALL, 2, 1.5, "half plain"))
     print(pc.case_half_state(emu, ref, pc.SMALL_SPLIT, 3, 1.2, "half 3ch split pitch", setup=lambda o: o.setTransposeSemitones(-5, 0)))
+
+
+def test_freq_map_tables_are_per_stream(emu):
+    """setFreqMap in table form: every stream keeps its own table, whatever its length (a table of another length than the
+    batch's first one is resampled).  Two tables of different length that describe the SAME linear map give the same
+    output, and neither disturbs a third stream that has no map (the reference's instances share nothing)."""
+    import numpy as np
+    from conftest import package, synth_input
+    pkg = package()
+    C, n = 2, 6000
+    x = synth_input(0, C, n, 48000) + 0.4*synth_input(4, C, n, 48000)
+    xs = np.stack([x, x, x])
+    t64 = np.array([(i + 0.5)/128*1.3 for i in range(64)], np.float32)
+    t160 = np.array([(i + 0.5)/320*1.3 for i in range(160)], np.float32)
+    b = pkg.StretchBatch(3, C, block=512, interval=128, lib=emu)
+    b.setFreqMapTable(t64, stream=0)
+    b.setFreqMapTable(t160, stream=1)   # another length: must not clear stream 0's map
+    y = b.process(xs, n)
+    b.close()
+    plain = pkg.StretchBatch(1, C, block=512, interval=128, lib=emu)
+    y_plain = plain.process(x[None], n)
+    plain.close()
+    one = pkg.StretchBatch(1, C, block=512, interval=128, lib=emu)
+    one.setFreqMapTable(t64)
+    y_one = one.process(x[None], n)
+    one.close()
+    assert np.array_equal(y[0], y_one[0])                       # stream 0 kept its map
+    assert np.array_equal(y[2], y_plain[0])                     # stream 2 has none
+    err = np.sqrt(np.mean((y[1] - y[0])**2)/np.mean(y[0]**2))   # same linear map, resampled: same result up to the table's own rounding
+    assert err < 1e-3, err
+    assert np.sqrt(np.mean((y[0] - y_plain[0])**2)/np.mean(y_plain[0]**2)) > 0.1  # and the map does something

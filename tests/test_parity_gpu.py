@@ -465,3 +465,29 @@ def test_half_state(hip, ref):
     lvl = float((outs[1].pow(2).mean().sqrt()/outs[0].pow(2).mean().sqrt() - 1).abs())
     assert lvl < 0.01, lvl
     assert bool(torch.isfinite(outs[1]).all())
+
+
+def test_stream_ordering_without_host_sync(hip):
+    """smst_batch_wait_for_stream / _signal_stream (the Python wrapper's `ordered=True`): the input is produced by a torch kernel
+    on a side stream that is still running when process() is called, and the output is consumed by torch right after the
+    call -- no host synchronisation anywhere; the result must equal the fully synchronised run."""
+    import torch
+    pkg = package()
+    S, C, sr, n = 4, 2, 48000, 48000
+    base = torch.from_numpy(np.stack([synth_input(s, C, n, sr) for s in range(S)])).cuda()
+    b = pkg.StretchBatch(S, C, preset="default", sample_rate=sr, lib=hip)
+    ref_out = b.process(base, 60000).clone()
+    b.synchronize()
+    side = torch.cuda.Stream()
+    for trial in range(3):
+        b.reset()
+        big = torch.randn(4096, 4096, device="cuda")
+        with torch.cuda.stream(side):
+            for _ in range(4):
+                big = big @ big*1e-4           # keeps the side stream busy for a while
+            x = base*2.0                       # the producer of the input, behind that work
+            x = x*0.5
+            y = b.process(x, 60000)            # ordered after `side`'s current work by an event
+            total = (y - ref_out).abs().max()  # consumer on the same torch stream, ordered after the batch's kernels
+        assert float(total) == 0.0, (trial, float(total))
+    b.close()
