@@ -1,9 +1,13 @@
-"""Prints the few numbers of a bench.py JSON line that matter while iterating: python bench.py ... | python tools/bench_summary.py [label]"""
+"""Prints the few numbers of a bench.py JSON line that matter while iterating:
+python bench.py ... | python tools/bench_summary.py [label]      or      python tools/bench_summary.py FILE.json [label]"""
 import json
+import os
 import sys
 
-label = sys.argv[1] if len(sys.argv) > 1 else ""
-for line in sys.stdin.read().strip().splitlines():
+args = sys.argv[1:]
+source = open(args.pop(0)) if args and os.path.isfile(args[0]) else sys.stdin
+label = args[0] if args else ""
+for line in source.read().strip().splitlines():
     if not line.startswith("{"):
         continue
     d = json.loads(line)
