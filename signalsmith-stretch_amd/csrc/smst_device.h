@@ -8,7 +8,7 @@ namespace smst {
 struct DevBatch {
 	// geometry (signalsmith-stretch.h:71-94; fftSamples/bands from the L1 contract)
 	int S, C, B, I, M, N, L, T;
-	int Mp;                       // row pitch (elements) of the per-tile [.][C][M] arrays: M + 32
+	int Mp;                       // row pitch (elements) of the per-tile [.][C][M] arrays: M + 32 rounded up to 16
 	int recPitch;                 // float4 per wavefront step in REC: chunks*64 + 16
 	int histLen, carryLen, delta; // B+I, B+I, split ? I : 0
 	int lag, ringSlots;           // wavefront skew (>= L+1) and LDS ring depth (power of two > lag)

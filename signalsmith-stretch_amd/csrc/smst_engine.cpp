@@ -369,7 +369,7 @@ void Batch::allocateWorkspace() {
 	const size_t recChunks = (9 + 3*(size_t)C + 3)/4;
 	d.recSteps = ((M + d.lag*(d.T - 1) + 63)/64)*64 + 8;
 	d.recPitch = int(recChunks*64 + 16);
-	d.Mp = M + 32;
+	d.Mp = (M + 32 + 15) & ~15; // rows start on 128-byte lines (the recurrence's writer stores aligned 64-byte groups)
 	const size_t perStream = (size_t)d.T*((size_t)C*((size_t)d.Mp*(3*sizeof(float2) + sizeof(float4)) + (size_t)B*sizeof(float))
 	                                      + (size_t)M*(sizeof(float2) + sizeof(float)) + 3*sizeof(float))
 	                         + (size_t)C*64*sizeof(float2)

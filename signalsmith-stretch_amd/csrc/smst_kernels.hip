@@ -1755,7 +1755,7 @@ __device__ __forceinline__ void vocoderProduceStaged(const DevBatch &d, int s, i
 	}
 }
 
-constexpr int kVocBlockSteps = 8, kVocBlocks = 3, kVocBlocksStaged = 2, kVocWaves = 16, kVocStagedProducers = 8;
+constexpr int kVocBlockSteps = 8, kVocBlocks = 3, kVocBlocksStaged = 2, kVocWaves = 16, kVocStagedProducers = 8, kVocOutBlocks = 3;
 
 __device__ __forceinline__ float2 fromLaneBelow(float2 v, float2 lane0) { // lane k receives lane k-1's v; lane 0 keeps its `lane0`
 	// DPP wave_shr:1 without bound_ctrl: a lane with no source lane keeps the old value of the destination register
@@ -1775,7 +1775,7 @@ __global__ __launch_bounds__(64*kVocWaves) __attribute__((amdgpu_waves_per_eu(4,
 	float2 *stage = reinterpret_cast<float2 *>(recs + NB*BS*NCH*64);    // [CH][128]: carried Band.output, 128-bin window
 	volatile int *sync = reinterpret_cast<volatile int *>(stage + CH*128); // [0..NB) units produced, [NB] blocks consumed
 	HopDesc *hopsLds = reinterpret_cast<HopDesc *>(const_cast<int *>(sync) + 16); // the tile's 64 hop descriptors
-	float2 *outRing = reinterpret_cast<float2 *>(hopsLds + 64);                    // [2 blocks][BS][CH][64]: results on their way to HBM
+	float2 *outRing = reinterpret_cast<float2 *>(hopsLds + 64);                    // [kVocOutBlocks][BS][CH][64]: results on their way to HBM
 	// sync words: [0..NB) units produced per slot, [NB] blocks consumed, [NB+1] result blocks ready, [NB+2] result blocks written
 
 	const int s = blockIdx.x, sg = sBase + s;
@@ -1801,25 +1801,35 @@ __global__ __launch_bounds__(64*kVocWaves) __attribute__((amdgpu_waves_per_eu(4,
 		// ---------------- producers ----------------
 		if (wave == 4) {
 			// ---------------- writer ----------------
-			// Drains the consumer's results to HBM 8 steps at a time.  Per lane and step the consumer would issue one
-			// 8-byte store per channel into 64 different cache lines (128 partial-line transactions per step, competing
-			// with the producers' loads); here 4 lanes cover one row's 8 bins with 16-byte stores, 16 rows per instruction.
-			// Bins outside [0, M) of an active row land in the rows' padding (row pitch M + 32).
-			const int g = k >> 2, part = k & 3;
-			for (int n = 0; n < totalBlocks; ++n) {
-				while (ldsPeek(&sync[NB + 1]) <= n) __builtin_amdgcn_s_sleep(2);
+			// Drains the consumer's results to HBM.  Per lane and step the consumer would issue one 8-byte store per channel
+			// into 64 different cache lines (128 partial-line transactions per step, competing with the producers' loads);
+			// here 4 lanes cover 8 bins of one row with 16-byte stores, 16 rows per instruction.  The 8 bins are an ALIGNED
+			// group (bins 8g..8g+7 = one 64-byte half line; rows are 128-byte aligned): the first version stored whatever 8 bins
+			// a row had produced in the block, at 8-byte alignment, and the partial lines went to HBM twice (rocprofv3
+			// WRITE_SIZE 1.42 GB per launch for 0.79 GB of results).  With block n row r completes group n - ceil(lag*r/8),
+			// whose bins lie in ring blocks n-1 and n -- hence a ring of three blocks -- and one extra pass after the last
+			// block flushes the rows' final groups.  Bins >= M of a group land in the rows' padding as zeros.
+			const int g4 = k >> 2, part = k & 3;
+			for (int n = 0; n <= totalBlocks; ++n) {
+				if (n < totalBlocks) {
+					while (ldsPeek(&sync[NB + 1]) <= n) __builtin_amdgcn_s_sleep(2);
+				}
 				asm volatile("" ::: "memory");
-				const float2 *blockOut = outRing + (size_t)(n & 1)*BS*CH*64;
 #pragma unroll
 				for (int pass = 0; pass < 4; ++pass) {
-					const int row = 16*pass + g;
-					const int b0 = BS*n - lag*row;
-					const bool ok = row < nh && b0 + BS - 1 >= 0 && b0 < M;
+					const int row = 16*pass + g4;
+					const int g = n - ((lag*row + 7) >> 3);
+					const int b = 8*g + 2*part;
+					const bool ok = row < nh && g >= 0 && 8*g < M;
+					const int t0 = b + lag*row, t1 = t0 + 1; // the steps at which the two bins were produced
+					const int r0 = t0 >= 0 ? (t0 >> 3)%kVocOutBlocks : 0, r1 = t1 >= 0 ? (t1 >> 3)%kVocOutBlocks : 0;
 #pragma unroll
 					for (int c = 0; c < CH; ++c) {
-						const float2 v0 = blockOut[((2*part)*CH + c)*64 + row], v1 = blockOut[((2*part + 1)*CH + c)*64 + row];
+						float2 v0 = outRing[((r0*BS + (t0 & 7))*CH + c)*64 + row], v1 = outRing[((r1*BS + (t1 & 7))*CH + c)*64 + row];
+						if (b >= M) v0 = make_float2(0.f, 0.f);
+						if (b + 1 >= M) v1 = make_float2(0.f, 0.f);
 						if (ok) {
-							float2 *dst = d.OUT + rowOf(d, s, row, c) + b0 + 2*part;
+							float2 *dst = d.OUT + rowOf(d, s, row, c) + b;
 							dst[0] = v0;
 							dst[1] = v1;
 						}
@@ -1837,7 +1847,7 @@ __global__ __launch_bounds__(64*kVocWaves) __attribute__((amdgpu_waves_per_eu(4,
 		if (pIndex >= NP) return;
 		if constexpr (STAGED) {
 			using G = StageGeom<CH, L>;
-			float2 *sbuf = outRing + (size_t)2*BS*CH*64 + (size_t)pIndex*G::ROWS*G::ROWLEN;
+			float2 *sbuf = outRing + (size_t)kVocOutBlocks*BS*CH*64 + (size_t)pIndex*G::ROWS*G::ROWLEN;
 			vocoderProduceStaged<CH, L, NB, NP>(d, s, sg, nh, pIndex, k, totalBlocks, recs, sync, hopsLds, sbuf);
 			return;
 		}
@@ -1905,7 +1915,7 @@ __global__ __launch_bounds__(64*kVocWaves) __attribute__((amdgpu_waves_per_eu(4,
 			const float4 *blockRecs = recs + (size_t)slot*BS*NCH*64;
 			while (n - ldsPeek(&sync[NB + 2]) >= 2) __builtin_amdgcn_s_sleep(1); // the writer still owns this result slot
 			asm volatile("" ::: "memory");
-			float2 *blockOut = outRing + (size_t)(n & 1)*BS*CH*64 + k;
+			float2 *blockOut = outRing + (size_t)(n%kVocOutBlocks)*BS*CH*64 + k;
 			float4 q[2][NCH]; // two register sets alternate, so the next step's record loads never overwrite live values
 #pragma unroll
 			for (int j = 0; j < NCH; ++j) q[0][j] = blockRecs[j*64 + k];
@@ -2637,7 +2647,7 @@ void launchPredictFused(const DevBatch &d, int sBase, int nStreams, int hopBase,
 template <int CH, int L>
 static void launchVocoderTL(const DevBatch &d, int sBase, int nStreams, int hopBase, bool plain, bool bounded, hipStream_t st) {
 	constexpr int NCH = (9 + 3*CH + 3)/4;
-	const size_t fixed = (size_t)CH*128*sizeof(float2) + 64 + 64*sizeof(HopDesc) + (size_t)2*kVocBlockSteps*CH*64*sizeof(float2);
+	const size_t fixed = (size_t)CH*128*sizeof(float2) + 64 + 64*sizeof(HopDesc) + (size_t)kVocOutBlocks*kVocBlockSteps*CH*64*sizeof(float2);
 	const size_t lds = (size_t)kVocBlocks*kVocBlockSteps*NCH*64*sizeof(float4) + fixed;
 	if constexpr (L <= 5) {
 		if (plain && bounded && !d.noStage) {
