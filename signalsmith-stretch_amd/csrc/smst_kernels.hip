@@ -1755,7 +1755,7 @@ __device__ __forceinline__ void vocoderProduceStaged(const DevBatch &d, int s, i
 	}
 }
 
-constexpr int kVocBlockSteps = 8, kVocBlocks = 3, kVocBlocksStaged = 2, kVocWaves = 16, kVocStagedProducers = 8, kVocOutBlocks = 3;
+constexpr int kVocBlockSteps = 8, kVocBlocks = 3, kVocBlocksStaged = 2, kVocWaves = 16, kVocStagedProducers = 8, kVocOutBlocks = 4;
 
 __device__ __forceinline__ float2 fromLaneBelow(float2 v, float2 lane0) { // lane k receives lane k-1's v; lane 0 keeps its `lane0`
 	// DPP wave_shr:1 without bound_ctrl: a lane with no source lane keeps the old value of the destination register
@@ -1774,7 +1774,8 @@ __global__ __launch_bounds__(64*kVocWaves) __attribute__((amdgpu_waves_per_eu(4,
 	float4 *recs = reinterpret_cast<float4 *>(smemRaw);                 // [(slot*BS + st)*NCH + j][64 lanes]
 	float2 *stage = reinterpret_cast<float2 *>(recs + NB*BS*NCH*64);    // [CH][128]: carried Band.output, 128-bin window
 	volatile int *sync = reinterpret_cast<volatile int *>(stage + CH*128); // [0..NB) units produced, [NB] blocks consumed
-	HopDesc *hopsLds = reinterpret_cast<HopDesc *>(const_cast<int *>(sync) + 16); // the tile's 64 hop descriptors
+	int *rowClass = const_cast<int *>(sync) + 16;                                  // [2][64]: the writer's two classes of rows
+	HopDesc *hopsLds = reinterpret_cast<HopDesc *>(rowClass + 128);                // the tile's 64 hop descriptors
 	float2 *outRing = reinterpret_cast<float2 *>(hopsLds + 64);                    // [kVocOutBlocks][BS][CH][64]: results on their way to HBM
 	// sync words: [0..NB) units produced per slot, [NB] blocks consumed, [NB+1] result blocks ready, [NB+2] result blocks written
 
@@ -1803,24 +1804,35 @@ __global__ __launch_bounds__(64*kVocWaves) __attribute__((amdgpu_waves_per_eu(4,
 			// ---------------- writer ----------------
 			// Drains the consumer's results to HBM.  Per lane and step the consumer would issue one 8-byte store per channel
 			// into 64 different cache lines (128 partial-line transactions per step, competing with the producers' loads);
-			// here 4 lanes cover 8 bins of one row with 16-byte stores, 16 rows per instruction.  The 8 bins are an ALIGNED
-			// group (bins 8g..8g+7 = one 64-byte half line; rows are 128-byte aligned): the first version stored whatever 8 bins
-			// a row had produced in the block, at 8-byte alignment, and the partial lines went to HBM twice (rocprofv3
-			// WRITE_SIZE 1.42 GB per launch for 0.79 GB of results).  With block n row r completes group n - ceil(lag*r/8),
-			// whose bins lie in ring blocks n-1 and n -- hence a ring of three blocks -- and one extra pass after the last
-			// block flushes the rows' final groups.  Bins >= M of a group land in the rows' padding as zeros.
-			const int g4 = k >> 2, part = k & 3;
-			for (int n = 0; n <= totalBlocks; ++n) {
+			// here 8 lanes cover 16 bins of one row with 16-byte stores: one whole, ALIGNED 128-byte line (rows start on line
+			// boundaries).  The first version stored whatever 8 bins a row had produced in the block, at 8-byte alignment, and
+			// the partial lines went to HBM twice (rocprofv3 WRITE_SIZE 1.42 GB per launch for 0.79 GB of results); aligned
+			// 64-byte halves still gave 1.04 GB.  Row r has produced line G = (n - ceil(lag*r/8) - 1)/2 completely at the end of
+			// block n when n - ceil(lag*r/8) is odd, so the rows fall into two classes that store on alternate blocks; the
+			// line's bins lie in ring blocks n-2..n (ring of four), and two extra passes after the last block flush the rows'
+			// final lines.  Bins >= M of a line land in the rows' padding as zeros.
+			int count[2] = {0, 0}; // rowClass[q][.]: the rows with ceil(lag*row/8) = q (mod 2)
+			for (int r = 0; r < 64; ++r) { // every lane walks the same list; lane 0 records it
+				const int q = ((lag*r + 7) >> 3) & 1;
+				if (k == 0) rowClass[q*64 + count[q]] = r;
+				++count[q];
+			}
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+			__builtin_amdgcn_wave_barrier();
+			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+			const int g8 = k >> 3, part = k & 7;
+			for (int n = 0; n <= totalBlocks + 1; ++n) {
 				if (n < totalBlocks) {
 					while (ldsPeek(&sync[NB + 1]) <= n) __builtin_amdgcn_s_sleep(2);
 				}
 				asm volatile("" ::: "memory");
-#pragma unroll
-				for (int pass = 0; pass < 4; ++pass) {
-					const int row = 16*pass + g4;
-					const int g = n - ((lag*row + 7) >> 3);
-					const int b = 8*g + 2*part;
-					const bool ok = row < nh && g >= 0 && 8*g < M;
+				const int q = (n + 1) & 1; // rows with ceil(lag*row/8) = n - 1 (mod 2) complete a line with this block
+				for (int pass = 0; 8*pass < count[q]; ++pass) {
+					const int idx = 8*pass + g8;
+					const int row = rowClass[q*64 + (idx < count[q] ? idx : 0)];
+					const int G = (n - ((lag*row + 7) >> 3) - 1) >> 1;
+					const int b = 16*G + 2*part;
+					const bool ok = idx < count[q] && row < nh && G >= 0 && 16*G < M;
 					const int t0 = b + lag*row, t1 = t0 + 1; // the steps at which the two bins were produced
 					const int r0 = t0 >= 0 ? (t0 >> 3)%kVocOutBlocks : 0, r1 = t1 >= 0 ? (t1 >> 3)%kVocOutBlocks : 0;
 #pragma unroll
@@ -2647,7 +2659,7 @@ void launchPredictFused(const DevBatch &d, int sBase, int nStreams, int hopBase,
 template <int CH, int L>
 static void launchVocoderTL(const DevBatch &d, int sBase, int nStreams, int hopBase, bool plain, bool bounded, hipStream_t st) {
 	constexpr int NCH = (9 + 3*CH + 3)/4;
-	const size_t fixed = (size_t)CH*128*sizeof(float2) + 64 + 64*sizeof(HopDesc) + (size_t)kVocOutBlocks*kVocBlockSteps*CH*64*sizeof(float2);
+	const size_t fixed = (size_t)CH*128*sizeof(float2) + 64 + 128*sizeof(int) + 64*sizeof(HopDesc) + (size_t)kVocOutBlocks*kVocBlockSteps*CH*64*sizeof(float2);
 	const size_t lds = (size_t)kVocBlocks*kVocBlockSteps*NCH*64*sizeof(float4) + fixed;
 	if constexpr (L <= 5) {
 		if (plain && bounded && !d.noStage) {
