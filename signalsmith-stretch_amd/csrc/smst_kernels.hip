@@ -2041,20 +2041,27 @@ __global__ __launch_bounds__(64*kVocWaves) __attribute__((amdgpu_waves_per_eu(4,
 
 	if (wave > 0) {
 		if (wave == 4) {
-			// ---------------- writer: 4 consecutive bins of a row = 32 contiguous bytes per channel, two lanes per row
+			// ---------------- writer: an ALIGNED group of 4 bins of a row = one 32-byte sector per channel, two lanes per row.
+			// With block n row r has completed group n - ceil(lag*r/4) (the bins a row produced in the block itself straddle two
+			// sectors, and partial sectors went to HBM twice -- see kVocoder's writer); one extra pass flushes the last groups.
 			const int g = k >> 1, part = k & 1;
-			for (int n = 0; n < totalBlocks; ++n) {
-				while (ldsPeek(&sync[NB + 1]) <= n) __builtin_amdgcn_s_sleep(2);
+			for (int n = 0; n <= totalBlocks; ++n) {
+				if (n < totalBlocks) {
+					while (ldsPeek(&sync[NB + 1]) <= n) __builtin_amdgcn_s_sleep(2);
+				}
 				asm volatile("" ::: "memory");
 #pragma unroll
 				for (int pass = 0; pass < 2; ++pass) {
 					const int row = 32*pass + g;
-					const int b0 = BS*n - lag*row + 2*part;
-					const bool ok = row < nh && b0 + 1 >= 0 && b0 < M;
+					const int grp = n - ((lag*row + 3) >> 2);
+					const int b0 = 4*grp + 2*part;
+					const bool ok = row < nh && grp >= 0 && 4*grp < M;
 #pragma unroll
 					for (int c = 0; c < CH; ++c) {
-						const float2 v0 = ring[(c*R + (b0 & Rm))*64 + row], v1 = ring[(c*R + ((b0 + 1) & Rm))*64 + row];
-						if (ok) { // bins outside [0, M) of an active row land in the rows' padding (row pitch M + 32)
+						float2 v0 = ring[(c*R + (b0 & Rm))*64 + row], v1 = ring[(c*R + ((b0 + 1) & Rm))*64 + row];
+						if (b0 >= M) v0 = make_float2(0.f, 0.f); // not produced in this tile: the slot holds an older bin
+						if (b0 + 1 >= M) v1 = make_float2(0.f, 0.f);
+						if (ok) { // bins M .. M+2 of the last group land in the rows' padding
 							float2 *dst = d.OUT + rowOf(d, s, row, c) + b0;
 							dst[0] = v0;
 							dst[1] = v1;
@@ -2119,8 +2126,9 @@ __global__ __launch_bounds__(64*kVocWaves) __attribute__((amdgpu_waves_per_eu(4,
 			const int slot = n%NB;
 			const int need = UNITS*(n/NB + 1);
 			while (ldsPeek(&sync[slot]) < need) __builtin_amdgcn_s_sleep(1);
-			// the ring slots this block overwrites (bins 4n .. 4n+3 of every row) last held block n - R/BS: it must be on its way to HBM
-			while (n - ldsPeek(&sync[NB + 2]) >= R/BS) __builtin_amdgcn_s_sleep(1);
+			// the ring slots this block overwrites last held the bins of 16 steps ago; the writer's pass m reads bins down to
+			// 4m - lag*row - 3, so it must have finished pass n - 3 (one block less slack than with unaligned groups)
+			while (n - ldsPeek(&sync[NB + 2]) >= R/BS - 1) __builtin_amdgcn_s_sleep(1);
 			asm volatile("" ::: "memory");
 			const float4 *blockRecs = recs + (size_t)slot*BS*NCH*64;
 #pragma unroll
