@@ -902,6 +902,29 @@ __device__ __forceinline__ float scanPass(const float *src, float *dst, int M, f
 	return total;
 }
 
+// channel-summed energy of one hop into LDS, en[b] = sum_c |input_c[b]|^2 in channel order.  Eight independent loads per
+// channel are in flight at a time: the plain loop (one bin per iteration, trip count unknown to the compiler) paid a full
+// memory round trip per iteration -- 13 of them per workgroup, 27 % of the kernel (ablation on the GPU: 16.1 -> 11.7 ms
+// per step of config 3 with the loads removed).
+__device__ __forceinline__ void feedEnergyToLds(const DevBatch &d, const HopDesc &hd, int s, int sg, float *en) {
+	const int M = d.M, C = d.C, t = threadIdx.x;
+	for (int b0 = t; b0 < M; b0 += 8*256) {
+		float acc[8];
+#pragma unroll
+		for (int i = 0; i < 8; ++i) acc[i] = 0.0f;
+		for (int c = 0; c < C; ++c) {
+			const float2 *row = inputRow(d, hd, s, sg, c);
+			float2 v[8];
+#pragma unroll
+			for (int i = 0; i < 8; ++i) v[i] = row[min(b0 + 256*i, M - 1)];
+#pragma unroll
+			for (int i = 0; i < 8; ++i) acc[i] += cnorm(v[i]);
+		}
+#pragma unroll
+		for (int i = 0; i < 8; ++i) if (b0 + 256*i < M) en[b0 + 256*i] = acc[i];
+	}
+}
+
 // energy, smoothing, peaks, output map, raw pitch estimate: one workgroup per (hop, stream)
 __global__ __launch_bounds__(256) void kFeedScanA(DevBatch d, int sBase, int hopBase) {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smemRaw[];
@@ -918,11 +941,7 @@ __global__ __launch_bounds__(256) void kFeedScanA(DevBatch d, int sBase, int hop
 	ScanMap *maps = reinterpret_cast<ScanMap *>(pk + M/2 + 2); // [264]
 	int *counts = reinterpret_cast<int *>(maps + 264);         // [264]
 	const StreamParams prm = d.params[sg];
-	for (int b = t; b < M; b += 256) {
-		float e = 0;
-		for (int c = 0; c < C; ++c) e += cnorm(inputRow(d, hd, s, sg, c)[b]);
-		en[b] = e;
-	}
+	feedEnergyToLds(d, hd, s, sg, en);
 	__syncthreads();
 	if (mapped) {
 		const float smoothingBins = Nf/float(d.I);
@@ -939,12 +958,17 @@ __global__ __launch_bounds__(256) void kFeedScanA(DevBatch d, int sBase, int hop
 		const int n = (M + 255)/256, b0 = t*n, b1 = min(M, b0 + n);
 		int starts = 0;
 		for (int b = b0; b < b1; ++b) starts += (en[b] > sm[b]) && !(b > 0 && en[b - 1] > sm[b - 1]);
-		counts[t] = starts;
-		__syncthreads();
-		if ((t & 63) == 0) {
-			int acc = 0;
-			for (int i = 0; i < 64; ++i) { const int c = counts[t + i]; counts[t + i] = acc; acc += c; }
-			counts[256 + (t >> 6)] = acc;
+		{ // exclusive prefix sum of the run starts: lane shuffles inside the wave (a serial 64-entry loop by one lane per wave
+			// cost 6 us per workgroup), wave totals through LDS
+			const int lane = t & 63;
+			int inc = starts;
+#pragma unroll
+			for (int dlt = 1; dlt < 64; dlt <<= 1) {
+				const int prev = __shfl(inc, max(lane - dlt, 0));
+				if (lane >= dlt) inc += prev;
+			}
+			counts[t] = inc - starts;
+			if (lane == 63) counts[256 + (t >> 6)] = inc;
 		}
 		__syncthreads();
 		int idx = counts[t];
@@ -953,7 +977,18 @@ __global__ __launch_bounds__(256) void kFeedScanA(DevBatch d, int sBase, int hop
 		for (int b = b0; b < b1; ++b) {
 			if ((en[b] > sm[b]) && !(b > 0 && en[b - 1] > sm[b - 1])) {
 				float bandSum = 0, energySum = 0;
-				for (int q = b; q < M && en[q] > sm[q]; ++q) { bandSum += q*en[q]; energySum += en[q]; }
+				for (int q = b; q < M; q += 4) { // four bins per LDS round trip; the additions stay in the reference's order
+					float e4[4], s4[4];
+#pragma unroll
+					for (int i = 0; i < 4; ++i) { const int qi = min(q + i, M - 1); e4[i] = en[qi]; s4[i] = sm[qi]; }
+					bool open = true;
+#pragma unroll
+					for (int i = 0; i < 4; ++i) {
+						open = open && (q + i < M) && e4[i] > s4[i];
+						if (open) { bandSum += (q + i)*e4[i]; energySum += e4[i]; }
+					}
+					if (!open) break;
+				}
 				const float avgBand = bandSum/energySum;
 				const float avgFreq = (avgBand + 0.5f)/Nf;
 				pk[idx++] = make_float2(avgBand, mapFreqDev(d, prm, sg, avgFreq)*Nf - 0.5f);
@@ -965,35 +1000,53 @@ __global__ __launch_bounds__(256) void kFeedScanA(DevBatch d, int sBase, int hop
 		const float2 first = nPeaks > 0 ? pk[0] : make_float2(0.f, 0.f);
 		const float2 lastP = nPeaks > 0 ? pk[nPeaks - 1] : make_float2(0.f, 0.f);
 		const int topStart = max(0, (int)lastP.y), bottomEnd = min(M, (int)ceilf(first.y));
-		for (int b = t; b < M; b += 256) {
-			float2 mp = make_float2(float(b), 1.0f);
-			if (nPeaks > 0) {
-				if (b >= topStart) {
-					mp = make_float2(b + (lastP.x - lastP.y), 1.0f);
-				} else if (b < bottomEnd) {
-					mp = make_float2(b + (first.x - first.y), 1.0f);
-				} else if (nPeaks >= 2) {
-					// largest q in [0, nPeaks-2] with max(0, ceil(peaks[q].out)) <= b (q = 0 qualifies: b >= bottomEnd)
-					int lo = 0, hi = nPeaks - 2;
-					while (lo < hi) {
-						const int mid = (lo + hi + 1) >> 1;
-						if (max(0, (int)ceilf(pk[mid].y)) <= b) lo = mid; else hi = mid - 1;
-					}
-					const float2 prev = pk[lo], next = pk[lo + 1];
-					if (b < min(M, (int)ceilf(next.y))) {
-						float rangeScale = 1/(next.y - prev.y);
-						float outOffset = prev.x - prev.y;
-						float outScale = next.x - next.y - prev.x + prev.y;
-						float gradScale = outScale*rangeScale;
-						float r = (b - prev.y)*rangeScale;
-						float h = r*r*(3 - 2*r);
-						float outB = b + outOffset + h*outScale;
-						float gradH = 6*r*(1 - r);
-						mp = make_float2(outB, 1 + gradH*gradScale);
+		// The covering pair of peaks of every bin by bisection.  A thread's bins are 256 apart, so their bisections are
+		// independent: eight run in lock step (eight LDS reads in flight per round instead of one dependent read at a time --
+		// the one-at-a-time version cost 2.7 of the kernel's 16 ms per step of config 3).
+		for (int b0 = t; b0 < M; b0 += 8*256) {
+			int lo[8], hi[8];
+#pragma unroll
+			for (int i = 0; i < 8; ++i) { lo[i] = 0; hi[i] = nPeaks - 2; }
+			if (nPeaks >= 2) {
+				for (int span = nPeaks - 2; span > 0; span >>= 1) { // ceil(log2(nPeaks - 1)) rounds settle every bisection
+					float y[8];
+#pragma unroll
+					for (int i = 0; i < 8; ++i) y[i] = pk[(lo[i] + hi[i] + 1) >> 1].y;
+#pragma unroll
+					for (int i = 0; i < 8; ++i) {
+						const int mid = (lo[i] + hi[i] + 1) >> 1;
+						if (lo[i] < hi[i]) { if (max(0, (int)ceilf(y[i])) <= b0 + 256*i) lo[i] = mid; else hi[i] = mid - 1; }
 					}
 				}
 			}
-			mapRow[b] = mp;
+#pragma unroll
+			for (int i = 0; i < 8; ++i) {
+				const int b = b0 + 256*i;
+				if (b >= M) continue;
+				float2 mp = make_float2(float(b), 1.0f);
+				if (nPeaks > 0) {
+					if (b >= topStart) {
+						mp = make_float2(b + (lastP.x - lastP.y), 1.0f);
+					} else if (b < bottomEnd) {
+						mp = make_float2(b + (first.x - first.y), 1.0f);
+					} else if (nPeaks >= 2) {
+						// lo = largest q in [0, nPeaks-2] with max(0, ceil(peaks[q].out)) <= b (q = 0 qualifies: b >= bottomEnd)
+						const float2 prev = pk[lo[i]], next = pk[lo[i] + 1];
+						if (b < min(M, (int)ceilf(next.y))) {
+							float rangeScale = 1/(next.y - prev.y);
+							float outOffset = prev.x - prev.y;
+							float outScale = next.x - next.y - prev.x + prev.y;
+							float gradScale = outScale*rangeScale;
+							float r = (b - prev.y)*rangeScale;
+							float h = r*r*(3 - 2*r);
+							float outB = b + outOffset + h*outScale;
+							float gradH = 6*r*(1 - r);
+							mp = make_float2(outB, 1 + gradH*gradScale);
+						}
+					}
+				}
+				mapRow[b] = mp;
+			}
 		}
 	}
 	if (formants && prm.formantBaseFreq <= 0) {
@@ -1065,11 +1118,7 @@ __global__ __launch_bounds__(256) void kFeedScanC(DevBatch d, int sBase, int hop
 	float *sm = en + M;
 	ScanMap *maps = reinterpret_cast<ScanMap *>(sm + M);
 	const StreamParams prm = d.params[sg];
-	for (int b = t; b < M; b += 256) {
-		float e = 0;
-		for (int c = 0; c < C; ++c) e += cnorm(inputRow(d, hd, s, sg, c)[b]);
-		en[b] = e;
-	}
+	feedEnergyToLds(d, hd, s, sg, en);
 	__syncthreads();
 	const float freqEstimate = d.freqEst[(size_t)s*d.T + k];
 	float decay = 1 - 1/(freqEstimate*0.5f + 1);
