@@ -902,6 +902,51 @@ __device__ __forceinline__ float scanPass(const float *src, float *dst, int M, f
 	return total;
 }
 
+// The same pass with every thread's chunk in REGISTERS.  Thread t owns bins [t*n, t*n + cnt) in both directions (the LDS form
+// above partitions by pass position, so an up pass and a down pass give a thread different bins and every pass goes through
+// LDS with two barriers and two dependent-latency walks); only the chunk maps cross lanes (shuffles, towards higher lanes for
+// an up pass, towards lower lanes for a down pass) and the four wave totals cross waves (LDS, one barrier: the totals of
+// consecutive passes use alternate halves of `maps`).  v[i], i < cnt: in = the pass's source, out = its result.
+template <int OP, bool DOWN, int NMAX, typename COf, typename Step>
+__device__ __forceinline__ float scanPassReg(float (&v)[NMAX], int cnt, float carry, float mStep, COf cOf, Step step, ScanMap *maps) {
+	const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+	ScanMap f; f.m = 1.0f; f.c = OP == 0 ? 0.0f : (OP == 1 ? -INFINITY : INFINITY); // identity
+#pragma unroll
+	for (int j = 0; j < NMAX; ++j) {
+		const int i = DOWN ? NMAX - 1 - j : j;
+		if (i < cnt) { ScanMap g; g.m = mStep; g.c = cOf(v[i]); f = scanCompose<OP>(g, f); }
+	}
+	ScanMap inc = f;
+#pragma unroll
+	for (int dlt = 1; dlt < 64; dlt <<= 1) {
+		const int from = DOWN ? min(lane + dlt, 63) : max(lane - dlt, 0);
+		ScanMap prev;
+		prev.m = __shfl(inc.m, from);
+		prev.c = __shfl(inc.c, from);
+		if (DOWN ? (lane + dlt <= 63) : (lane >= dlt)) inc = scanCompose<OP>(inc, prev);
+	}
+	ScanMap ex; // the chunks before this one in pass order, inside the wave
+	ex.m = __shfl(inc.m, DOWN ? min(lane + 1, 63) : max(lane - 1, 0));
+	ex.c = __shfl(inc.c, DOWN ? min(lane + 1, 63) : max(lane - 1, 0));
+	if (lane == (DOWN ? 63 : 0)) { ex.m = 1.0f; ex.c = OP == 0 ? 0.0f : (OP == 1 ? -INFINITY : INFINITY); }
+	if (lane == (DOWN ? 0 : 63)) maps[w] = inc;
+	__syncthreads();
+	float e = carry, total = carry;
+#pragma unroll
+	for (int j = 0; j < 4; ++j) {
+		const int ww = DOWN ? 3 - j : j; // waves in pass order
+		if (DOWN ? (ww > w) : (ww < w)) e = scanApply<OP>(maps[ww], e);
+		total = scanApply<OP>(maps[ww], total);
+	}
+	e = scanApply<OP>(ex, e);
+#pragma unroll
+	for (int j = 0; j < NMAX; ++j) {
+		const int i = DOWN ? NMAX - 1 - j : j;
+		if (i < cnt) { e = step(e, v[i]); v[i] = e; }
+	}
+	return total;
+}
+
 // channel-summed energy of one hop into LDS, en[b] = sum_c |input_c[b]|^2 in channel order.  Eight independent loads per
 // channel are in flight at a time: the plain loop (one bin per iteration, trip count unknown to the compiler) paid a full
 // memory round trip per iteration -- 13 of them per workgroup, 27 % of the kernel (ablation on the GPU: 16.1 -> 11.7 ms
@@ -926,6 +971,7 @@ __device__ __forceinline__ void feedEnergyToLds(const DevBatch &d, const HopDesc
 }
 
 // energy, smoothing, peaks, output map, raw pitch estimate: one workgroup per (hop, stream)
+template <int NMAX> // bins per thread held in registers during the smoothing passes; 0: through LDS (any M)
 __global__ __launch_bounds__(256) void kFeedScanA(DevBatch d, int sBase, int hopBase) {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smemRaw[];
 	const int k = blockIdx.x, s = blockIdx.y, sg = sBase + s;
@@ -949,10 +995,24 @@ __global__ __launch_bounds__(256) void kFeedScanA(DevBatch d, int sBase, int hop
 		auto pole = [slew](float acc, float x) { return acc + (x - acc)*slew; };
 		auto cOf = [slew](float x) { return slew*x; };
 		float e = 0;
-		e = scanPass<0, true>(en, sm, M, e, 1 - slew, cOf, pole, maps);
-		e = scanPass<0, false>(sm, sm, M, e, 1 - slew, cOf, pole, maps);
-		e = scanPass<0, true>(sm, sm, M, e, 1 - slew, cOf, pole, maps);
-		e = scanPass<0, false>(sm, sm, M, e, 1 - slew, cOf, pole, maps);
+		if constexpr (NMAX > 0) {
+			const int n = (M + 255)/256, cnt = min(max(M - t*n, 0), n);
+			float v[NMAX];
+#pragma unroll
+			for (int i = 0; i < NMAX; ++i) v[i] = (i < cnt) ? en[t*n + i] : 0.0f;
+			e = scanPassReg<0, true>(v, cnt, e, 1 - slew, cOf, pole, maps);
+			e = scanPassReg<0, false>(v, cnt, e, 1 - slew, cOf, pole, maps + 4);
+			e = scanPassReg<0, true>(v, cnt, e, 1 - slew, cOf, pole, maps);
+			e = scanPassReg<0, false>(v, cnt, e, 1 - slew, cOf, pole, maps + 4);
+#pragma unroll
+			for (int i = 0; i < NMAX; ++i) if (i < cnt) sm[t*n + i] = v[i];
+			__syncthreads();
+		} else {
+			e = scanPass<0, true>(en, sm, M, e, 1 - slew, cOf, pole, maps);
+			e = scanPass<0, false>(sm, sm, M, e, 1 - slew, cOf, pole, maps);
+			e = scanPass<0, true>(sm, sm, M, e, 1 - slew, cOf, pole, maps);
+			e = scanPass<0, false>(sm, sm, M, e, 1 - slew, cOf, pole, maps);
+		}
 		// findPeaks: every thread counts the runs that START in its chunk, an exclusive scan numbers them, and the owner
 		// of a run's first bin sums the run in the reference's order (:866-873)
 		const int n = (M + 255)/256, b0 = t*n, b1 = min(M, b0 + n);
@@ -1106,6 +1166,7 @@ __global__ __launch_bounds__(64) void kFeedFreq(DevBatch d, int sBase, int nStre
 }
 
 // formant envelope (2 x (down, up) max-decay, 2 x (down, up) min-grow, :987-1006) and the per-bin energy ratio (:1018-1033)
+template <int NMAX>
 __global__ __launch_bounds__(256) void kFeedScanC(DevBatch d, int sBase, int hopBase) {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smemRaw[];
 	const int k = blockIdx.x, s = blockIdx.y, sg = sBase + s;
@@ -1123,23 +1184,49 @@ __global__ __launch_bounds__(256) void kFeedScanC(DevBatch d, int sBase, int hop
 	const float freqEstimate = d.freqEst[(size_t)s*d.T + k];
 	float decay = 1 - 1/(freqEstimate*0.5f + 1);
 	float e = 0;
-	{
-		const float dk = decay;
-		auto maxDecay = [dk](float acc, float x) { return fmaxf(x, acc*dk); };
-		auto cOf = [](float x) { return x; };
-		e = scanPass<1, true>(en, sm, M, e, dk, cOf, maxDecay, maps);
-		e = scanPass<1, false>(sm, sm, M, e, dk, cOf, maxDecay, maps);
-		e = scanPass<1, true>(sm, sm, M, e, dk, cOf, maxDecay, maps);
-		e = scanPass<1, false>(sm, sm, M, e, dk, cOf, maxDecay, maps);
-	}
-	decay = 1/decay;
-	{
-		const float dk = decay;
-		auto minGrow = [dk](float acc, float x) { return fminf(x, acc*dk); };
-		auto cOf = [](float x) { return x; };
-		for (int rep = 0; rep < 2; ++rep) {
-			e = scanPass<2, true>(sm, sm, M, e, dk, cOf, minGrow, maps);
-			e = scanPass<2, false>(sm, sm, M, e, dk, cOf, minGrow, maps);
+	auto ident = [](float x) { return x; };
+	if constexpr (NMAX > 0) {
+		const int n = (M + 255)/256, cnt = min(max(M - t*n, 0), n);
+		float v[NMAX];
+#pragma unroll
+		for (int i = 0; i < NMAX; ++i) v[i] = (i < cnt) ? en[t*n + i] : 0.0f;
+		{
+			const float dk = decay;
+			auto maxDecay = [dk](float acc, float x) { return fmaxf(x, acc*dk); };
+			e = scanPassReg<1, true>(v, cnt, e, dk, ident, maxDecay, maps);
+			e = scanPassReg<1, false>(v, cnt, e, dk, ident, maxDecay, maps + 4);
+			e = scanPassReg<1, true>(v, cnt, e, dk, ident, maxDecay, maps);
+			e = scanPassReg<1, false>(v, cnt, e, dk, ident, maxDecay, maps + 4);
+		}
+		decay = 1/decay;
+		{
+			const float dk = decay;
+			auto minGrow = [dk](float acc, float x) { return fminf(x, acc*dk); };
+			for (int rep = 0; rep < 2; ++rep) {
+				e = scanPassReg<2, true>(v, cnt, e, dk, ident, minGrow, maps);
+				e = scanPassReg<2, false>(v, cnt, e, dk, ident, minGrow, maps + 4);
+			}
+		}
+#pragma unroll
+		for (int i = 0; i < NMAX; ++i) if (i < cnt) sm[t*n + i] = v[i];
+		__syncthreads();
+	} else {
+		{
+			const float dk = decay;
+			auto maxDecay = [dk](float acc, float x) { return fmaxf(x, acc*dk); };
+			e = scanPass<1, true>(en, sm, M, e, dk, ident, maxDecay, maps);
+			e = scanPass<1, false>(sm, sm, M, e, dk, ident, maxDecay, maps);
+			e = scanPass<1, true>(sm, sm, M, e, dk, ident, maxDecay, maps);
+			e = scanPass<1, false>(sm, sm, M, e, dk, ident, maxDecay, maps);
+		}
+		decay = 1/decay;
+		{
+			const float dk = decay;
+			auto minGrow = [dk](float acc, float x) { return fminf(x, acc*dk); };
+			for (int rep = 0; rep < 2; ++rep) {
+				e = scanPass<2, true>(sm, sm, M, e, dk, ident, minGrow, maps);
+				e = scanPass<2, false>(sm, sm, M, e, dk, ident, minGrow, maps);
+			}
 		}
 	}
 	float *ratio = d.ratio + ((size_t)s*d.T + k)*M;
@@ -2691,10 +2778,15 @@ void launchFeed(const DevBatch &d, int sBase, int nStreams, int hopBase, int til
 	}
 	const size_t ldsA = (size_t)2*d.M*sizeof(float) + (size_t)(d.M/2 + 2)*sizeof(float2) + 264*sizeof(ScanMap) + 264*sizeof(int);
 	const size_t ldsC = (size_t)2*d.M*sizeof(float) + 264*sizeof(ScanMap);
-	hipLaunchKernelGGL(kFeedScanA, dim3(tileHops, nStreams), dim3(256), ldsA, st, d, sBase, hopBase);
+	const int perThread = divUp(d.M, 256); // bins per thread: in registers up to 24 (M <= 6144), through LDS beyond
+	if (perThread <= 16) hipLaunchKernelGGL(kFeedScanA<16>, dim3(tileHops, nStreams), dim3(256), ldsA, st, d, sBase, hopBase);
+	else if (perThread <= 24) hipLaunchKernelGGL(kFeedScanA<24>, dim3(tileHops, nStreams), dim3(256), ldsA, st, d, sBase, hopBase);
+	else hipLaunchKernelGGL(kFeedScanA<0>, dim3(tileHops, nStreams), dim3(256), ldsA, st, d, sBase, hopBase);
 	if (anyFormants) {
 		hipLaunchKernelGGL(kFeedFreq, dim3(divUp(nStreams, 64)), dim3(64), 0, st, d, sBase, nStreams, hopBase);
-		hipLaunchKernelGGL(kFeedScanC, dim3(tileHops, nStreams), dim3(256), ldsC, st, d, sBase, hopBase);
+		if (perThread <= 16) hipLaunchKernelGGL(kFeedScanC<16>, dim3(tileHops, nStreams), dim3(256), ldsC, st, d, sBase, hopBase);
+		else if (perThread <= 24) hipLaunchKernelGGL(kFeedScanC<24>, dim3(tileHops, nStreams), dim3(256), ldsC, st, d, sBase, hopBase);
+		else hipLaunchKernelGGL(kFeedScanC<0>, dim3(tileHops, nStreams), dim3(256), ldsC, st, d, sBase, hopBase);
 	}
 }
 template <int CH>
