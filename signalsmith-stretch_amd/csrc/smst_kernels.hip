@@ -1017,7 +1017,18 @@ __global__ __launch_bounds__(256) void kFeedScanA(DevBatch d, int sBase, int hop
 		// of a run's first bin sums the run in the reference's order (:866-873)
 		const int n = (M + 255)/256, b0 = t*n, b1 = min(M, b0 + n);
 		int starts = 0;
-		for (int b = b0; b < b1; ++b) starts += (en[b] > sm[b]) && !(b > 0 && en[b - 1] > sm[b - 1]);
+		unsigned startMask = 0; // bit i: a run starts at bin b0 + i
+		if constexpr (NMAX > 0) { // the chunk's energies and smoothed energies side by side in registers: 2 n independent LDS reads
+			bool prevAbove = b0 > 0 && b0 <= M && en[b0 - 1] > sm[b0 - 1];
+#pragma unroll
+			for (int i = 0; i < NMAX; ++i) {
+				const bool above = (b0 + i < b1) && en[min(b0 + i, M - 1)] > sm[min(b0 + i, M - 1)];
+				if (above && !prevAbove) { startMask |= 1u << i; ++starts; }
+				prevAbove = above;
+			}
+		} else {
+			for (int b = b0; b < b1; ++b) starts += (en[b] > sm[b]) && !(b > 0 && en[b - 1] > sm[b - 1]);
+		}
 		{ // exclusive prefix sum of the run starts: lane shuffles inside the wave (a serial 64-entry loop by one lane per wave
 			// cost 6 us per workgroup), wave totals through LDS
 			const int lane = t & 63;
@@ -1035,7 +1046,7 @@ __global__ __launch_bounds__(256) void kFeedScanA(DevBatch d, int sBase, int hop
 		for (int w = 0; w < (t >> 6); ++w) idx += counts[256 + w];
 		const int nPeaks = counts[256] + counts[257] + counts[258] + counts[259];
 		for (int b = b0; b < b1; ++b) {
-			if ((en[b] > sm[b]) && !(b > 0 && en[b - 1] > sm[b - 1])) {
+			if (NMAX > 0 ? ((startMask >> (b - b0)) & 1u) != 0 : ((en[b] > sm[b]) && !(b > 0 && en[b - 1] > sm[b - 1]))) {
 				float bandSum = 0, energySum = 0;
 				for (int q = b; q < M; q += 4) { // four bins per LDS round trip; the additions stay in the reference's order
 					float e4[4], s4[4];
@@ -1060,52 +1071,85 @@ __global__ __launch_bounds__(256) void kFeedScanA(DevBatch d, int sBase, int hop
 		const float2 first = nPeaks > 0 ? pk[0] : make_float2(0.f, 0.f);
 		const float2 lastP = nPeaks > 0 ? pk[nPeaks - 1] : make_float2(0.f, 0.f);
 		const int topStart = max(0, (int)lastP.y), bottomEnd = min(M, (int)ceilf(first.y));
-		// The covering pair of peaks of every bin by bisection.  A thread's bins are 256 apart, so their bisections are
-		// independent: eight run in lock step (eight LDS reads in flight per round instead of one dependent read at a time --
-		// the one-at-a-time version cost 2.7 of the kernel's 16 ms per step of config 3).
-		for (int b0 = t; b0 < M; b0 += 8*256) {
-			int lo[8], hi[8];
-#pragma unroll
-			for (int i = 0; i < 8; ++i) { lo[i] = 0; hi[i] = nPeaks - 2; }
-			if (nPeaks >= 2) {
-				for (int span = nPeaks - 2; span > 0; span >>= 1) { // ceil(log2(nPeaks - 1)) rounds settle every bisection
-					float y[8];
-#pragma unroll
-					for (int i = 0; i < 8; ++i) y[i] = pk[(lo[i] + hi[i] + 1) >> 1].y;
-#pragma unroll
-					for (int i = 0; i < 8; ++i) {
-						const int mid = (lo[i] + hi[i] + 1) >> 1;
-						if (lo[i] < hi[i]) { if (max(0, (int)ceilf(y[i])) <= b0 + 256*i) lo[i] = mid; else hi[i] = mid - 1; }
+		auto mapOf = [&](int b, int lo) { // lo = largest q in [0, nPeaks-2] with max(0, ceil(peaks[q].out)) <= b (only used between bottomEnd and topStart)
+			float2 mp = make_float2(float(b), 1.0f);
+			if (nPeaks > 0) {
+				if (b >= topStart) {
+					mp = make_float2(b + (lastP.x - lastP.y), 1.0f);
+				} else if (b < bottomEnd) {
+					mp = make_float2(b + (first.x - first.y), 1.0f);
+				} else if (nPeaks >= 2) {
+					const float2 prev = pk[lo], next = pk[lo + 1];
+					if (b < min(M, (int)ceilf(next.y))) {
+						float rangeScale = 1/(next.y - prev.y);
+						float outOffset = prev.x - prev.y;
+						float outScale = next.x - next.y - prev.x + prev.y;
+						float gradScale = outScale*rangeScale;
+						float r = (b - prev.y)*rangeScale;
+						float h = r*r*(3 - 2*r);
+						float outB = b + outOffset + h*outScale;
+						float gradH = 6*r*(1 - r);
+						mp = make_float2(outB, 1 + gradH*gradScale);
 					}
 				}
 			}
+			return mp;
+		};
+		if constexpr (NMAX > 0) {
+			// The covering pair of every bin without a search: every peak marks the bin its segment starts at (LDS atomic max:
+			// several peaks may start at one bin, the last one counts), a prefix maximum over the bins spreads the marks.  The
+			// bisection it replaces cost ten rounds of nine instructions per bin for a noise spectrum (700 peaks): 5.2 of the
+			// kernel's 13 ms per step of config 3.  Same result for ascending peak positions (every map the tonality-limit rule
+			// or an ascending table produces); for a descending custom map both are arbitrary.
+			int *cover = reinterpret_cast<int *>(sm);          // the smoothed energies are dead after the run sums
+			int *waveMax = reinterpret_cast<int *>(maps + 8);
+			const int cnt = max(b1 - b0, 0), lane = t & 63, w = t >> 6;
 #pragma unroll
-			for (int i = 0; i < 8; ++i) {
-				const int b = b0 + 256*i;
-				if (b >= M) continue;
-				float2 mp = make_float2(float(b), 1.0f);
-				if (nPeaks > 0) {
-					if (b >= topStart) {
-						mp = make_float2(b + (lastP.x - lastP.y), 1.0f);
-					} else if (b < bottomEnd) {
-						mp = make_float2(b + (first.x - first.y), 1.0f);
-					} else if (nPeaks >= 2) {
-						// lo = largest q in [0, nPeaks-2] with max(0, ceil(peaks[q].out)) <= b (q = 0 qualifies: b >= bottomEnd)
-						const float2 prev = pk[lo[i]], next = pk[lo[i] + 1];
-						if (b < min(M, (int)ceilf(next.y))) {
-							float rangeScale = 1/(next.y - prev.y);
-							float outOffset = prev.x - prev.y;
-							float outScale = next.x - next.y - prev.x + prev.y;
-							float gradScale = outScale*rangeScale;
-							float r = (b - prev.y)*rangeScale;
-							float h = r*r*(3 - 2*r);
-							float outB = b + outOffset + h*outScale;
-							float gradH = 6*r*(1 - r);
-							mp = make_float2(outB, 1 + gradH*gradScale);
+			for (int i = 0; i < NMAX; ++i) if (i < cnt) cover[b0 + i] = -1;
+			__syncthreads();
+			for (int q = t; q <= nPeaks - 2; q += 256) {
+				const int start = max(0, (int)ceilf(pk[q].y));
+				if (start < M) atomicMax(&cover[start], q);
+			}
+			__syncthreads();
+			int c[NMAX], run = -1;
+#pragma unroll
+			for (int i = 0; i < NMAX; ++i) { if (i < cnt) run = max(run, cover[b0 + i]); c[i] = run; }
+			int inc = run;
+#pragma unroll
+			for (int dlt = 1; dlt < 64; dlt <<= 1) {
+				const int prev = __shfl(inc, max(lane - dlt, 0));
+				if (lane >= dlt) inc = max(inc, prev);
+			}
+			int base = __shfl(inc, max(lane - 1, 0));
+			if (lane == 0) base = -1;
+			if (lane == 63) waveMax[w] = inc;
+			__syncthreads();
+			for (int ww = 0; ww < w; ++ww) base = max(base, waveMax[ww]);
+#pragma unroll
+			for (int i = 0; i < NMAX; ++i) if (i < cnt) cover[b0 + i] = max(c[i], base);
+			__syncthreads();
+			for (int b = t; b < M; b += 256) mapRow[b] = mapOf(b, max(cover[b], 0)); // coalesced stores
+		} else {
+			// by bisection; a thread's bins are 256 apart, so eight independent bisections run in lock step
+			for (int bb = t; bb < M; bb += 8*256) {
+				int lo[8], hi[8];
+#pragma unroll
+				for (int i = 0; i < 8; ++i) { lo[i] = 0; hi[i] = nPeaks - 2; }
+				if (nPeaks >= 2) {
+					for (int span = nPeaks - 2; span > 0; span >>= 1) { // ceil(log2(nPeaks - 1)) rounds settle every bisection
+						float y[8];
+#pragma unroll
+						for (int i = 0; i < 8; ++i) y[i] = pk[(lo[i] + hi[i] + 1) >> 1].y;
+#pragma unroll
+						for (int i = 0; i < 8; ++i) {
+							const int mid = (lo[i] + hi[i] + 1) >> 1;
+							if (lo[i] < hi[i]) { if (max(0, (int)ceilf(y[i])) <= bb + 256*i) lo[i] = mid; else hi[i] = mid - 1; }
 						}
 					}
 				}
-				mapRow[b] = mp;
+#pragma unroll
+				for (int i = 0; i < 8; ++i) if (bb + 256*i < M) mapRow[bb + 256*i] = mapOf(bb + 256*i, max(lo[i], 0));
 			}
 		}
 	}

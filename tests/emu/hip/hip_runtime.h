@@ -116,6 +116,7 @@ static inline int __shfl(int v, int lane) { return emuShflI(v, lane); }
 int emuDppShr1(int old, int v);
 static inline int __builtin_amdgcn_update_dpp(int old, int src, int ctrl, int, int, bool) { (void)ctrl; return emuDppShr1(old, src); }
 static inline int atomicAdd(int *p, int v) { int o = *p; *p = o + v; return o; }
+static inline int atomicMax(int *p, int v) { int o = *p; if (v > o) *p = v; return o; }
 #define __HIP_MEMORY_SCOPE_WORKGROUP 2
 #define __hip_atomic_load(p, order, scope) (*(volatile int *)(p))
 #define __hip_atomic_store(p, v, order, scope) (*(volatile int *)(p) = (v))
