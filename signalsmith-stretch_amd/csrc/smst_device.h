@@ -46,7 +46,7 @@ struct DevBatch {
 	const EmitDesc *emit;  // [S][emitStride]
 	// per-tile workspace, [subS][T][C][M] unless noted
 	float2 *Xcur, *Xprev, *OUT;
-	float4 *PE;     // (Prediction.input, Prediction.energy, -) per (hop, channel, bin): [subS][T][C][Mp]
+	PredEntry *PE;  // (Prediction.input, Prediction.energy) per (hop, channel, bin), 12 bytes: [subS][T][C][Mp]
 	float2 *dump;   // [subS][C][64] parking lot for the recurrence kernel's out-of-range lanes
 	float4 *REC;    // skewed per-step records of the bin recurrence [subS][recSteps][chunks][64 lanes]
 	float2 *map;    // [subS][T][M]

@@ -370,7 +370,7 @@ void Batch::allocateWorkspace() {
 	d.recSteps = ((M + d.lag*(d.T - 1) + 63)/64)*64 + 8;
 	d.recPitch = int(recChunks*64 + 16);
 	d.Mp = (M + 32 + 15) & ~15; // rows start on 128-byte lines (the recurrence's writer stores aligned 64-byte groups)
-	const size_t perStream = (size_t)d.T*((size_t)C*((size_t)d.Mp*(3*sizeof(float2) + sizeof(float4)) + (size_t)B*sizeof(float))
+	const size_t perStream = (size_t)d.T*((size_t)C*((size_t)d.Mp*(3*sizeof(float2) + sizeof(PredEntry)) + (size_t)B*sizeof(float))
 	                                      + (size_t)M*(sizeof(float2) + sizeof(float)) + 3*sizeof(float))
 	                         + (size_t)C*64*sizeof(float2)
 	                         + (needRecords ? (size_t)d.recSteps*d.recPitch*sizeof(float4) : 0)
@@ -389,7 +389,7 @@ void Batch::allocateWorkspace() {
 				w = TileBuffers{};
 				w.Xcur = devAlloc<float2>(rows);
 				w.Xprev = devAlloc<float2>(rows);
-				w.PE = devAlloc<float4>(rows);
+				w.PE = devAlloc<PredEntry>(rows);
 				w.OUT = devAlloc<float2>(rows);
 				if (needRecords) {
 					w.REC = devAlloc<float4>((size_t)subS*d.recSteps*d.recPitch);

@@ -112,7 +112,7 @@ private:
 	} callSets[2]{};
 	int callCur = 0;
 	hipEvent_t evStart = nullptr, evFeed[2] = {nullptr, nullptr}, evChain[2] = {nullptr, nullptr}, evSynth[2] = {nullptr, nullptr};
-	struct TileBuffers { float2 *Xcur, *Xprev, *OUT, *dump, *map, *peaksT; float4 *REC, *PE; float *ratio, *energyT, *smoothT, *est, *freqEst, *frames; } slots[2]{};
+	struct TileBuffers { float2 *Xcur, *Xprev, *OUT, *dump, *map, *peaksT; float4 *REC; PredEntry *PE; float *ratio, *energyT, *smoothT, *est, *freqEst, *frames; } slots[2]{};
 	bool overlap = true, noFuse = false, noSingleHop = false;
 	int subS = 0;
 	// per-call host scratch, kept between calls (no heap traffic in steady state); growth events are counted

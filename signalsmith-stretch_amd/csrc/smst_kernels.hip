@@ -1366,8 +1366,12 @@ __global__ __launch_bounds__(256) void kPredictA(DevBatch d, int sBase, int hopB
 			if (loIn) eLo *= ratio[li.lo];
 			if (hiIn) eHi *= ratio[li.lo + 1];
 		}
-		// Prediction.input and Prediction.energy of a bin side by side: their readers fetch both with one 16-byte load
-		d.PE[o] = make_float4(inLo.x + (inHi.x - inLo.x)*li.fr, inLo.y + (inHi.y - inLo.y)*li.fr, (eLo + (eHi - eLo)*li.fr)*gradScale, 0.0f);
+		// Prediction.input and Prediction.energy of a bin side by side: their readers fetch both with one 12-byte load
+		PredEntry pe;
+		pe.x = inLo.x + (inHi.x - inLo.x)*li.fr;
+		pe.y = inLo.y + (inHi.y - inLo.y)*li.fr;
+		pe.e = (eLo + (eHi - eLo)*li.fr)*gradScale;
+		d.PE[o] = pe;
 	}
 }
 
@@ -1399,7 +1403,8 @@ struct RecordSource {
 	// (Prediction.input.x, .y, Prediction.energy, -) of channel c at bin b
 	__device__ __forceinline__ float4 PE(int c, int b) const {
 		if (PLAIN) { const float2 p = in0[(size_t)c*pitch + b]; return make_float4(p.x, p.y, cnorm(p), 0.0f); }
-		return d.PE[rowOf(d, s, k, c) + b];
+		const PredEntry pe = d.PE[rowOf(d, s, k, c) + b];
+		return make_float4(pe.x, pe.y, pe.e, 0.0f);
 	}
 	__device__ __forceinline__ float2 mapAt(int b) const {
 		if (PLAIN) return make_float2(float(b), 1.0f);
@@ -1495,7 +1500,7 @@ __device__ __forceinline__ void computeRecord(const DevBatch &d, const HopDesc &
 		// Prediction.energy of the previous hop: the carried state for the tile's first hop, else hop k-1's
 		// the carried state is a plain float row; inside the tile the energy is the third float of hop k-1's (P, E) entries
 		const float *EprevRow = (k == 0) ? d.stEnergy + stateRow(d, sg, cm) : (PLAIN ? nullptr : reinterpret_cast<const float *>(d.PE + rowOf(d, s, k - 1, cm)) + 2);
-		const int eprevStride = (k == 0) ? 1 : 4;
+		const int eprevStride = (k == 0) ? 1 : 3;
 		const float2 *inPrevHop = (PLAIN && k > 0) ? inputRow(d, hp, s, sg, cm) : nullptr;
 		const float2 zero = make_float2(0.f, 0.f);
 		A = cmulc(Pcm, lerpBand(in, lerpIndex(mp.x - tfUp), M));
@@ -2646,7 +2651,7 @@ __global__ __launch_bounds__(256) void kCarryFeed(DevBatch d, int sBase, int hop
 	{
 		const HopDesc hl = d.hops[(size_t)sg*d.hopStride + hopBase + nh - 1];
 		const bool plain = !(hl.flags & (HOP_MAPPED | HOP_FORMANTS));
-		storeCarriedEnergy(d, stateRow(d, sg, c) + b, plain ? cnorm(inputRow(d, hl, s, sg, c)[b]) : d.PE[rowOf(d, s, nh - 1, c) + b].z);
+		storeCarriedEnergy(d, stateRow(d, sg, c) + b, plain ? cnorm(inputRow(d, hl, s, sg, c)[b]) : d.PE[rowOf(d, s, nh - 1, c) + b].e);
 	}
 	if (anyFormants && b == 0 && c == 0) { // a serial walk over the tile's hops: skipped for tiles without formant processing
 		float w = d.stFreq[2*sg], wt = d.stFreq[2*sg + 1];

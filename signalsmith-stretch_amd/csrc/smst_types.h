@@ -58,6 +58,10 @@ struct StreamParams {
 typedef _Float16 half_t;
 struct Half2 { half_t x, y; };
 
+// Prediction.input and Prediction.energy of one (hop, channel, bin), packed to 12 bytes: written once by pass A, read by the
+// record producers with one 12-byte load (the 16-byte float4 it replaces carried a quarter of dead bytes through HBM)
+struct PredEntry { float x, y, e; };
+
 struct FftPlan {
 	int H;      // complex FFT length = fftSamples/2 = bands
 	int N;      // fftSamples
