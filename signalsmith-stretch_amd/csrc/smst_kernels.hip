@@ -1338,9 +1338,9 @@ __device__ __forceinline__ float2 lerpBand(const float2 *row, LerpIndex li, int 
 	const BandPair p = pairAt(row, li.lo, M);
 	return make_float2(p.lo.x + (p.hi.x - p.lo.x)*li.fr, p.lo.y + (p.hi.y - p.lo.y)*li.fr);
 }
-__device__ __forceinline__ float2 rotAt(const DevBatch &d, int idx, bool rotate) { // hop rotation of bin idx, 1 outside / when off
-	const int ci = min(max(idx, 0), d.M - 1);
-	const float2 v = d.rot[ci];
+__device__ __forceinline__ float2 rotAt(const float2 *rot, int M, int idx, bool rotate) { // hop rotation of bin idx, 1 outside / when off
+	const int ci = min(max(idx, 0), M - 1);
+	const float2 v = rot[ci];
 	return (rotate && ci == idx) ? v : make_float2(1.f, 0.f);
 }
 
@@ -1416,18 +1416,19 @@ struct RecordSource {
 // coefficient multiplying the previous hop's final output at bin bx (bx = b+1 or b+L), see the record description
 template <int CH, bool PLAIN>
 __device__ __forceinline__ float2 twistAt(const RecordSource<CH, PLAIN> &src, int mc, int bx, float2 mp, bool rotate, const float2 *in,
-                                          const float2 *pv, const float *EprevRow, int eprevStride, const float2 *inPrevHop, float tfDown, float stepMul) {
+                                          const float2 *pv, const float *EprevRow, int eprevStride, const float2 *inPrevHop, float tfDown, float stepMul,
+                                          const float2 *rot) {
 	// bx may be one past the last bin for the callers' masked-out cases: every access below clamps; mp = mapAt(min(bx, M-1))
 	const DevBatch &d = src.d;
 	const int M = src.M;
 	const int bc = min(bx, M - 1);
-	const float2 rotB = rotAt(d, bc, rotate);
+	const float2 rotB = rotAt(rot, M, bc, rotate);
 	float2 Q;
 	if (PLAIN) { // identity map: the previous-input tap sits exactly on bin bc (fraction 0), and shares its rotation
 		Q = cmul(pv[bc], rotB);
 	} else {
 		const LerpIndex li = lerpIndex(mp.x);
-		const BandPair pvp = pairAt(pv, li.lo, M), rp = pairAt(d.rot, li.lo, M); // two 16-byte loads instead of four 8-byte ones
+		const BandPair pvp = pairAt(pv, li.lo, M), rp = pairAt(rot, li.lo, M); // two 16-byte loads instead of four 8-byte ones
 		const bool loIn = li.lo >= 0 && li.lo < M, hiIn = li.lo + 1 >= 0 && li.lo + 1 < M;
 		const float2 one = make_float2(1.f, 0.f);
 		const float2 qLo = cmul(pvp.lo, (rotate && loIn) ? rp.lo : one);
@@ -1452,8 +1453,13 @@ __device__ __forceinline__ float2 twistAt(const RecordSource<CH, PLAIN> &src, in
 // Fills one record.  Per-channel fields: {P.x, P.y, sqrt(E)} and, with LOCK, the channel-lock twist P_c conj(P_m).
 // SPEC (mono/stereo): the four twists are evaluated for EVERY channel and the maximum-energy channel's set is
 // selected afterwards, so no load address depends on loaded data (one memory round trip per record instead of two).
-template <int CH, bool PLAIN, bool LOCK, bool SPEC, int NFLOATS>
-__device__ __forceinline__ void computeRecord(const DevBatch &d, const HopDesc &hd, const HopDesc &hp, int s, int sg, int k, int b, float (&f)[NFLOATS]) {
+// ROT_LDS: the hop-rotation table is read from `rotLds` (a copy in LDS) instead of d.rot -- three of a mapped record's 18
+// gathers per twist pair go to the table, and the texture-address unit is what bounds the gathering producers.
+template <int CH, bool PLAIN, bool LOCK, bool SPEC, int NFLOATS, bool ROT_LDS = false>
+__device__ __forceinline__ void computeRecord(const DevBatch &d, const HopDesc &hd, const HopDesc &hp, int s, int sg, int k, int b, float (&f)[NFLOATS],
+                                              const float2 *rotLds = nullptr) {
+	const float2 *rot;
+	if constexpr (ROT_LDS) rot = rotLds; else rot = d.rot;
 	constexpr int PC = LOCK ? 5 : 3;
 	const int M = d.M, L = d.L;
 	const bool rotate = hd.flags & HOP_NEW_SPECTRUM, randomTf = hd.flags & HOP_RANDOM_TF;
@@ -1505,8 +1511,8 @@ __device__ __forceinline__ void computeRecord(const DevBatch &d, const HopDesc &
 		const float2 zero = make_float2(0.f, 0.f);
 		A = cmulc(Pcm, lerpBand(in, lerpIndex(mp.x - tfUp), M));
 		B = cmulc(Pcm, lerpBand(in, lerpIndex(mp.x - L*tfUp), M));
-		Cc = twistAt<CH, PLAIN>(src, cm, b + 1, mp1, rotate, in, pv, EprevRow, eprevStride, inPrevHop, tfDn, 1.0f);
-		Dc = twistAt<CH, PLAIN>(src, cm, b + L, mpL, rotate, in, pv, EprevRow, eprevStride, inPrevHop, tfDn, float(L));
+		Cc = twistAt<CH, PLAIN>(src, cm, b + 1, mp1, rotate, in, pv, EprevRow, eprevStride, inPrevHop, tfDn, 1.0f, rot);
+		Dc = twistAt<CH, PLAIN>(src, cm, b + L, mpL, rotate, in, pv, EprevRow, eprevStride, inPrevHop, tfDn, float(L), rot);
 		if (!(b > 0)) A = zero;      // :748
 		if (!(b >= L)) B = zero;     // :756
 		if (!(b < M - 1)) Cc = zero; // :765
@@ -1948,9 +1954,10 @@ __device__ __forceinline__ float2 fromLaneBelow(float2 v, float2 lane0) { // lan
 	                   __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(lane0.y), __float_as_int(v.y), 0x138, 0xf, 0xf, false)));
 }
 
-template <int CH, bool PLAIN, int L, bool STAGED>
+template <int CH, bool PLAIN, int L, bool STAGED, bool ROTL = false>
 __global__ __launch_bounds__(64*kVocWaves) __attribute__((amdgpu_waves_per_eu(4, 4))) void kVocoder(DevBatch d, int sBase, int hopBase) {
 	static_assert(!STAGED || (PLAIN && L <= 5), "staged producers: identity map, bounded windows");
+	static_assert(!ROTL || (!PLAIN && !STAGED), "the LDS copy of the rotation table serves the gathering producers of mapped tiles");
 	constexpr int NF = 9 + 3*CH, NCH = (NF + 3)/4, BS = kVocBlockSteps, NB = STAGED ? kVocBlocksStaged : kVocBlocks;
 	constexpr int NP = STAGED ? kVocStagedProducers : kVocWaves - 2;
 	constexpr int lag = L + 1;
@@ -1981,6 +1988,10 @@ __global__ __launch_bounds__(64*kVocWaves) __attribute__((amdgpu_waves_per_eu(4,
 	}
 	if (threadIdx.x <= NB + 2) sync[threadIdx.x] = 0;
 	if (threadIdx.x < 64) hopsLds[threadIdx.x] = d.hops[(size_t)sg*d.hopStride + hopBase + threadIdx.x];
+	float2 *rotLds = outRing + (size_t)kVocOutBlocks*BS*CH*64; // [M] hop rotation table (ROTL; the staged kernel keeps its windows here)
+	if constexpr (ROTL) {
+		for (int i = threadIdx.x; i < M; i += blockDim.x) rotLds[i] = d.rot[i];
+	}
 	__syncthreads();
 
 	if (wave > 0) {
@@ -2060,7 +2071,7 @@ __global__ __launch_bounds__(64*kVocWaves) __attribute__((amdgpu_waves_per_eu(4,
 			float f[NCH*4];
 #pragma unroll
 			for (int j = 0; j < NCH*4; ++j) f[j] = 0.0f;
-			if (row < nh && b >= 0 && b < M && d.debugMode != 1) computeRecord<CH, PLAIN, false, false>(d, hopsLds[row], hopsLds[row > 0 ? row - 1 : 0], s, sg, row, b, f);
+			if (row < nh && b >= 0 && b < M && d.debugMode != 1) computeRecord<CH, PLAIN, false, false, NCH*4, ROTL>(d, hopsLds[row], hopsLds[row > 0 ? row - 1 : 0], s, sg, row, b, f, rotLds);
 #pragma unroll
 			// lane rotation by 2*st spreads the 8 lanes of a row (same row, 8 steps = 8 LDS rows a multiple of 256 B apart) over 8 bank groups
 			for (int j = 0; j < NCH; ++j) recs[((slot*BS + st)*NCH + j)*64 + ((row + 2*st) & 63)] = make_float4(f[4*j], f[4*j + 1], f[4*j + 2], f[4*j + 3]);
@@ -2867,7 +2878,10 @@ static void launchVocoderTL(const DevBatch &d, int sBase, int nStreams, int hopB
 			return;
 		}
 	}
-	if (plain) hipLaunchKernelGGL((kVocoder<CH, true, L, false>), dim3(nStreams), dim3(64*kVocWaves), lds, st, d, sBase, hopBase);
+	if (plain) { hipLaunchKernelGGL((kVocoder<CH, true, L, false>), dim3(nStreams), dim3(64*kVocWaves), lds, st, d, sBase, hopBase); return; }
+	// mapped tiles: the hop rotation table beside the rings when the CU's 160 KB hold it (presetDefault: 3073 bins, 24 KB)
+	const size_t ldsRot = lds + (size_t)d.M*sizeof(float2);
+	if (ldsRot <= (size_t)160*1024) hipLaunchKernelGGL((kVocoder<CH, false, L, false, true>), dim3(nStreams), dim3(64*kVocWaves), ldsRot, st, d, sBase, hopBase);
 	else hipLaunchKernelGGL((kVocoder<CH, false, L, false>), dim3(nStreams), dim3(64*kVocWaves), lds, st, d, sBase, hopBase);
 }
 template <int CH>
