@@ -1375,6 +1375,39 @@ __global__ __launch_bounds__(256) void kPredictA(DevBatch d, int sBase, int hopB
 	}
 }
 
+// Per-channel fields of a record (floats 9..).  Any channel count but two: {P_c, sqrt(E_c)} per channel, the recurrence forms
+// the lock  makeOutput(out_m * P_c conj(P_m), P_c, sqrt(E_c))  itself (:791-800).  STEREO: the one locked channel's
+// makeOutput is folded into the record -- |out_m|^2 = E_m by construction (:602), so the norm of the lock's phase is
+// E_m |P_o conj(P_m)|^2 and the producer can scale the twist itself:
+//   9..11  P_m, sqrt(E_m)                     (the maximum channel's own makeOutput)
+//   12,13  T' = P_o conj(P_m) * sqrt(E_o) / sqrt(E_m |P_o conj(P_m)|^2)        (0 if that norm is below the noise floor)
+//   14,15  F  = P_o * sqrt(E_o) / sqrt(|P_o|^2 + 1e-15)  in that weak case, else 0   (the fallback to the input, :598-601)
+// and the recurrence wave computes  out_o = out_m T' + F : one complex multiply-add instead of two multiplies, a norm, a
+// compare, a reciprocal square root and four selects ON THE SERIAL PATH -- 77 of the 563 clock cycles a step took (cycle
+// trace, tools/probes/voc_trace.py).  The norm is E_m |T|^2 instead of |out_m T|^2: equal up to rounding (1e-7 relative).
+template <int CH, int NFLOATS>
+__device__ __forceinline__ void recordChannelFields(float (&f)[NFLOATS], const float2 (&p)[CH], const float (&e)[CH], int mc) {
+	if constexpr (CH == 2) {
+		const float2 Pm = mc ? p[1] : p[0], Po = mc ? p[0] : p[1];
+		const float eM = mc ? e[1] : e[0], eO = mc ? e[0] : e[1];
+		const float2 T = cmulc(Po, Pm);
+		const float nT = eM*cnorm(T);
+		const bool weak = nT <= 1e-15f;
+		const float g = __builtin_amdgcn_sqrtf(eO)*__builtin_amdgcn_rsqf(weak ? cnorm(Po) + 1e-15f : nT);
+		f[9] = Pm.x; f[10] = Pm.y; f[11] = __builtin_amdgcn_sqrtf(eM);
+		f[12] = weak ? 0.0f : T.x*g; f[13] = weak ? 0.0f : T.y*g;
+		f[14] = weak ? Po.x*g : 0.0f; f[15] = weak ? Po.y*g : 0.0f;
+	} else {
+#pragma unroll
+		for (int c = 0; c < CH; ++c) { f[9 + 3*c] = p[c].x; f[10 + 3*c] = p[c].y; f[11 + 3*c] = __builtin_amdgcn_sqrtf(e[c]); } // 1-ulp hardware square root
+	}
+}
+// stereo: the locked channel's output from the maximum channel's (see recordChannelFields)
+template <int NFLOATS>
+__device__ __forceinline__ float2 lockedOutput(float2 om, const float (&f)[NFLOATS]) {
+	return cadd(cmul(om, make_float2(f[12], f[13])), make_float2(f[14], f[15]));
+}
+
 // One record of the bin recurrence = everything hop k needs at bin b, with the maximum-energy channel m(b)
 // already selected (signalsmith-stretch.h:729-737):
 //   phi = out_m[b-1]*A + out_m[b-L]*B + prevHopOut_m[b+1]*Cc + prevHopOut_m[b+L]*Dc         (:744-786)
@@ -1532,15 +1565,9 @@ __device__ __forceinline__ void computeRecord(const DevBatch &d, const HopDesc &
 	}
 	f[0] = A.x; f[1] = A.y; f[2] = B.x; f[3] = B.y; f[4] = Cc.x; f[5] = Cc.y; f[6] = Dc.x; f[7] = Dc.y;
 	f[8] = __int_as_float(mc);
-#pragma unroll
-	for (int c = 0; c < CH; ++c) {
-		f[9 + PC*c] = p[c].x; f[10 + PC*c] = p[c].y;
-		f[11 + PC*c] = __builtin_amdgcn_sqrtf(e[c]); // 1-ulp hardware square root, no denormal fix-up sequence
-		if (LOCK) {
-			float2 lock = cmulc(p[c], Pm);
-			f[12 + PC*c] = lock.x; f[13 + PC*c] = lock.y;
-		}
-	}
+	static_assert(!LOCK, "the separate lock-twist fields are gone: stereo records carry the scaled twist (recordChannelFields)");
+	(void)PC;
+	recordChannelFields<CH>(f, p, e, mc);
 }
 
 // One workgroup = 8 wavefront steps x all 64 hops of a stream.  Reads are coalesced along the bin index (8 lanes
@@ -1681,7 +1708,10 @@ __global__ __launch_bounds__(64) void kChain(DevBatch d, int sBase, int hopBase)
 				float sm = f[11];
 #pragma unroll
 				for (int c = 1; c < CH; ++c) {
-					if (c == mc) { o1 = own1[c]; pm = make_float2(f[9 + 3*c], f[10 + 3*c]); sm = f[11 + 3*c]; }
+					if (c == mc) {
+						o1 = own1[c];
+						if (CH != 2) { pm = make_float2(f[9 + 3*c], f[10 + 3*c]); sm = f[11 + 3*c]; } // stereo records lead with the maximum channel
+					}
 				}
 				const int ringRow = mc*R;
 				const float2 oL = lds[(ringRow + ((b - L) & Rm))*64 + k];
@@ -1694,10 +1724,16 @@ __global__ __launch_bounds__(64) void kChain(DevBatch d, int sBase, int hopBase)
 				phi = cadd(phi, cmul(pL, make_float2(f[6], f[7])));
 				phi = cadd(phi, cmul(o1, make_float2(f[0], f[1])));
 				const float2 om = makeOutput(phi, pm, sm); // :788
+				const float2 olock = (CH == 2) ? lockedOutput(om, f) : om; // stereo: see recordChannelFields
 #pragma unroll
 				for (int c = 0; c < CH; ++c) {
-					const float2 pc = make_float2(f[9 + 3*c], f[10 + 3*c]);
-					float2 oc = makeOutput(cmul(om, cmulc(pc, pm)), pc, f[11 + 3*c]); // channel lock, :791-800
+					float2 oc;
+					if constexpr (CH == 2) {
+						oc = olock;
+					} else {
+						const float2 pc = make_float2(f[9 + 3*c], f[10 + 3*c]);
+						oc = makeOutput(cmul(om, cmulc(pc, pm)), pc, f[11 + 3*c]); // channel lock, :791-800
+					}
 					if (c == mc) oc = om;
 					if (!valid) oc = make_float2(0.f, 0.f);
 					own1[c] = oc;
@@ -1933,8 +1969,7 @@ __device__ __forceinline__ void vocoderProduceStaged(const DevBatch &d, int s, i
 			if (!(b < M - L)) Dc = zero;
 			f[0] = A.x; f[1] = A.y; f[2] = B.x; f[3] = B.y; f[4] = Cc.x; f[5] = Cc.y; f[6] = Dc.x; f[7] = Dc.y;
 			f[8] = __int_as_float(mc);
-#pragma unroll
-			for (int c = 0; c < CH; ++c) { f[9 + 3*c] = p[c].x; f[10 + 3*c] = p[c].y; f[11 + 3*c] = __builtin_amdgcn_sqrtf(e[c]); }
+			recordChannelFields<CH>(f, p, e, mc);
 		}
 #pragma unroll
 		for (int j = 0; j < NCH; ++j) recs[((slot*BS + st)*NCH + j)*64 + ((row + 2*st) & 63)] = make_float4(f[4*j], f[4*j + 1], f[4*j + 2], f[4*j + 3]);
@@ -2144,13 +2179,13 @@ __global__ __launch_bounds__(64*kVocWaves) __attribute__((amdgpu_waves_per_eu(4,
 				// taps: own history, and lane k-1's history (lane 0: the staged carried state)
 				float2 o1 = h[(i + 7) & 7][0], oL = h[(i + 8 - L) & 7][0];
 				float2 p1 = fromLaneBelow(oL, sv1[0]), pL = fromLaneBelow(o1, svL[0]); // lane 0: the staged carried state
-				float2 pm = make_float2(f[9], f[10]);
-				float sm = f[11];
+				const float2 pm = make_float2(f[9], f[10]); // mono: the channel's; stereo: the maximum channel's (recordChannelFields)
+				const float sm = f[11];
 #pragma unroll
 				for (int c = 1; c < CH; ++c) {
 					const float2 o1c = h[(i + 7) & 7][c], oLc = h[(i + 8 - L) & 7][c];
 					const float2 p1c = fromLaneBelow(oLc, sv1[c]), pLc = fromLaneBelow(o1c, svL[c]);
-					if (c == mc) { o1 = o1c; oL = oLc; p1 = p1c; pL = pLc; pm = make_float2(f[9 + 3*c], f[10 + 3*c]); sm = f[11 + 3*c]; }
+					if (c == mc) { o1 = o1c; oL = oLc; p1 = p1c; pL = pLc; }
 				}
 				// next step's staged values (only lane 0 uses them): bins (b+1)+1 and (b+1)+L
 #pragma unroll
@@ -2163,10 +2198,8 @@ __global__ __launch_bounds__(64*kVocWaves) __attribute__((amdgpu_waves_per_eu(4,
 				phi = cadd(phi, cmul(pL, make_float2(f[6], f[7])));
 				phi = cadd(phi, cmul(o1, make_float2(f[0], f[1])));
 				const float2 om = makeOutput(phi, pm, sm); // :788
-				if (CH == 2) { // one locked channel: evaluate the lock once, for whichever channel is not the maximum
-					const float2 pother = mc ? make_float2(f[9], f[10]) : make_float2(f[12], f[13]);
-					const float sother = mc ? f[11] : f[14];
-					float2 olock = makeOutput(cmul(om, cmulc(pother, pm)), pother, sother); // channel lock, :791-800
+				if (CH == 2) { // one locked channel (:791-800), its makeOutput folded into the record
+					const float2 olock = lockedOutput(om, f);
 					// cells outside the tile (inactive hop, bin outside [0, M)) have all-zero records, which give exactly zero here
 					const float2 oc0 = mc ? olock : om, oc1 = mc ? om : olock;
 					h[i][0] = oc0;
@@ -2493,17 +2526,26 @@ __global__ __launch_bounds__(128) void kVocoderOne(DevBatch d, int sBase, int ho
 #pragma unroll
 				for (int c = 1; c < CH; ++c) {
 					const float2 p1c = stage[c*128 + ((b + 1) & 127)], pLc = stage[c*128 + ((b + L) & 127)];
-					if (c == mc) { o1 = h[(i + 7) & 7][c]; oL = h[(i + 8 - L) & 7][c]; p1 = p1c; pL = pLc; pm = make_float2(f[9 + 3*c], f[10 + 3*c]); sm = f[11 + 3*c]; }
+					if (c == mc) {
+						o1 = h[(i + 7) & 7][c]; oL = h[(i + 8 - L) & 7][c]; p1 = p1c; pL = pLc;
+						if (CH != 2) { pm = make_float2(f[9 + 3*c], f[10 + 3*c]); sm = f[11 + 3*c]; } // stereo records lead with the maximum channel
+					}
 				}
 				float2 phi = cmul(oL, make_float2(f[2], f[3]));
 				phi = cadd(phi, cmul(p1, make_float2(f[4], f[5])));
 				phi = cadd(phi, cmul(pL, make_float2(f[6], f[7])));
 				phi = cadd(phi, cmul(o1, make_float2(f[0], f[1])));
 				const float2 om = makeOutput(phi, pm, sm); // :788
+				const float2 olock = (CH == 2) ? lockedOutput(om, f) : om; // stereo: see recordChannelFields
 #pragma unroll
 				for (int c = 0; c < CH; ++c) {
-					const float2 pc = make_float2(f[9 + 3*c], f[10 + 3*c]);
-					float2 oc = makeOutput(cmul(om, cmulc(pc, pm)), pc, f[11 + 3*c]); // channel lock, :791-800
+					float2 oc;
+					if constexpr (CH == 2) {
+						oc = olock;
+					} else {
+						const float2 pc = make_float2(f[9 + 3*c], f[10 + 3*c]);
+						oc = makeOutput(cmul(om, cmulc(pc, pm)), pc, f[11 + 3*c]); // channel lock, :791-800
+					}
 					if (c == mc) oc = om;
 					h[i][c] = oc; // bins past the last one have all-zero records, which give exactly zero
 					if (k == 0) blockOut[c*BS + step] = oc;
