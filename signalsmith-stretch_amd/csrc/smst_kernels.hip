@@ -2131,6 +2131,9 @@ __global__ __launch_bounds__(64*kVocWaves) __attribute__((amdgpu_waves_per_eu(4,
 		svL[c] = stage[c*128 + ((L - kLag) & 127)];
 	}
 
+	// the two hand-off words the NEXT block waits for are read during the current block's last step (an LDS round trip each,
+	// 200 clock cycles, sat on the serial path at every block boundary -- cycle trace); the poll loops remain for the rare miss
+	int seenProduced = ldsPeek(&sync[0]), seenWritten = 0;
 	for (int ch = 0; ch < chunks; ++ch) {
 		const int tb = ch << 6;
 		if (ch > 0) {
@@ -2153,10 +2156,10 @@ __global__ __launch_bounds__(64*kVocWaves) __attribute__((amdgpu_waves_per_eu(4,
 			const int n = ch*(64/BS) + blk;
 			const int slot = n%NB;
 			const int need = 8*(n/NB + 1);
-			while (ldsPeek(&sync[slot]) < need) __builtin_amdgcn_s_sleep(1);
+			while (seenProduced < need) { __builtin_amdgcn_s_sleep(1); seenProduced = ldsPeek(&sync[slot]); }
 			asm volatile("" ::: "memory");
 			const float4 *blockRecs = recs + (size_t)slot*BS*NCH*64;
-			while (n - ldsPeek(&sync[NB + 2]) >= 2) __builtin_amdgcn_s_sleep(1); // the writer still owns this result slot
+			while (n - seenWritten >= 2) { __builtin_amdgcn_s_sleep(1); seenWritten = ldsPeek(&sync[NB + 2]); } // the writer still owns this result slot
 			asm volatile("" ::: "memory");
 			float2 *blockOut = outRing + (size_t)(n%kVocOutBlocks)*BS*CH*64 + k;
 			float4 q[2][NCH]; // two register sets alternate, so the next step's record loads never overwrite live values
@@ -2169,6 +2172,9 @@ __global__ __launch_bounds__(64*kVocWaves) __attribute__((amdgpu_waves_per_eu(4,
 				if (i + 1 < BS) {
 #pragma unroll
 					for (int j = 0; j < NCH; ++j) q[(i + 1) & 1][j] = blockRecs[((i + 1)*NCH + j)*64 + ((k + 2*(i + 1)) & 63)];
+				} else { // last step: look at the next block's hand-off words now, their latency hides under this step
+					seenProduced = ldsPeek(&sync[(n + 1)%NB]);
+					seenWritten = ldsPeek(&sync[NB + 2]);
 				}
 				float f[NCH*4];
 #pragma unroll
