@@ -2121,7 +2121,8 @@ __global__ __launch_bounds__(64*kVocWaves) __attribute__((amdgpu_waves_per_eu(4,
 	const int kLag = lag*k;
 	float2 pf[CH];
 	float2 h[8][CH];   // this lane's outputs of the last 8 steps
-	float2 sv1[CH], svL[CH]; // lane 0: carried outputs at bins b+1 and b+L of the NEXT step, read one step ahead
+	float2 sv1[CH], svL[CH]; // lane 0: carried outputs at bins b+1 and b+L of the coming step ...
+	float2 sw1[CH], swL[CH]; // ... and of the step after it: read TWO steps ahead (one step ahead the LDS latency, 100 cycles, sat on the serial path: the compiler hoists the next step's DPP moves, which take these as their `old` operand, into the current step)
 #pragma unroll
 	for (int c = 0; c < CH; ++c) {
 		pf[c] = make_float2(0.f, 0.f);
@@ -2129,6 +2130,8 @@ __global__ __launch_bounds__(64*kVocWaves) __attribute__((amdgpu_waves_per_eu(4,
 		for (int i = 0; i < 8; ++i) h[i][c] = make_float2(0.f, 0.f);
 		sv1[c] = stage[c*128 + ((1 - kLag) & 127)];
 		svL[c] = stage[c*128 + ((L - kLag) & 127)];
+		sw1[c] = stage[c*128 + ((2 - kLag) & 127)];
+		swL[c] = stage[c*128 + ((L + 1 - kLag) & 127)];
 	}
 
 	// the two hand-off words the NEXT block waits for are read during the current block's last step (an LDS round trip each,
@@ -2196,8 +2199,10 @@ __global__ __launch_bounds__(64*kVocWaves) __attribute__((amdgpu_waves_per_eu(4,
 				// next step's staged values (only lane 0 uses them): bins (b+1)+1 and (b+1)+L
 #pragma unroll
 				for (int c = 0; c < CH; ++c) {
-					sv1[c] = stage[c*128 + ((b + 2) & 127)];
-					svL[c] = stage[c*128 + ((b + 1 + L) & 127)];
+					sv1[c] = sw1[c];
+					svL[c] = swL[c];
+					sw1[c] = stage[c*128 + ((b + 3) & 127)];
+					swL[c] = stage[c*128 + ((b + 2 + L) & 127)];
 				}
 				float2 phi = cmul(oL, make_float2(f[2], f[3]));
 				phi = cadd(phi, cmul(p1, make_float2(f[4], f[5])));

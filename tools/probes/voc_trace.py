@@ -11,9 +11,9 @@ import importlib
 import torch
 pkg = importlib.import_module("signalsmith-stretch_amd")
 
-S, CH, sr, secs = 256, 2, 48000, 4.0
-n_in = int(sr*secs)
-n_out = int(n_in*1.5)
+S, CH, sr = 256, 2, 48000
+n_out = 256*1440          # 256 hops: four FULL 64-hop tiles (the trace keeps the last launch; a partial tile leaves most producers idle)
+n_in = n_out*2//3
 b = pkg.StretchBatch(S, CH, preset="default", sample_rate=float(sr))
 kind = sys.argv[1] if len(sys.argv) > 1 else "noise"
 if kind == "noise":
@@ -27,16 +27,21 @@ y = torch.empty(S, CH, n_out, device="cuda")
 for _ in range(2):
     b.process(x, n_out, out=y, ordered=False)
 torch.cuda.synchronize()
-buf = np.zeros(12*400, np.uint64)
+buf = np.zeros(12*400 + 8, np.uint64)
 rc = b.lib.smst_batch_debug_get_state(b.h, 0, 7, buf.ctypes.data_as(C.POINTER(C.c_float)))
 assert rc == 0
-t = buf.reshape(12, 400).astype(np.int64)
+t = buf[:12*400].reshape(12, 400).astype(np.int64)
+wall = buf[12*400:].astype(np.int64)  # 100 MHz wall clock at blocks 100 and 300 of the recurrence wave
 lo, hi = 100, 300
 def d(a, bb):
     return float(np.mean(t[bb, lo:hi] - t[a, lo:hi]))
 def period(a):
     return float(np.mean(np.diff(t[a, lo:hi])))
 print("clock ticks per block (mean over blocks %d..%d)" % (lo, hi))
+if wall[1] > wall[0]:
+    ns = (wall[1] - wall[0])*10.0
+    cyc = float(t[5, 300] - t[5, 100])
+    print("blocks 100..300: %.1f us wall, %.0f shader-clock ticks -> %.2f GHz, %.2f us per block" % (ns/1e3, cyc, cyc/ns, ns/200e3))
 print("producer 0 : period %.0f | park+barrier %.0f | issue+slot wait %.0f | compute %.0f | record write %.0f | rest %.0f" % (
     period(0), d(0, 1), d(1, 2), d(2, 3), d(3, 4), period(0) - d(0, 4)))
 print("recurrence : period %.0f | wait records %.0f | wait writer %.0f | 8 steps %.0f | rest %.0f" % (

@@ -3,7 +3,7 @@ p='/root/repo/signalsmith-stretch_amd/csrc/smst_kernels.hip'
 s=open(p).read()
 anchor="// Staged producers (PLAIN tiles without random time factors, L <= 5)."
 assert anchor in s
-s=s.replace(anchor,"__device__ unsigned long long gTrace[12*400];\nvoid traceRead(void *dst) { hipMemcpyFromSymbol(dst, HIP_SYMBOL(gTrace), sizeof(gTrace)); }\n#define TR(slot, n) do { if (s == 0 && k == 0 && (n) < 400) gTrace[(slot)*400 + (n)] = clock64(); } while (0)\n"+anchor,1)
+s=s.replace(anchor,"__device__ unsigned long long gTrace[12*400 + 8];\nvoid traceRead(void *dst) { hipMemcpyFromSymbol(dst, HIP_SYMBOL(gTrace), sizeof(gTrace)); }\n#define TR(slot, n) do { if (s == 0 && k == 0 && (n) < 400) { gTrace[(slot)*400 + (n)] = clock64(); if ((slot) == 5 && ((n) == 100 || (n) == 300)) gTrace[12*400 + ((n) == 300)] = wall_clock64(); } } while (0)\n"+anchor,1)
 def rep(old,new):
     global s
     assert old in s, old[:60]
@@ -33,17 +33,17 @@ rep("""#pragma unroll
 		if (pIndex == 0) TR(4, n);
 		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");""")
 rep("""			const int need = 8*(n/NB + 1);
-			while (ldsPeek(&sync[slot]) < need) __builtin_amdgcn_s_sleep(1);
+			while (seenProduced < need) { __builtin_amdgcn_s_sleep(1); seenProduced = ldsPeek(&sync[slot]); }
 			asm volatile("" ::: "memory");
 			const float4 *blockRecs = recs + (size_t)slot*BS*NCH*64;
-			while (n - ldsPeek(&sync[NB + 2]) >= 2) __builtin_amdgcn_s_sleep(1); // the writer still owns this result slot
+			while (n - seenWritten >= 2) { __builtin_amdgcn_s_sleep(1); seenWritten = ldsPeek(&sync[NB + 2]); } // the writer still owns this result slot
 			asm volatile("" ::: "memory");""","""			const int need = 8*(n/NB + 1);
 			TR(5, n);
-			while (ldsPeek(&sync[slot]) < need) __builtin_amdgcn_s_sleep(1);
+			while (seenProduced < need) { __builtin_amdgcn_s_sleep(1); seenProduced = ldsPeek(&sync[slot]); }
 			asm volatile("" ::: "memory");
 			TR(6, n);
 			const float4 *blockRecs = recs + (size_t)slot*BS*NCH*64;
-			while (n - ldsPeek(&sync[NB + 2]) >= 2) __builtin_amdgcn_s_sleep(1); // the writer still owns this result slot
+			while (n - seenWritten >= 2) { __builtin_amdgcn_s_sleep(1); seenWritten = ldsPeek(&sync[NB + 2]); } // the writer still owns this result slot
 			asm volatile("" ::: "memory");
 			TR(7, n);""")
 rep("""			asm volatile("" ::: "memory");
