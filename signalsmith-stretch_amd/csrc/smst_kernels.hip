@@ -2320,14 +2320,18 @@ __global__ __launch_bounds__(64*kVocWaves) __attribute__((amdgpu_waves_per_eu(4,
 		for (int u = pIndex; u < totalBlocks*UNITS; u += NP) {
 			const int n = u/UNITS, it = u - n*UNITS;
 			const int slot = n%NB;
-			while (n - ldsPeek(&sync[NB]) >= NB) __builtin_amdgcn_s_sleep(2); // slot still being read
-			asm volatile("" ::: "memory");
 			const int row = ROWS*it + r;
 			const int b = BS*n + st - lag*row;
 			float f[NCH*4];
 #pragma unroll
 			for (int j = 0; j < NCH*4; ++j) f[j] = 0.0f;
 			if (row < nh && b >= 0 && b < M && d.debugMode != 1) computeRecord<CH, PLAIN, false, false>(d, hopsLds[row], hopsLds[row > 0 ? row - 1 : 0], s, sg, row, b, f);
+			// The records depend on feed-forward data only, so a pass is COMPUTED as soon as its wave is free and waits for its
+			// slot just before it is stored.  With the wait in front (first version) one block was in production at a time: a
+			// pass is two dependent rounds of gathers, 7 + 15 thousand cycles on a full tile (cycle trace), the 2-block ring let
+			// 4 of the 14 producers work, and the recurrence wave waited 57 % of every block for records.
+			while (n - ldsPeek(&sync[NB]) >= NB) __builtin_amdgcn_s_sleep(2); // slot still being read
+			asm volatile("" ::: "memory");
 #pragma unroll
 			for (int j = 0; j < NCH; ++j) recs[((slot*BS + st)*NCH + j)*64 + ((row + 2*st) & 63)] = make_float4(f[4*j], f[4*j + 1], f[4*j + 2], f[4*j + 3]);
 			asm volatile("" ::: "memory");
