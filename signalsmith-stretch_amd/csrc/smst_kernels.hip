@@ -2085,10 +2085,13 @@ __global__ __launch_bounds__(64*kVocWaves) __attribute__((amdgpu_waves_per_eu(4,
 			}
 			return;
 		}
-		// 0..NP-1 over the producer waves.  Waves land on SIMD (wave & 3); the staged kernel runs 8 producers: two on each
-		// of SIMDs 1-3 and two (waves 8, 12) sharing SIMD 0 with the consumer and the writer.
+		// 0..NP-1 over the producer waves.  Waves w and w+4 share a SIMD (tools/probes/wave_simd_map.hip).  The staged kernel
+		// runs 8 producers on three SIMDs (waves 1,5,9 / 2,6,10 / 3,7) and leaves the recurrence wave's SIMD to it and the
+		// writer: with two producers beside it (the first placement) the recurrence wave, which is the critical path once the
+		// producers are light enough, lost issue slots to them -- 8.15 -> 7.45 ms per step.  (Earlier in the round, with
+		// heavier producers, the same move changed nothing.)
 		int pIndex = wave - 1 - (wave > 4);
-		if (STAGED) pIndex = (wave & 3) ? ((wave < 8) ? pIndex : NP) : ((wave == 8) ? 6 : ((wave == 12) ? 7 : NP));
+		if (STAGED) pIndex = (wave & 3) ? ((wave < 8) ? pIndex : ((wave == 9) ? 6 : ((wave == 10) ? 7 : NP))) : NP;
 		if (pIndex >= NP) return;
 		if constexpr (STAGED) {
 			using G = StageGeom<CH, L>;
