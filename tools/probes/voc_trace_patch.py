@@ -13,14 +13,15 @@ rep("""	for (; n < totalBlocks; n += NPB) {
 		if (pIndex == 0) TR(0, n);
 		park(n);""")
 rep("""		if (n + NPB < totalBlocks) issue(n + NPB);
-		const int slot = n%NB;
-		while (n - ldsPeek(&sync[NB]) >= NB) __builtin_amdgcn_s_sleep(2); // slot still being read
-		asm volatile("" ::: "memory");""","""		if (pIndex == 0) TR(1, n);
+		const int slot = n%NB;""","""		if (pIndex == 0) TR(1, n);
 		if (n + NPB < totalBlocks) issue(n + NPB);
-		const int slot = n%NB;
-		while (n - ldsPeek(&sync[NB]) >= NB) __builtin_amdgcn_s_sleep(2); // slot still being read
+		const int slot = n%NB;""")
+rep("""		while (n - ldsPeek(&sync[NB]) >= NB) __builtin_amdgcn_s_sleep(2); // slot still being read
 		asm volatile("" ::: "memory");
-		if (pIndex == 0) TR(2, n);""")
+		const int b0 = BS*n - lag*row, b = b0 + st;""","""		while (n - ldsPeek(&sync[NB]) >= NB) __builtin_amdgcn_s_sleep(2); // slot still being read
+		asm volatile("" ::: "memory");
+		if (pIndex == 0) TR(2, n);
+		const int b0 = BS*n - lag*row, b = b0 + st;""")
 rep("""#pragma unroll
 		for (int j = 0; j < NCH; ++j) recs[((slot*BS + st)*NCH + j)*64 + ((row + 2*st) & 63)] = make_float4(f[4*j], f[4*j + 1], f[4*j + 2], f[4*j + 3]);
 		asm volatile("" ::: "memory");
