@@ -197,6 +197,19 @@ def case_pitch_and_formants(lib, ref, cfg=SMALL, n=9000):
                        cap=CAP_FORMANT if label.startswith("formant") else CAP_TONAL)
 
 
+def case_large_plan_mapped(lib, ref):
+    """A plan beyond the presets (8193 bins: 33 bins per thread in the feed kernels, above their register-resident limit
+    of 24): pitch map + formant envelope go through the LDS form of the scan passes and the bisection form of the peak
+    cover, which no preset reaches."""
+    cfg = dict(preset="configure", block=15360, interval=3840, split=False)
+    C, sr, n = 2, 48000, 5*3840 + 200
+    x = synth_input(1, C, n, sr) + 0.5*synth_input(3, C, n, sr)
+    for label, setup in (("large plan pitch+5", lambda o: o.setTransposeSemitones(5, 8000/48000)),
+                         ("large plan formant-comp", lambda o: (o.setTransposeSemitones(-3, 0), o.setFormantFactor(1, True), o.setFormantBase(200/48000)))):
+        check_scenario(lib, ref, cfg, x, lambda o, xx: o.process(xx, n), label, setup=setup,
+                       cap=CAP_FORMANT if "formant" in label else CAP_TONAL)
+
+
 def case_silence(lib, ref):
     sr = 48000
     x = synth_input(0, 1, 4000, sr)

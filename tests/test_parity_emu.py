@@ -24,6 +24,10 @@ def test_pitch_and_formants(emu, ref):
     pc.case_pitch_and_formants(emu, ref)
 
 
+def test_large_plan_mapped(emu, ref):
+    pc.case_large_plan_mapped(emu, ref)
+
+
 def test_silence(emu, ref):
     pc.case_silence(emu, ref)
 

@@ -38,6 +38,10 @@ def test_pitch_and_formants_preset_default(hip, ref):
     pc.case_pitch_and_formants(hip, ref, cfg=D48, n=20000)
 
 
+def test_large_plan_mapped(hip, ref):
+    pc.case_large_plan_mapped(hip, ref)
+
+
 def test_silence(hip, ref):
     pc.case_silence(hip, ref)
 
