@@ -17,6 +17,7 @@ struct DevBatch {
 	int mapTableLen;
 	int histCur, carryCur;        // which half of the double buffers is current
 	int debugMode;                // SMST_DEBUG_MODE experiments (0 = product behaviour)
+	int noFeedFusion;             // SMST_NO_FEED_FUSION=1: pass A stays its own kernel (kPredictA) -- cross-check of the folded form
 	int feedSerial;               // SMST_FEED_SERIAL: bin-by-bin feed recurrences (kFeedSerial) instead of the scan form
 	int halfState;                // carried Band.output / Prediction.energy / overlap-add sums stored in fp16 (BASELINE config 5 "fp16 internal")
 	int noStage;                  // SMST_NO_STAGE: producers of the fused kernel gather from HBM even where staging applies
@@ -70,10 +71,10 @@ struct IoArgs {
 
 void launchEnergy(const DevBatch &d, const IoArgs &io, int sBase, int nStreams, float *energyOut, hipStream_t st);
 void launchAnalyse(const DevBatch &d, const IoArgs &io, int sBase, int nStreams, int hopBase, int tileHops, hipStream_t st);
-void launchFeed(const DevBatch &d, int sBase, int nStreams, int hopBase, int tileHops, bool anyFormants, hipStream_t st);
-void launchPredict(const DevBatch &d, int sBase, int nStreams, int hopBase, int tileHops, bool plain, hipStream_t st);
+bool launchFeed(const DevBatch &d, int sBase, int nStreams, int hopBase, int tileHops, bool anyFormants, hipStream_t st); // true: pass A done too
+void launchPredict(const DevBatch &d, int sBase, int nStreams, int hopBase, int tileHops, bool plain, bool passADone, hipStream_t st);
 void launchChain(const DevBatch &d, int sBase, int nStreams, int hopBase, hipStream_t st);
-void launchPredictFused(const DevBatch &d, int sBase, int nStreams, int hopBase, int tileHops, bool plain, hipStream_t st);
+void launchPredictFused(const DevBatch &d, int sBase, int nStreams, int hopBase, int tileHops, bool plain, bool passADone, hipStream_t st);
 void launchVocoder(const DevBatch &d, int sBase, int nStreams, int hopBase, bool plain, bool bounded, hipStream_t st); // bounded: no random time factors in the tile
 bool fusedSupported(const DevBatch &d);
 bool singleHopSupported(const DevBatch &d);

@@ -168,6 +168,8 @@ void Batch::construct(const FftPlan &plan, long seed) {
 	d.halfState = halfState ? 1 : 0;
 	d.debugMode = 0;
 	if (const char *env = std::getenv("SMST_DEBUG_MODE")) d.debugMode = atoi(env);
+	d.noFeedFusion = 0;
+	if (const char *env = std::getenv("SMST_NO_FEED_FUSION")) d.noFeedFusion = atoi(env);
 	d.noStage = std::getenv("SMST_NO_STAGE") != nullptr;
 	d.feedSerial = std::getenv("SMST_FEED_SERIAL") != nullptr;
 
@@ -826,10 +828,11 @@ void Batch::process(const float *in, long long inSS, long long inCS, const int *
 			if (!serial && fused && !plain && q >= 1) SMST_HIP(hipStreamWaitEvent(sF, evChain[slot ^ 1], 0)); // pass A reads the carried state
 			if (th[0]) {
 				if (th[3]) timed(timings.analyseMs, [&] { launchAnalyse(dd, io, sBase, ns, hopBase, tileHops, sF); if (profiling) ++timings.analyseLaunches; });
-				if (th[1] || th[2]) timed(timings.feedMs, [&] { launchFeed(dd, sBase, ns, hopBase, tileHops, th[2] != 0, sF); });
+				bool passADone = false;
+				if (th[1] || th[2]) timed(timings.feedMs, [&] { passADone = launchFeed(dd, sBase, ns, hopBase, tileHops, th[2] != 0, sF); });
 				timed(timings.predictMs, [&] {
-					if (fused) launchPredictFused(dd, sBase, ns, hopBase, tileHops, plain, sF);
-					else launchPredict(dd, sBase, ns, hopBase, tileHops, plain, sF);
+					if (fused) launchPredictFused(dd, sBase, ns, hopBase, tileHops, plain, passADone, sF);
+					else launchPredict(dd, sBase, ns, hopBase, tileHops, plain, passADone, sF);
 					if (profiling) ++timings.predictLaunches;
 				});
 				// the carried feed-forward state (Band.input/.prevInput, Prediction.energy) may only move on once every

@@ -970,15 +970,29 @@ __device__ __forceinline__ void feedEnergyToLds(const DevBatch &d, const HopDesc
 	}
 }
 
+// Pass A (Prediction.input / .energy rows, kPredictA below) for one hop, folded into the feed kernel when no hop of the tile has
+// formant processing: the thread that has just computed the map entry of a bin forms the bin's (P, E) at once -- the map row is
+// not read back (8 B per bin) and the input rows, which this workgroup read a moment ago for the energies, come out of L2
+// instead of HBM.  Same arithmetic as kPredictA: bit-identical entries.  Eight bins per thread in flight.
+struct LerpIndex;
+__device__ __forceinline__ LerpIndex lerpIndex(float x);
+__device__ __forceinline__ float2 bandAt(const float2 *row, int idx, int M);
+template <typename MapAt>
+__device__ __forceinline__ void feedPredictionRows(const DevBatch &d, const HopDesc &hd, int s, int sg, int k, bool mapped, MapAt mapAt);
+
 // energy, smoothing, peaks, output map, raw pitch estimate: one workgroup per (hop, stream)
-template <int NMAX> // bins per thread held in registers during the smoothing passes; 0: through LDS (any M)
+template <int NMAX, bool FUSE_PE = false> // NMAX: bins per thread held in registers during the smoothing passes; 0: through LDS (any M)
 __global__ __launch_bounds__(256) void kFeedScanA(DevBatch d, int sBase, int hopBase) {
+	static_assert(!FUSE_PE || NMAX > 0, "pass A is folded into the register form only");
 	extern __shared__ __attribute__((aligned(16))) unsigned char smemRaw[];
 	const int k = blockIdx.x, s = blockIdx.y, sg = sBase + s;
 	if (k >= d.nHops[s]) return;
 	const HopDesc hd = d.hops[(size_t)sg*d.hopStride + hopBase + k];
 	const bool mapped = hd.flags & HOP_MAPPED, formants = hd.flags & HOP_FORMANTS;
-	if (!mapped && !formants) return;
+	if (!mapped && !formants) {
+		if constexpr (FUSE_PE) feedPredictionRows(d, hd, s, sg, k, false, [](int bb) { return make_float2(float(bb), 1.0f); });
+		return;
+	}
 	const int M = d.M, C = d.C, t = threadIdx.x;
 	const float Nf = float(d.N);
 	float *en = reinterpret_cast<float *>(smemRaw);         // [M] channel-summed energy
@@ -1129,7 +1143,8 @@ __global__ __launch_bounds__(256) void kFeedScanA(DevBatch d, int sBase, int hop
 #pragma unroll
 			for (int i = 0; i < NMAX; ++i) if (i < cnt) cover[b0 + i] = max(c[i], base);
 			__syncthreads();
-			for (int b = t; b < M; b += 256) mapRow[b] = mapOf(b, max(cover[b], 0)); // coalesced stores
+			if constexpr (FUSE_PE) feedPredictionRows(d, hd, s, sg, k, true, [&](int bb) { return mapOf(bb, max(cover[bb], 0)); });
+			else for (int b = t; b < M; b += 256) mapRow[b] = mapOf(b, max(cover[b], 0)); // coalesced stores
 		} else {
 			// by bisection; a thread's bins are 256 apart, so eight independent bisections run in lock step
 			for (int bb = t; bb < M; bb += 8*256) {
@@ -1406,6 +1421,41 @@ __device__ __forceinline__ void recordChannelFields(float (&f)[NFLOATS], const f
 template <int NFLOATS>
 __device__ __forceinline__ float2 lockedOutput(float2 om, const float (&f)[NFLOATS]) {
 	return cadd(cmul(om, make_float2(f[12], f[13])), make_float2(f[14], f[15]));
+}
+
+template <typename MapAt>
+__device__ __forceinline__ void feedPredictionRows(const DevBatch &d, const HopDesc &hd, int s, int sg, int k, bool mapped, MapAt mapAt) {
+	const int M = d.M, C = d.C, t = threadIdx.x;
+	float2 *mapRow = d.map + ((size_t)s*d.T + k)*M;
+	for (int b0 = t; b0 < M; b0 += 8*256) {
+		LerpIndex li[8];
+		float grad[8];
+#pragma unroll
+		for (int i = 0; i < 8; ++i) {
+			const int b = b0 + 256*i;
+			float2 mp = make_float2(float(b), 1.0f);
+			if (b < M && mapped) { mp = mapAt(b); mapRow[b] = mp; }
+			li[i] = lerpIndex(mp.x);
+			grad[i] = fmaxf(0.0f, mp.y);
+		}
+		for (int c = 0; c < C; ++c) {
+			const float2 *in = inputRow(d, hd, s, sg, c);
+			float2 lo[8], hi[8];
+#pragma unroll
+			for (int i = 0; i < 8; ++i) { lo[i] = bandAt(in, li[i].lo, M); hi[i] = bandAt(in, li[i].lo + 1, M); }
+#pragma unroll
+			for (int i = 0; i < 8; ++i) {
+				const int b = b0 + 256*i;
+				if (b >= M) continue;
+				const float eLo = cnorm(lo[i]), eHi = cnorm(hi[i]);
+				PredEntry pe;
+				pe.x = lo[i].x + (hi[i].x - lo[i].x)*li[i].fr;
+				pe.y = lo[i].y + (hi[i].y - lo[i].y)*li[i].fr;
+				pe.e = (eLo + (eHi - eLo)*li[i].fr)*grad[i];
+				d.PE[rowOf(d, s, k, c) + b] = pe;
+			}
+		}
+	}
 }
 
 // One record of the bin recurrence = everything hop k needs at bin b, with the maximum-energy channel m(b)
@@ -2892,15 +2942,22 @@ void launchAnalyse(const DevBatch &d, const IoArgs &io, int sBase, int nStreams,
 	size_t lds = 2*(size_t)d.M*sizeof(float2);
 	hipLaunchKernelGGL(kAnalyse, grid, dim3(256), lds, st, d, io, sBase, hopBase);
 }
-void launchFeed(const DevBatch &d, int sBase, int nStreams, int hopBase, int tileHops, bool anyFormants, hipStream_t st) {
+// returns true if pass A (the (P, E) rows) has been done here: tiles without formant processing, presets' plan sizes
+bool launchFeed(const DevBatch &d, int sBase, int nStreams, int hopBase, int tileHops, bool anyFormants, hipStream_t st) {
 	if (d.feedSerial) { // bin-by-bin evaluation (SMST_FEED_SERIAL=1)
 		hipLaunchKernelGGL(kFeedEnergy, dim3(divUp(d.M, 64), nStreams), dim3(256), 64*65*sizeof(float), st, d, sBase, hopBase);
 		hipLaunchKernelGGL(kFeedSerial, dim3(nStreams), dim3(64), 0, st, d, sBase, hopBase);
-		return;
+		return false;
 	}
 	const size_t ldsA = (size_t)2*d.M*sizeof(float) + (size_t)(d.M/2 + 2)*sizeof(float2) + 264*sizeof(ScanMap) + 264*sizeof(int);
 	const size_t ldsC = (size_t)2*d.M*sizeof(float) + 264*sizeof(ScanMap);
 	const int perThread = divUp(d.M, 256); // bins per thread: in registers up to 24 (M <= 6144), through LDS beyond
+	const bool fusePassA = !anyFormants && perThread <= 24 && !d.noFeedFusion;
+	if (fusePassA) {
+		if (perThread <= 16) hipLaunchKernelGGL((kFeedScanA<16, true>), dim3(tileHops, nStreams), dim3(256), ldsA, st, d, sBase, hopBase);
+		else hipLaunchKernelGGL((kFeedScanA<24, true>), dim3(tileHops, nStreams), dim3(256), ldsA, st, d, sBase, hopBase);
+		return true;
+	}
 	if (perThread <= 16) hipLaunchKernelGGL(kFeedScanA<16>, dim3(tileHops, nStreams), dim3(256), ldsA, st, d, sBase, hopBase);
 	else if (perThread <= 24) hipLaunchKernelGGL(kFeedScanA<24>, dim3(tileHops, nStreams), dim3(256), ldsA, st, d, sBase, hopBase);
 	else hipLaunchKernelGGL(kFeedScanA<0>, dim3(tileHops, nStreams), dim3(256), ldsA, st, d, sBase, hopBase);
@@ -2910,21 +2967,22 @@ void launchFeed(const DevBatch &d, int sBase, int nStreams, int hopBase, int til
 		else if (perThread <= 24) hipLaunchKernelGGL(kFeedScanC<24>, dim3(tileHops, nStreams), dim3(256), ldsC, st, d, sBase, hopBase);
 		else hipLaunchKernelGGL(kFeedScanC<0>, dim3(tileHops, nStreams), dim3(256), ldsC, st, d, sBase, hopBase);
 	}
+	return false;
 }
 template <int CH>
-static void launchPredictT(const DevBatch &d, int sBase, int nStreams, int hopBase, int tileHops, bool plain, hipStream_t st) {
+static void launchPredictT(const DevBatch &d, int sBase, int nStreams, int hopBase, int tileHops, bool plain, bool passADone, hipStream_t st) {
 	const dim3 grid(divUp(d.M + d.lag*(d.T - 1), 8), nStreams);
 	const size_t lds = (size_t)8*((9 + 3*CH + 3)/4)*65*sizeof(float4);
 	if (plain) {
 		hipLaunchKernelGGL((kPredictB<CH, true>), grid, dim3(256), lds, st, d, sBase, hopBase);
 	} else {
-		hipLaunchKernelGGL(kPredictA, dim3(divUp(d.M, 256), tileHops, nStreams), dim3(256), 0, st, d, sBase, hopBase);
+		if (!passADone) hipLaunchKernelGGL(kPredictA, dim3(divUp(d.M, 256), tileHops, nStreams), dim3(256), 0, st, d, sBase, hopBase);
 		hipLaunchKernelGGL((kPredictB<CH, false>), grid, dim3(256), lds, st, d, sBase, hopBase);
 	}
 }
 // mono / stereo: pass A (only with a pitch map or formants) on the feed-forward stream ...
-void launchPredictFused(const DevBatch &d, int sBase, int nStreams, int hopBase, int tileHops, bool plain, hipStream_t st) {
-	if (!plain) hipLaunchKernelGGL(kPredictA, dim3(divUp(d.M, 256), tileHops, nStreams), dim3(256), 0, st, d, sBase, hopBase);
+void launchPredictFused(const DevBatch &d, int sBase, int nStreams, int hopBase, int tileHops, bool plain, bool passADone, hipStream_t st) {
+	if (!plain && !passADone) hipLaunchKernelGGL(kPredictA, dim3(divUp(d.M, 256), tileHops, nStreams), dim3(256), 0, st, d, sBase, hopBase);
 }
 // ... and the fused producer/consumer recurrence
 template <int CH, int L>
@@ -3019,16 +3077,16 @@ void launchVocoder(const DevBatch &d, int sBase, int nStreams, int hopBase, bool
 	default: launchVocoderN<8>(d, sBase, nStreams, hopBase, plain, st); return;
 	}
 }
-void launchPredict(const DevBatch &d, int sBase, int nStreams, int hopBase, int tileHops, bool plain, hipStream_t st) {
+void launchPredict(const DevBatch &d, int sBase, int nStreams, int hopBase, int tileHops, bool plain, bool passADone, hipStream_t st) {
 	switch (d.C) {
-	case 1: launchPredictT<1>(d, sBase, nStreams, hopBase, tileHops, plain, st); break;
-	case 2: launchPredictT<2>(d, sBase, nStreams, hopBase, tileHops, plain, st); break;
-	case 3: launchPredictT<3>(d, sBase, nStreams, hopBase, tileHops, plain, st); break;
-	case 4: launchPredictT<4>(d, sBase, nStreams, hopBase, tileHops, plain, st); break;
-	case 5: launchPredictT<5>(d, sBase, nStreams, hopBase, tileHops, plain, st); break;
-	case 6: launchPredictT<6>(d, sBase, nStreams, hopBase, tileHops, plain, st); break;
-	case 7: launchPredictT<7>(d, sBase, nStreams, hopBase, tileHops, plain, st); break;
-	default: launchPredictT<8>(d, sBase, nStreams, hopBase, tileHops, plain, st); break;
+	case 1: launchPredictT<1>(d, sBase, nStreams, hopBase, tileHops, plain, passADone, st); break;
+	case 2: launchPredictT<2>(d, sBase, nStreams, hopBase, tileHops, plain, passADone, st); break;
+	case 3: launchPredictT<3>(d, sBase, nStreams, hopBase, tileHops, plain, passADone, st); break;
+	case 4: launchPredictT<4>(d, sBase, nStreams, hopBase, tileHops, plain, passADone, st); break;
+	case 5: launchPredictT<5>(d, sBase, nStreams, hopBase, tileHops, plain, passADone, st); break;
+	case 6: launchPredictT<6>(d, sBase, nStreams, hopBase, tileHops, plain, passADone, st); break;
+	case 7: launchPredictT<7>(d, sBase, nStreams, hopBase, tileHops, plain, passADone, st); break;
+	default: launchPredictT<8>(d, sBase, nStreams, hopBase, tileHops, plain, passADone, st); break;
 	}
 }
 template <int CH>

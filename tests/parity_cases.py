@@ -259,6 +259,32 @@ def case_fused_equals_unfused(lib, monkeypatch, channel_counts=(3, 8), geometry=
         assert np.array_equal(outs[0], outs[1]), (C, float(np.abs(outs[0] - outs[1]).max()))
 
 
+def case_feed_fusion_equals_separate(lib, monkeypatch, channel_counts=(2, 3), geometry=None, n=9000):
+    """Pass A folded into the feed kernel (tiles with a pitch map and no formant processing) against the separate kPredictA
+    (SMST_NO_FEED_FUSION=1): the same arithmetic on the same operands, so bit-identical -- mapped and unmapped streams side
+    by side, two calls."""
+    pkg = package()
+    geometry = geometry or dict(block=512, interval=128, split=False)
+    for C in channel_counts:
+        xs = np.stack([synth_input(s, C, n, 48000)*(1 + 0.2*np.arange(C))[:, None].astype(np.float32) for s in range(4)])
+        outs = []
+        for separate in (False, True):
+            if separate:
+                monkeypatch.setenv("SMST_NO_FEED_FUSION", "1")
+            else:
+                monkeypatch.delenv("SMST_NO_FEED_FUSION", raising=False)
+            b = pkg.StretchBatch(4, C, lib=lib, **geometry)
+            b.setTransposeSemitones(5.0, 0.2, stream=0)
+            b.setTransposeSemitones(-7.0, 0.0, stream=2)
+            y1 = np.array(b.process(xs[:, :, :n//3], int(n//3*0.9)), copy=True)
+            y2 = np.array(b.process(xs[:, :, n//3:], int((n - n//3)*0.9)), copy=True)
+            b.close()
+            outs.append(np.concatenate([y1, y2], axis=2))
+        monkeypatch.delenv("SMST_NO_FEED_FUSION", raising=False)
+        assert np.abs(outs[0]).max() > 0.05
+        assert np.array_equal(outs[0], outs[1]), (C, float(np.abs(outs[0] - outs[1]).max()))
+
+
 def case_single_hop_chunks(lib, geometry=None, channel_counts=(1, 2, 3), hops=15, setup=None):
     """Calls that fire ONE hop each (the real-time pattern) run the single-hop recurrence kernel (kVocoderOne); one call with
     all the hops runs the skewed-wavefront kernels.  Same records, same order of operations: bit-identical outputs."""

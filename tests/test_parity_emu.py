@@ -74,6 +74,10 @@ def test_fused_equals_unfused(emu, monkeypatch):
     pc.case_fused_equals_unfused(emu, monkeypatch, channel_counts=(2, 3, 5))
 
 
+def test_feed_fusion_equals_separate(emu, monkeypatch):
+    pc.case_feed_fusion_equals_separate(emu, monkeypatch)
+
+
 def test_single_hop_chunks(emu):
     pc.case_single_hop_chunks(emu)
     pc.case_single_hop_chunks(emu, channel_counts=(2,), setup=lambda b: b.setTransposeSemitones(5, 0.2))

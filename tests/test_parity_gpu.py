@@ -432,6 +432,11 @@ def test_process_does_not_allocate_in_steady_state_gpu(hip):
     _steady_state_allocations(hip, dict(preset="default", sample_rate=48000.0), S=16, C=2, calls=4)
 
 
+def test_feed_fusion_equals_separate(hip, monkeypatch):
+    pc.case_feed_fusion_equals_separate(hip, monkeypatch, channel_counts=(1, 2, 3, 8))
+    pc.case_feed_fusion_equals_separate(hip, monkeypatch, channel_counts=(2,), geometry=dict(preset="default", sample_rate=48000.0), n=40000)
+
+
 def test_fused_equals_unfused(hip, monkeypatch):
     """3-8 channels: kVocoderN (records in LDS) is bit-identical to kPredictB + kChain (records through HBM)."""
     pc.case_fused_equals_unfused(hip, monkeypatch, channel_counts=(1, 2, 3, 4, 5, 6, 7, 8))
