@@ -978,7 +978,7 @@ struct LerpIndex;
 __device__ __forceinline__ LerpIndex lerpIndex(float x);
 __device__ __forceinline__ float2 bandAt(const float2 *row, int idx, int M);
 template <typename MapAt>
-__device__ __forceinline__ void feedPredictionRows(const DevBatch &d, const HopDesc &hd, int s, int sg, int k, bool mapped, MapAt mapAt);
+__device__ __forceinline__ void feedPredictionRows(const DevBatch &d, const HopDesc &hd, int s, int sg, int k, bool mapped, MapAt mapAt, bool storeMap, const float *ratioLds);
 
 // energy, smoothing, peaks, output map, raw pitch estimate: one workgroup per (hop, stream)
 template <int NMAX, bool FUSE_PE = false> // NMAX: bins per thread held in registers during the smoothing passes; 0: through LDS (any M)
@@ -990,7 +990,7 @@ __global__ __launch_bounds__(256) void kFeedScanA(DevBatch d, int sBase, int hop
 	const HopDesc hd = d.hops[(size_t)sg*d.hopStride + hopBase + k];
 	const bool mapped = hd.flags & HOP_MAPPED, formants = hd.flags & HOP_FORMANTS;
 	if (!mapped && !formants) {
-		if constexpr (FUSE_PE) feedPredictionRows(d, hd, s, sg, k, false, [](int bb) { return make_float2(float(bb), 1.0f); });
+		if constexpr (FUSE_PE) feedPredictionRows(d, hd, s, sg, k, false, [](int bb) { return make_float2(float(bb), 1.0f); }, false, nullptr);
 		return;
 	}
 	const int M = d.M, C = d.C, t = threadIdx.x;
@@ -1143,7 +1143,7 @@ __global__ __launch_bounds__(256) void kFeedScanA(DevBatch d, int sBase, int hop
 #pragma unroll
 			for (int i = 0; i < NMAX; ++i) if (i < cnt) cover[b0 + i] = max(c[i], base);
 			__syncthreads();
-			if constexpr (FUSE_PE) feedPredictionRows(d, hd, s, sg, k, true, [&](int bb) { return mapOf(bb, max(cover[bb], 0)); });
+			if constexpr (FUSE_PE) feedPredictionRows(d, hd, s, sg, k, true, [&](int bb) { return mapOf(bb, max(cover[bb], 0)); }, true, nullptr);
 			else for (int b = t; b < M; b += 256) mapRow[b] = mapOf(b, max(cover[b], 0)); // coalesced stores
 		} else {
 			// by bisection; a thread's bins are 256 apart, so eight independent bisections run in lock step
@@ -1225,13 +1225,19 @@ __global__ __launch_bounds__(64) void kFeedFreq(DevBatch d, int sBase, int nStre
 }
 
 // formant envelope (2 x (down, up) max-decay, 2 x (down, up) min-grow, :987-1006) and the per-bin energy ratio (:1018-1033)
-template <int NMAX>
+template <int NMAX, bool FUSE_PE = false> // FUSE_PE: pass A of the tile's hops here (tiles WITH formant processing; the ratios stay in LDS)
 __global__ __launch_bounds__(256) void kFeedScanC(DevBatch d, int sBase, int hopBase) {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smemRaw[];
 	const int k = blockIdx.x, s = blockIdx.y, sg = sBase + s;
 	if (k >= d.nHops[s]) return;
 	const HopDesc hd = d.hops[(size_t)sg*d.hopStride + hopBase + k];
-	if (!(hd.flags & HOP_FORMANTS)) return;
+	if (!(hd.flags & HOP_FORMANTS)) {
+		if constexpr (FUSE_PE) {
+			const float2 *mapRowIn = d.map + ((size_t)s*d.T + k)*d.M;
+			feedPredictionRows(d, hd, s, sg, k, (hd.flags & HOP_MAPPED) != 0, [&](int bb) { return mapRowIn[bb]; }, false, nullptr);
+		}
+		return;
+	}
 	const int M = d.M, C = d.C, t = threadIdx.x;
 	const float Nf = float(d.N);
 	float *en = reinterpret_cast<float *>(smemRaw);
@@ -1304,7 +1310,13 @@ __global__ __launch_bounds__(256) void kFeedScanC(DevBatch d, int sBase, int hop
 			const float low = (fl < M) ? sm[fl] : 0.0f, high = (fl + 1 < M) ? sm[fl + 1] : 0.0f;
 			targetE = low + (high - low)*fr;
 		}
-		ratio[b] = targetE/(inputE + 1e-30f);
+		if constexpr (FUSE_PE) en[b] = targetE/(inputE + 1e-30f); // the energies are dead: the ratios take their place in LDS
+		else ratio[b] = targetE/(inputE + 1e-30f);
+	}
+	if constexpr (FUSE_PE) {
+		__syncthreads();
+		const float2 *mapRowIn = d.map + ((size_t)s*d.T + k)*M;
+		feedPredictionRows(d, hd, s, sg, k, (hd.flags & HOP_MAPPED) != 0, [&](int bb) { return mapRowIn[bb]; }, false, en);
 	}
 }
 
@@ -1423,8 +1435,10 @@ __device__ __forceinline__ float2 lockedOutput(float2 om, const float (&f)[NFLOA
 	return cadd(cmul(om, make_float2(f[12], f[13])), make_float2(f[14], f[15]));
 }
 
+// storeMap: mapAt has just computed the entry (kFeedScanA) and it goes to the map row; otherwise mapAt reads that row.
+// ratioLds: the hop's formant energy ratios (kFeedScanC keeps them in LDS), applied to the two energy taps as kPredictA does.
 template <typename MapAt>
-__device__ __forceinline__ void feedPredictionRows(const DevBatch &d, const HopDesc &hd, int s, int sg, int k, bool mapped, MapAt mapAt) {
+__device__ __forceinline__ void feedPredictionRows(const DevBatch &d, const HopDesc &hd, int s, int sg, int k, bool mapped, MapAt mapAt, bool storeMap, const float *ratioLds) {
 	const int M = d.M, C = d.C, t = threadIdx.x;
 	float2 *mapRow = d.map + ((size_t)s*d.T + k)*M;
 	for (int b0 = t; b0 < M; b0 += 8*256) {
@@ -1434,7 +1448,7 @@ __device__ __forceinline__ void feedPredictionRows(const DevBatch &d, const HopD
 		for (int i = 0; i < 8; ++i) {
 			const int b = b0 + 256*i;
 			float2 mp = make_float2(float(b), 1.0f);
-			if (b < M && mapped) { mp = mapAt(b); mapRow[b] = mp; }
+			if (b < M && mapped) { mp = mapAt(b); if (storeMap) mapRow[b] = mp; }
 			li[i] = lerpIndex(mp.x);
 			grad[i] = fmaxf(0.0f, mp.y);
 		}
@@ -1447,7 +1461,11 @@ __device__ __forceinline__ void feedPredictionRows(const DevBatch &d, const HopD
 			for (int i = 0; i < 8; ++i) {
 				const int b = b0 + 256*i;
 				if (b >= M) continue;
-				const float eLo = cnorm(lo[i]), eHi = cnorm(hi[i]);
+				float eLo = cnorm(lo[i]), eHi = cnorm(hi[i]);
+				if (ratioLds) {
+					if (li[i].lo >= 0 && li[i].lo < M) eLo *= ratioLds[li[i].lo];
+					if (li[i].lo + 1 >= 0 && li[i].lo + 1 < M) eHi *= ratioLds[li[i].lo + 1];
+				}
 				PredEntry pe;
 				pe.x = lo[i].x + (hi[i].x - lo[i].x)*li[i].fr;
 				pe.y = lo[i].y + (hi[i].y - lo[i].y)*li[i].fr;
@@ -2963,6 +2981,12 @@ bool launchFeed(const DevBatch &d, int sBase, int nStreams, int hopBase, int til
 	else hipLaunchKernelGGL(kFeedScanA<0>, dim3(tileHops, nStreams), dim3(256), ldsA, st, d, sBase, hopBase);
 	if (anyFormants) {
 		hipLaunchKernelGGL(kFeedFreq, dim3(divUp(nStreams, 64)), dim3(64), 0, st, d, sBase, nStreams, hopBase);
+		if (!d.noFeedFusion) { // tiles with formant processing: pass A at the end of the envelope kernel, the ratios still in LDS
+			if (perThread <= 16) hipLaunchKernelGGL((kFeedScanC<16, true>), dim3(tileHops, nStreams), dim3(256), ldsC, st, d, sBase, hopBase);
+			else if (perThread <= 24) hipLaunchKernelGGL((kFeedScanC<24, true>), dim3(tileHops, nStreams), dim3(256), ldsC, st, d, sBase, hopBase);
+			else hipLaunchKernelGGL((kFeedScanC<0, true>), dim3(tileHops, nStreams), dim3(256), ldsC, st, d, sBase, hopBase);
+			return true;
+		}
 		if (perThread <= 16) hipLaunchKernelGGL(kFeedScanC<16>, dim3(tileHops, nStreams), dim3(256), ldsC, st, d, sBase, hopBase);
 		else if (perThread <= 24) hipLaunchKernelGGL(kFeedScanC<24>, dim3(tileHops, nStreams), dim3(256), ldsC, st, d, sBase, hopBase);
 		else hipLaunchKernelGGL(kFeedScanC<0>, dim3(tileHops, nStreams), dim3(256), ldsC, st, d, sBase, hopBase);

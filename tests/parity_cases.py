@@ -259,7 +259,7 @@ def case_fused_equals_unfused(lib, monkeypatch, channel_counts=(3, 8), geometry=
         assert np.array_equal(outs[0], outs[1]), (C, float(np.abs(outs[0] - outs[1]).max()))
 
 
-def case_feed_fusion_equals_separate(lib, monkeypatch, channel_counts=(2, 3), geometry=None, n=9000):
+def case_feed_fusion_equals_separate(lib, monkeypatch, channel_counts=(2, 3), geometry=None, n=9000, formants=False):
     """Pass A folded into the feed kernel (tiles with a pitch map and no formant processing) against the separate kPredictA
     (SMST_NO_FEED_FUSION=1): the same arithmetic on the same operands, so bit-identical -- mapped and unmapped streams side
     by side, two calls."""
@@ -276,6 +276,10 @@ def case_feed_fusion_equals_separate(lib, monkeypatch, channel_counts=(2, 3), ge
             b = pkg.StretchBatch(4, C, lib=lib, **geometry)
             b.setTransposeSemitones(5.0, 0.2, stream=0)
             b.setTransposeSemitones(-7.0, 0.0, stream=2)
+            if formants:  # formant tiles fold pass A into the envelope kernel instead (ratios in LDS)
+                b.setFormantFactor(1.0, True, stream=0)
+                b.setFormantBase(200/48000, stream=0)
+                b.setFormantSemitones(3.0, False, stream=3)
             y1 = np.array(b.process(xs[:, :, :n//3], int(n//3*0.9)), copy=True)
             y2 = np.array(b.process(xs[:, :, n//3:], int((n - n//3)*0.9)), copy=True)
             b.close()

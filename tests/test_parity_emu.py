@@ -76,6 +76,7 @@ def test_fused_equals_unfused(emu, monkeypatch):
 
 def test_feed_fusion_equals_separate(emu, monkeypatch):
     pc.case_feed_fusion_equals_separate(emu, monkeypatch)
+    pc.case_feed_fusion_equals_separate(emu, monkeypatch, channel_counts=(2,), formants=True)
 
 
 def test_single_hop_chunks(emu):
