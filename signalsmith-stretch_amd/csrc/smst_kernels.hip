@@ -1853,7 +1853,11 @@ template <int CH, int L>
 struct StageGeom {
 	static constexpr int PIN = (8 + 3*L + 1)/2;  // 16-byte pieces (2 bins) of one IN window
 	static constexpr int PPV = (7 + L + 1)/2;    // pieces of one PV / ROT window
-	static constexpr int PV_OFF = CH*2*PIN, ROT_OFF = PV_OFF + CH*2*PPV, ROWLEN = ROT_OFF + 2*PPV; // float2 units
+	static constexpr int PV_OFF = CH*2*PIN, ROT_OFF = PV_OFF + CH*2*PPV, ROWUSED = ROT_OFF + 2*PPV; // float2 units
+	// row pitch = 8 (mod 16) float2: the 16 lanes an LDS cycle serves are two rows x eight consecutive bins, and with this
+	// pitch the two rows fall into the two halves of the 32 banks (76 float2 put rows r and r+4 on the same banks: every
+	// read of the record computation two-way conflicted; SQ_LDS_BANK_CONFLICT 143 M cycles per launch)
+	static constexpr int ROWLEN = ((ROWUSED + 7)/16)*16 + 8;
 	static constexpr int ROW_PIECES = CH*PIN + CH*PPV + PPV;
 	static constexpr int X_FIRST = L/2, X_PIECES = 3 + L - L/2 + 1; // extra row (hop above): window indices [L, 6+2L]
 	static constexpr int TOTAL = 8*ROW_PIECES + CH*X_PIECES;
@@ -2042,7 +2046,7 @@ __device__ __forceinline__ void vocoderProduceStaged(const DevBatch &d, int s, i
 			recordChannelFields<CH>(f, p, e, mc);
 		}
 #pragma unroll
-		for (int j = 0; j < NCH; ++j) recs[((slot*BS + st)*NCH + j)*64 + ((row + 2*st) & 63)] = make_float4(f[4*j], f[4*j + 1], f[4*j + 2], f[4*j + 3]);
+		for (int j = 0; j < NCH; ++j) recs[((slot*BS + st)*NCH + j)*64 + ((row + st) & 63)] = make_float4(f[4*j], f[4*j + 1], f[4*j + 2], f[4*j + 3]);
 		asm volatile("" ::: "memory");
 		if (k == 0) ldsCount(&sync[slot]);
 		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -2181,8 +2185,9 @@ __global__ __launch_bounds__(64*kVocWaves) __attribute__((amdgpu_waves_per_eu(4,
 			while (n - ldsPeek(&sync[NB]) >= NB) __builtin_amdgcn_s_sleep(2); // slot still being read (waited for AFTER the pass is computed)
 			asm volatile("" ::: "memory");
 #pragma unroll
-			// lane rotation by 2*st spreads the 8 lanes of a row (same row, 8 steps = 8 LDS rows a multiple of 256 B apart) over 8 bank groups
-			for (int j = 0; j < NCH; ++j) recs[((slot*BS + st)*NCH + j)*64 + ((row + 2*st) & 63)] = make_float4(f[4*j], f[4*j + 1], f[4*j + 2], f[4*j + 3]);
+			// lane rotation by st: the 8 lanes of a row (same row, 8 steps = 8 LDS rows a multiple of 4 KB apart) land in 8 different
+			// 16-byte bank groups (a rotation by 2*st, the first version, used only four of them)
+			for (int j = 0; j < NCH; ++j) recs[((slot*BS + st)*NCH + j)*64 + ((row + st) & 63)] = make_float4(f[4*j], f[4*j + 1], f[4*j + 2], f[4*j + 3]);
 			asm volatile("" ::: "memory");
 			if (k == 0) ldsCount(&sync[slot]); // LDS ops of a wave are in order: data first, then the count
 		}
@@ -2247,7 +2252,7 @@ __global__ __launch_bounds__(64*kVocWaves) __attribute__((amdgpu_waves_per_eu(4,
 				const int t = tb + blk*BS + i;
 				if (i + 1 < BS) {
 #pragma unroll
-					for (int j = 0; j < NCH; ++j) q[(i + 1) & 1][j] = blockRecs[((i + 1)*NCH + j)*64 + ((k + 2*(i + 1)) & 63)];
+					for (int j = 0; j < NCH; ++j) q[(i + 1) & 1][j] = blockRecs[((i + 1)*NCH + j)*64 + ((k + (i + 1)) & 63)];
 				} else { // last step: look at the next block's hand-off words now, their latency hides under this step
 					seenProduced = ldsPeek(&sync[(n + 1)%NB]);
 					seenWritten = ldsPeek(&sync[NB + 2]);
@@ -2406,7 +2411,7 @@ __global__ __launch_bounds__(64*kVocWaves) __attribute__((amdgpu_waves_per_eu(4,
 			while (n - ldsPeek(&sync[NB]) >= NB) __builtin_amdgcn_s_sleep(2); // slot still being read
 			asm volatile("" ::: "memory");
 #pragma unroll
-			for (int j = 0; j < NCH; ++j) recs[((slot*BS + st)*NCH + j)*64 + ((row + 2*st) & 63)] = make_float4(f[4*j], f[4*j + 1], f[4*j + 2], f[4*j + 3]);
+			for (int j = 0; j < NCH; ++j) recs[((slot*BS + st)*NCH + j)*64 + ((row + st) & 63)] = make_float4(f[4*j], f[4*j + 1], f[4*j + 2], f[4*j + 3]);
 			asm volatile("" ::: "memory");
 			if (k == 0) ldsCount(&sync[slot]); // LDS ops of a wave are in order: data first, then the count
 		}
@@ -2455,7 +2460,7 @@ __global__ __launch_bounds__(64*kVocWaves) __attribute__((amdgpu_waves_per_eu(4,
 				float f[NCH*4];
 #pragma unroll
 				for (int j = 0; j < NCH; ++j) {
-					const float4 q = blockRecs[(i*NCH + j)*64 + ((k + 2*i) & 63)];
+					const float4 q = blockRecs[(i*NCH + j)*64 + ((k + i) & 63)];
 					f[4*j] = q.x; f[4*j + 1] = q.y; f[4*j + 2] = q.z; f[4*j + 3] = q.w;
 				}
 				const int b = t - kLag;
