@@ -2056,6 +2056,9 @@ __device__ __forceinline__ void vocoderProduceStaged(const DevBatch &d, int s, i
 }
 
 constexpr int kVocBlockSteps = 8, kVocBlocks = 3, kVocBlocksStaged = 2, kVocWaves = 16, kVocStagedProducers = 8, kVocOutBlocks = 4;
+// results ring: [block][step][channel][kVocOutPitch] -- 66, not 64: the writer reads a row's values of steps 2 apart in adjacent
+// lane groups, and 2*CH*64 float2 is a multiple of the 32 banks (an 8-way conflict on every writer read with the first layout)
+constexpr int kVocOutPitch = 66;
 
 __device__ __forceinline__ float2 fromLaneBelow(float2 v, float2 lane0) { // lane k receives lane k-1's v; lane 0 keeps its `lane0`
 	// DPP wave_shr:1 without bound_ctrl: a lane with no source lane keeps the old value of the destination register
@@ -2097,7 +2100,7 @@ __global__ __launch_bounds__(64*kVocWaves) __attribute__((amdgpu_waves_per_eu(4,
 	}
 	if (threadIdx.x <= NB + 2) sync[threadIdx.x] = 0;
 	if (threadIdx.x < 64) hopsLds[threadIdx.x] = d.hops[(size_t)sg*d.hopStride + hopBase + threadIdx.x];
-	float2 *rotLds = outRing + (size_t)kVocOutBlocks*BS*CH*64; // [M] hop rotation table (ROTL; the staged kernel keeps its windows here)
+	float2 *rotLds = outRing + (size_t)kVocOutBlocks*BS*CH*kVocOutPitch; // [M] hop rotation table (ROTL; the staged kernel keeps its windows here)
 	if constexpr (ROTL) {
 		for (int i = threadIdx.x; i < M; i += blockDim.x) rotLds[i] = d.rot[i];
 	}
@@ -2125,7 +2128,7 @@ __global__ __launch_bounds__(64*kVocWaves) __attribute__((amdgpu_waves_per_eu(4,
 			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 			__builtin_amdgcn_wave_barrier();
 			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-			const int g8 = k >> 3, part = k & 7;
+			const int g8 = k & 7, part = k >> 3; // eight consecutive lanes read eight consecutive rows of the ring (conflict-free); a store instruction still covers whole lines
 			for (int n = 0; n <= totalBlocks + 1; ++n) {
 				if (n < totalBlocks) {
 					while (ldsPeek(&sync[NB + 1]) <= n) __builtin_amdgcn_s_sleep(2);
@@ -2142,7 +2145,7 @@ __global__ __launch_bounds__(64*kVocWaves) __attribute__((amdgpu_waves_per_eu(4,
 					const int r0 = t0 >= 0 ? (t0 >> 3)%kVocOutBlocks : 0, r1 = t1 >= 0 ? (t1 >> 3)%kVocOutBlocks : 0;
 #pragma unroll
 					for (int c = 0; c < CH; ++c) {
-						float2 v0 = outRing[((r0*BS + (t0 & 7))*CH + c)*64 + row], v1 = outRing[((r1*BS + (t1 & 7))*CH + c)*64 + row];
+						float2 v0 = outRing[((r0*BS + (t0 & 7))*CH + c)*kVocOutPitch + row], v1 = outRing[((r1*BS + (t1 & 7))*CH + c)*kVocOutPitch + row];
 						if (b >= M) v0 = make_float2(0.f, 0.f);
 						if (b + 1 >= M) v1 = make_float2(0.f, 0.f);
 						if (ok) {
@@ -2167,7 +2170,7 @@ __global__ __launch_bounds__(64*kVocWaves) __attribute__((amdgpu_waves_per_eu(4,
 		if (pIndex >= NP) return;
 		if constexpr (STAGED) {
 			using G = StageGeom<CH, L>;
-			float2 *sbuf = outRing + (size_t)kVocOutBlocks*BS*CH*64 + (size_t)pIndex*G::ROWS*G::ROWLEN;
+			float2 *sbuf = outRing + (size_t)kVocOutBlocks*BS*CH*kVocOutPitch + (size_t)pIndex*G::ROWS*G::ROWLEN;
 			vocoderProduceStaged<CH, L, NB, NP>(d, s, sg, nh, pIndex, k, totalBlocks, recs, sync, hopsLds, sbuf);
 			return;
 		}
@@ -2242,7 +2245,7 @@ __global__ __launch_bounds__(64*kVocWaves) __attribute__((amdgpu_waves_per_eu(4,
 			const float4 *blockRecs = recs + (size_t)slot*BS*NCH*64;
 			while (n - seenWritten >= 2) { __builtin_amdgcn_s_sleep(1); seenWritten = ldsPeek(&sync[NB + 2]); } // the writer still owns this result slot
 			asm volatile("" ::: "memory");
-			float2 *blockOut = outRing + (size_t)(n%kVocOutBlocks)*BS*CH*64 + k;
+			float2 *blockOut = outRing + (size_t)(n%kVocOutBlocks)*BS*CH*kVocOutPitch + k;
 			float4 q[2][NCH]; // two register sets alternate, so the next step's record loads never overwrite live values
 #pragma unroll
 			for (int j = 0; j < NCH; ++j) q[0][j] = blockRecs[j*64 + k];
@@ -2293,13 +2296,13 @@ __global__ __launch_bounds__(64*kVocWaves) __attribute__((amdgpu_waves_per_eu(4,
 					const float2 oc0 = mc ? olock : om, oc1 = mc ? om : olock;
 					h[i][0] = oc0;
 					h[i][CH - 1] = oc1;
-					blockOut[(i*CH)*64] = oc0;
-					blockOut[(i*CH + CH - 1)*64] = oc1;
+					blockOut[(i*CH)*kVocOutPitch] = oc0;
+					blockOut[(i*CH + CH - 1)*kVocOutPitch] = oc1;
 				} else {
 #pragma unroll
 					for (int c = 0; c < CH; ++c) {
 						h[i][c] = om;
-						blockOut[(i*CH + c)*64] = om;
+						blockOut[(i*CH + c)*kVocOutPitch] = om;
 					}
 				}
 			}
@@ -3017,7 +3020,7 @@ void launchPredictFused(const DevBatch &d, int sBase, int nStreams, int hopBase,
 template <int CH, int L>
 static void launchVocoderTL(const DevBatch &d, int sBase, int nStreams, int hopBase, bool plain, bool bounded, hipStream_t st) {
 	constexpr int NCH = (9 + 3*CH + 3)/4;
-	const size_t fixed = (size_t)CH*128*sizeof(float2) + 64 + 128*sizeof(int) + 64*sizeof(HopDesc) + (size_t)kVocOutBlocks*kVocBlockSteps*CH*64*sizeof(float2);
+	const size_t fixed = (size_t)CH*128*sizeof(float2) + 64 + 128*sizeof(int) + 64*sizeof(HopDesc) + (size_t)kVocOutBlocks*kVocBlockSteps*CH*kVocOutPitch*sizeof(float2);
 	const size_t lds = (size_t)kVocBlocks*kVocBlockSteps*NCH*64*sizeof(float4) + fixed;
 	if constexpr (L <= 5) {
 		if (plain && bounded && !d.noStage) {
