@@ -1551,7 +1551,7 @@ __device__ __forceinline__ float2 twistAt(const RecordSource<CH, PLAIN> &src, in
 	return make_float2(r.x*inv, r.y*inv);
 }
 
-// Fills one record.  Per-channel fields: {P.x, P.y, sqrt(E)} and, with LOCK, the channel-lock twist P_c conj(P_m).
+// Fills one record.  Per-channel fields: see recordChannelFields.  (LOCK: kept in the signature for the call sites, always false.)
 // SPEC (mono/stereo): the four twists are evaluated for EVERY channel and the maximum-energy channel's set is
 // selected afterwards, so no load address depends on loaded data (one memory round trip per record instead of two).
 // ROT_LDS: the hop-rotation table is read from `rotLds` (a copy in LDS) instead of d.rot -- three of a mapped record's 18
@@ -1561,7 +1561,6 @@ __device__ __forceinline__ void computeRecord(const DevBatch &d, const HopDesc &
                                               const float2 *rotLds = nullptr) {
 	const float2 *rot;
 	if constexpr (ROT_LDS) rot = rotLds; else rot = d.rot;
-	constexpr int PC = LOCK ? 5 : 3;
 	const int M = d.M, L = d.L;
 	const bool rotate = hd.flags & HOP_NEW_SPECTRUM, randomTf = hd.flags & HOP_RANDOM_TF;
 	const RecordSource<CH, PLAIN> src(d, hd, s, k, sg);
@@ -1634,7 +1633,6 @@ __device__ __forceinline__ void computeRecord(const DevBatch &d, const HopDesc &
 	f[0] = A.x; f[1] = A.y; f[2] = B.x; f[3] = B.y; f[4] = Cc.x; f[5] = Cc.y; f[6] = Dc.x; f[7] = Dc.y;
 	f[8] = __int_as_float(mc);
 	static_assert(!LOCK, "the separate lock-twist fields are gone: stereo records carry the scaled twist (recordChannelFields)");
-	(void)PC;
 	recordChannelFields<CH>(f, p, e, mc);
 }
 
