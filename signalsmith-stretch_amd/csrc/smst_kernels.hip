@@ -2262,8 +2262,7 @@ __global__ __launch_bounds__(64*kVocWaves) __attribute__((amdgpu_waves_per_eu(4,
 #pragma unroll
 				for (int j = 0; j < NCH; ++j) { f[4*j] = q[i & 1][j].x; f[4*j + 1] = q[i & 1][j].y; f[4*j + 2] = q[i & 1][j].z; f[4*j + 3] = q[i & 1][j].w; }
 				const int b = t - kLag;
-				int mc = __float_as_int(f[8]);
-				mc = (mc < 0) ? 0 : ((mc > CH - 1) ? CH - 1 : mc);
+				const int mc = __float_as_int(f[8]); // 0 .. CH-1: every record of the ring was written by a producer (all-zero outside the tile)
 				// taps: own history, and lane k-1's history (lane 0: the staged carried state)
 				float2 o1 = h[(i + 7) & 7][0], oL = h[(i + 8 - L) & 7][0];
 				float2 p1 = fromLaneBelow(oL, sv1[0]), pL = fromLaneBelow(o1, svL[0]); // lane 0: the staged carried state
