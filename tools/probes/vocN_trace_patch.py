@@ -20,7 +20,7 @@ rep("""			const int n = u/UNITS, it = u - n*UNITS;
 rep("""			while (n - ldsPeek(&sync[NB]) >= NB) __builtin_amdgcn_s_sleep(2); // slot still being read
 			asm volatile("" ::: "memory");
 #pragma unroll
-			for (int j = 0; j < NCH; ++j) recs[((slot*BS + st)*NCH + j)*64 + ((row + 2*st) & 63)] = make_float4(f[4*j], f[4*j + 1], f[4*j + 2], f[4*j + 3]);
+			for (int j = 0; j < NCH; ++j) recs[((slot*BS + st)*NCH + j)*64 + ((row + st) & 63)] = make_float4(f[4*j], f[4*j + 1], f[4*j + 2], f[4*j + 3]);
 			asm volatile("" ::: "memory");
 			if (k == 0) ldsCount(&sync[slot]); // LDS ops of a wave are in order: data first, then the count
 		}
@@ -35,7 +35,7 @@ rep("""			while (n - ldsPeek(&sync[NB]) >= NB) __builtin_amdgcn_s_sleep(2); // s
 			asm volatile("" ::: "memory");
 			if (pIndex == 0) TR(3, u/NP);
 #pragma unroll
-			for (int j = 0; j < NCH; ++j) recs[((slot*BS + st)*NCH + j)*64 + ((row + 2*st) & 63)] = make_float4(f[4*j], f[4*j + 1], f[4*j + 2], f[4*j + 3]);
+			for (int j = 0; j < NCH; ++j) recs[((slot*BS + st)*NCH + j)*64 + ((row + st) & 63)] = make_float4(f[4*j], f[4*j + 1], f[4*j + 2], f[4*j + 3]);
 			asm volatile("" ::: "memory");
 			if (k == 0) ldsCount(&sync[slot]); // LDS ops of a wave are in order: data first, then the count
 		}

@@ -23,12 +23,12 @@ rep("""		while (n - ldsPeek(&sync[NB]) >= NB) __builtin_amdgcn_s_sleep(2); // sl
 		if (pIndex == 0) TR(2, n);
 		const int b0 = BS*n - lag*row, b = b0 + st;""")
 rep("""#pragma unroll
-		for (int j = 0; j < NCH; ++j) recs[((slot*BS + st)*NCH + j)*64 + ((row + 2*st) & 63)] = make_float4(f[4*j], f[4*j + 1], f[4*j + 2], f[4*j + 3]);
+		for (int j = 0; j < NCH; ++j) recs[((slot*BS + st)*NCH + j)*64 + ((row + st) & 63)] = make_float4(f[4*j], f[4*j + 1], f[4*j + 2], f[4*j + 3]);
 		asm volatile("" ::: "memory");
 		if (k == 0) ldsCount(&sync[slot]);
 		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");""","""		if (pIndex == 0) TR(3, n);
 #pragma unroll
-		for (int j = 0; j < NCH; ++j) recs[((slot*BS + st)*NCH + j)*64 + ((row + 2*st) & 63)] = make_float4(f[4*j], f[4*j + 1], f[4*j + 2], f[4*j + 3]);
+		for (int j = 0; j < NCH; ++j) recs[((slot*BS + st)*NCH + j)*64 + ((row + st) & 63)] = make_float4(f[4*j], f[4*j + 1], f[4*j + 2], f[4*j + 3]);
 		asm volatile("" ::: "memory");
 		if (k == 0) ldsCount(&sync[slot]);
 		if (pIndex == 0) TR(4, n);
