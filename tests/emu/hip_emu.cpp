@@ -79,9 +79,9 @@ bool emuAny(bool v) {
 	const int me = laneIndex(), bank = collectiveSeq[me]++ & 1;
 	anyBank[bank][me] = v;
 	emuSyncThreads();
-	bool r = false;
-	const int n = (int)(blockDim.x*blockDim.y*blockDim.z);
-	for (int i = 0; i < n; ++i) r = r || anyBank[bank][i];
+	bool r = false; // a wave-level vote: the 64 lanes of the caller's own wave (other waves may not be voting at all)
+	const int n = (int)(blockDim.x*blockDim.y*blockDim.z), w0 = me & ~63;
+	for (int i = w0; i < w0 + 64 && i < n; ++i) r = r || anyBank[bank][i];
 	emuSyncThreads();
 	return r;
 }
