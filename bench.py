@@ -66,16 +66,17 @@ def host_topology():
     return len(per_core), per_core, len(logical)
 
 
-def cpu_baseline(budget_s=6.0):
-    """The CPU reference (oracle/_ref) on this box's host cores: ONE PROCESS PER PHYSICAL CORE, each pinned to its core and
-    rendering 10 s stereo streams at 1.5x back to back for `budget_s` seconds of process() time (bounded sample).  The
-    earlier one-process-per-LOGICAL-core figure swung by 2x between boxes (SMT siblings + unpinned processes contending);
-    `single_core` is the same binary on one otherwise idle core, measured first."""
+def cpu_baseline(budget_s=5.0):
+    """The CPU reference (oracle/_ref) on this box's host cores, timed TWICE on a bounded sample: one pinned process per
+    PHYSICAL core, and one pinned process per LOGICAL CPU (SMT siblings busy too).  `value` is the LARGER aggregate (the
+    better the CPU does, the more honest any ratio against it); both are reported, with the single-idle-core rate measured
+    first.  Each process renders 10 s stereo streams at 1.5x back to back for `budget_s` seconds of process() time."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import ref_oracle
     if not ref_oracle.available():
         return None
     physical, cpus, logical = host_topology()
+    all_cpus = sorted(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else list(range(os.cpu_count() or 1))
     script = os.path.join(ROOT, "oracle", "cpu_baseline.py")
 
     def launch(cpu, budget, first):
@@ -85,20 +86,30 @@ def cpu_baseline(budget_s=6.0):
             except OSError:
                 pass
         return subprocess.Popen([sys.executable, script, str(budget), "10", "1.5", str(first)], stdout=subprocess.PIPE, text=True, preexec_fn=pin)
+
+    def aggregate(cpu_list):
+        t0 = time.perf_counter()
+        procs = [launch(cpu, budget_s, 3*i) for i, cpu in enumerate(cpu_list)]
+        outs = [json.loads(p.communicate()[0].strip().splitlines()[-1]) for p in procs]
+        wall = time.perf_counter() - t0
+        # all processes busy concurrently: sum of per-process rates (time inside process() only)
+        return sum(o["samples"]/o["process_s"] for o in outs), sum(o["streams"] for o in outs), wall
+
     one = json.loads(launch(cpus[0], 1.5, 0).communicate()[0].strip().splitlines()[-1])
     single = one["samples"]/one["process_s"]
-    t0 = time.perf_counter()
-    procs = [launch(cpu, budget_s, 3*i) for i, cpu in enumerate(cpus)]
-    outs = [json.loads(p.communicate()[0].strip().splitlines()[-1]) for p in procs]
-    wall = time.perf_counter() - t0
-    rate = sum(o["samples"]/o["process_s"] for o in outs)  # all cores busy concurrently: sum of per-core rates
-    streams = sum(o["streams"] for o in outs)
-    return dict(value=rate/1e6, unit="Msamples/s", cores=physical, kind="reference",
-                sample="%d pinned processes (one per PHYSICAL core; %d logical CPUs) x ~%.0f s of process() each = %d stereo 48 kHz "
-                       "presetDefault streams of 10 s at 1.5x; unmodified reference header, g++ -O3, L1 (signalsmith-linear) restated "
-                       "in oracle/linear_shim; wall %.1f s" % (physical, logical, budget_s, streams, wall),
-                logical_cpus=logical, single_core_Msamples_s=single/1e6, per_core_when_all_busy_Msamples_s=rate/1e6/max(physical, 1),
-                realtime_x=rate/(2*2.5*SR))
+    rate_phys, streams_phys, wall_phys = aggregate(cpus)
+    rate_log, streams_log, wall_log = (rate_phys, streams_phys, wall_phys) if logical == physical else aggregate(all_cpus)
+    use_logical = rate_log > rate_phys
+    rate, threads = (rate_log, logical) if use_logical else (rate_phys, physical)
+    return dict(value=rate/1e6, unit="Msamples/s", cores=threads, kind="reference",
+                sample="the larger of two aggregates, each = pinned processes x ~%.0f s of process() on stereo 48 kHz presetDefault "
+                       "streams of 10 s at 1.5x: %d processes (one per PHYSICAL core) = %.1f Msamples/s over %d streams, wall %.1f s; "
+                       "%d processes (one per LOGICAL CPU) = %.1f Msamples/s over %d streams, wall %.1f s; unmodified reference "
+                       "header, g++ -O3, L1 (signalsmith-linear) restated in oracle/linear_shim"
+                       % (budget_s, physical, rate_phys/1e6, streams_phys, wall_phys, logical, rate_log/1e6, streams_log, wall_log),
+                physical_cores=physical, logical_cpus=logical,
+                per_physical_core_pinned_Msamples_s=rate_phys/1e6, per_logical_cpu_pinned_Msamples_s=rate_log/1e6,
+                single_core_Msamples_s=single/1e6, realtime_x=rate/(2*2.5*SR))
 
 
 def pin_rank_to_numa_node(local_rank, world):
@@ -129,17 +140,51 @@ def pin_rank_to_numa_node(local_rank, world):
         return None
 
 
+def own_algorithmic_bytes(B, I, M, r):
+    """The SURVEY.md 8(d) figure split by the kernel class that owns each term (they add up to the whole):
+    analysis = the new input samples; recurrence = the carried per-bin state read + written (Band.output 8 B +
+    Prediction.energy 4 B, + prevInput when it is carried instead of re-analysed); synthesis + emission = the output
+    samples and the overlap-add partial sums read + written."""
+    return {"analyse": 4*(I/r), "chain": 2*12*M + (2*8*M if r == 1 else 0), "synth+emit": 4*I + 2*4*(B - I)}
+
+
+def library_sha16():
+    import hashlib
+    pkg = importlib.import_module("signalsmith-stretch_amd")
+    with open(pkg.LIBRARY_PATH, "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()[:16]
+
+
+def measured_traffic(sha16):
+    """HBM bytes per step from the PMC passes (rocprofv3 FETCH_SIZE / WRITE_SIZE, separate runs, gfx950 correction:
+    profiles/summarize.py) -- ONLY if profiles/traffic_latest.json was measured on this very library build; a bench
+    run cannot collect PMC counters itself, so anything else is reported as null."""
+    path = os.path.join(ROOT, "profiles", "traffic_latest.json")
+    try:
+        t = json.load(open(path))
+    except Exception:
+        return None, "none (no PMC summary in profiles/)"
+    if t.get("library_sha16") != sha16:
+        return None, "none (profiles/traffic_latest.json was measured on library %s, this run uses %s)" % (t.get("library_sha16"), sha16)
+    return t, "profiles/traffic_latest.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `%s` on library %s)" % (t.get("command", "bench.py"), sha16)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--streams", type=int, default=256, help="streams per GPU (BASELINE configs[1]: 256)")
     ap.add_argument("--seconds", type=float, default=10.0, help="seconds of input per stream per step")
     ap.add_argument("--stretch", type=float, default=1.5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-serial-pass", action="store_true", help="skip the extra, serialised per-kernel-class profiling call (used under rocprofv3, so that every launch it sees is an in-place one)")
-    ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (RCCL) even with one rank: exercises the barrier / max-over-ranks path of the N>1 runs on a 1-GPU box")
+    ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed even with one rank: exercises the barrier / max-over-ranks path of the N>1 runs on a 1-GPU box")
+    ap.add_argument("--oversubscribe", action="store_true", help="N ranks on ONE GPU (every LOCAL_RANK maps to device 0): exercises the N>1 launch path -- rendezvous, barrier, "
+                    "all_reduce(MAX/SUM), NUMA pinning, engines sharing a device -- where only one GPU exists.  The line says so in config.sharding; it is not a scaling measurement")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"], help="nccl = RCCL (the multi-GPU default); gloo only for --oversubscribe if RCCL refuses two ranks on one device")
+    ap.add_argument("--as-rank", type=int, default=None, help="single-process run with the stream indices and seed of this rank (cross-check of an --oversubscribe run)")
+    ap.add_argument("--dump-output", default=None, help="write rank-local output of the first streams to this .npy prefix (oversubscribe cross-check)")
     ap.add_argument("--half-state", action="store_true", help="BASELINE config 5 'fp16 internal': carried state and overlap-add sums stored in fp16 (SMST_FLAG_HALF_STATE)")
     ap.add_argument("--config", default="2", choices=["2", "3", "4", "4b", "5"],
                     help="BASELINE.json config (default 2 = the one the headline metric is quoted on; the others are "
@@ -167,33 +212,47 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    stream_rank = args.as_rank if (args.as_rank is not None and world == 1) else rank
     if world != args.gpus and world > 1:
         raise SystemExit("WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus))
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    dev_index = 0 if args.oversubscribe else local_rank
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     use_dist = world > 1 or args.force_dist
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+    red_device = device if args.dist_backend == "nccl" else torch.device("cpu")
 
-    affinity = pin_rank_to_numa_node(local_rank, world) if world > 1 else None
+    affinity = pin_rank_to_numa_node(dev_index if args.oversubscribe else local_rank, world) if world > 1 else None
+    if args.oversubscribe and affinity and world > 1:  # ranks share the device's NUMA node: split its CPUs by RANK, not by device index
+        try:
+            cpus = sorted(os.sched_getaffinity(0))
+            share = max(1, len(cpus)//world)
+            os.sched_setaffinity(0, set(cpus[rank*share:(rank + 1)*share] or cpus))
+            affinity = sorted(os.sched_getaffinity(0))
+        except OSError:
+            pass
     pkg = importlib.import_module("signalsmith-stretch_amd")
     S = args.streams
     n_in = int(args.seconds*sr_cfg)
     n_out = int(round(n_in*args.stretch))
-    batch = pkg.StretchBatch(S, C, preset=preset, sample_rate=sr_cfg, device=local_rank, seed=rank, half_state=args.half_state)
+    batch = pkg.StretchBatch(S, C, preset=preset, sample_rate=sr_cfg, device=dev_index, seed=stream_rank, half_state=args.half_state)
     if setup:
         setup(batch)
     if per_stream:  # config 5: per-stream random stretch 0.75-1.5x and +-12 st
         import numpy as np
         g = np.random.Generator(np.random.PCG64(5))
-        stretches = g.uniform(0.75, 1.5, 8192)[rank*S:(rank + 1)*S]
-        semis = g.uniform(-12, 12, 8192)[rank*S:(rank + 1)*S]
+        stretches = g.uniform(0.75, 1.5, 8192)[stream_rank*S:(stream_rank + 1)*S]
+        semis = g.uniform(-12, 12, 8192)[stream_rank*S:(stream_rank + 1)*S]
         for i in range(S):
             batch.setTransposeSemitones(float(semis[i]), 0.0, stream=i)
         n_out = [int(round(n_in*float(v))) for v in stretches]
-    x = make_inputs(torch, S, C, n_in, device, first_stream=rank*S, sr=sr_cfg)
+    x = make_inputs(torch, S, C, n_in, device, first_stream=stream_rank*S, sr=sr_cfg)
     n_out_max = max(n_out) if per_stream else n_out
     y = torch.empty((S, C, n_out_max), dtype=torch.float32, device=device)
     torch.cuda.synchronize()
@@ -210,27 +269,43 @@ def main():
     # the recurrence kernel is timed IN PLACE over the timed region: a HIP-event pair on the stream it is launched on
     # (the engine's chain stream), the other streams keep overlapping it (two event records per 64-hop tile)
     batch.enableProfiling(0 if os.environ.get("SMST_BENCH_NO_LIVE") else 2)
+    # per-step completion stamps: a side stream waits (by event) for the batch's stream after every call and records a timing
+    # event -- the steps stay pipelined (no host synchronisation between them), the stamps give each step's device-side period
+    side = torch.cuda.Stream(device=device)
+    stamps = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    pkg_lib = batch.lib
+    import ctypes
+
+    def stamp(i):
+        pkg_lib.smst_batch_signal_stream(batch.h, ctypes.c_void_p(side.cuda_stream))
+        stamps[i].record(side)
+    stamp(0)
     t0 = time.perf_counter()
     # inputs are complete (synchronised above) and the outputs are only looked at after batch.synchronize(): no per-call
     # ordering against torch's stream, so the host scheduling of step n+1 overlaps the kernels of step n
-    for _ in range(args.steps):
+    for i in range(args.steps):
         batch.process(x, n_out, out=y, ordered=False)
+        stamp(i + 1)
     batch.synchronize()
     torch.cuda.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
     live_ms, live_launches = batch.takeTimings()
     batch.enableProfiling(0)
+    step_ms = sorted(stamps[i].elapsed_time(stamps[i + 1]) for i in range(args.steps))
     if use_dist:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=red_device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     ok = bool(torch.isfinite(y).all().item()) and float(y.abs().max().item()) > 0.01
+    if args.dump_output:
+        import numpy as np
+        np.save("%s.rank%d.npy" % (args.dump_output, stream_rank), y[:4].cpu().numpy())
 
     total_out = sum(n_out) if per_stream else S*n_out
     samples_local = C*(S*n_in + total_out)
     if use_dist:  # per-stream stretch factors differ between ranks (config 5): add up what every rank really processed
-        tot = torch.tensor([samples_local], dtype=torch.float64, device=device)
+        tot = torch.tensor([samples_local], dtype=torch.float64, device=red_device)
         dist.all_reduce(tot, op=dist.ReduceOp.SUM)
         samples_per_step = int(tot.item())
     else:
@@ -239,16 +314,17 @@ def main():
     B, I, M = batch.blockSamples(), batch.intervalSamples(), batch.bands()
     hops_per_stream = -(-(total_out//S)//I)
     bytes_per_chop = algorithmic_bytes_per_channel_hop(B, I, M, args.stretch)
+    own = own_algorithmic_bytes(B, I, M, args.stretch)
+    chops_per_step = S*C*hops_per_stream
 
     roofline = None
     if rank == 0:
-        # per-kernel-class device time: HIP events recorded on the engine's own stream around every launch
+        # per-kernel-class device time, each class ALONE on the GPU: one extra, serialised call with HIP events around every launch
         if args.no_serial_pass:
-            tiles = live_launches.get("chain_live", 0)/max(args.steps, 1)
             ms = {k: 0.0 for k in ("analyse", "feed", "predict", "chain", "synth", "emit", "other")}
             ms["chain"] = live_ms.get("chain_live", 0.0)/max(args.steps, 1)
             launches = {k: 0 for k in ("analyse", "predict", "chain", "synth", "emit")}
-            launches["chain"] = int(tiles)
+            launches["chain"] = int(live_launches.get("chain_live", 0)/max(args.steps, 1))
         else:
             batch.enableProfiling(1)
             batch.process(x, n_out, out=y, ordered=False)
@@ -257,30 +333,50 @@ def main():
             batch.enableProfiling(0)
             ms.pop("chain_live", None)
             launches.pop("chain_live", None)
-        launch_count = {"analyse": launches["analyse"], "predict": launches["predict"], "chain": launches["chain"],
-                        "synth": launches["synth"], "emit": launches["emit"]}
-        dom = max(launch_count, key=lambda k: ms[k])
-        avg_ms_serial = ms[dom]/max(launch_count[dom], 1) or float("nan")
-        avg_ms = avg_ms_serial
-        if dom == "chain" and live_launches.get("chain_live", 0) > 0:  # in place, over the timed steps (agrees with rocprofv3)
-            avg_ms = live_ms["chain_live"]/live_launches["chain_live"]
-        chops_per_launch = S*C*hops_per_stream/max(launch_count[dom], 1)
-        achieved = bytes_per_chop*chops_per_launch/(avg_ms*1e-3)/1e9 if avg_ms == avg_ms and avg_ms > 0 else None
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic_latest.json")
-        if os.path.exists(tpath):
-            try:
-                traffic = json.load(open(tpath)).get({"analyse": "kAnalyseFast", "predict": "kPredictB", "chain": "kVocoder" if C <= 2 else "kChain",
-                                                      "synth": "kSynthFast", "emit": "kEmit"}[dom])
-            except Exception:
-                traffic = None
-        names = {"analyse": "kAnalyseFast", "predict": "kPredictB", "chain": "kVocoder" if C <= 2 else "kChain", "synth": "kSynthFast", "emit": "kEmit"}
-        roofline = dict(bound="hbm", kernel=names[dom],
-                        achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=(achieved/HBM_PEAK_GBS if achieved else None), traffic=traffic,
-                        avg_launch_ms=avg_ms, avg_launch_ms_alone=avg_ms_serial, launches_per_step=launch_count[dom],
-                        algorithmic_bytes_per_channel_hop=bytes_per_chop, channel_hops_per_launch=chops_per_launch,
-                        kernel_ms_per_step_alone={k: round(v, 3) for k, v in ms.items()},
-                        pipeline_frac=(bytes_per_chop*S*C*hops_per_stream/(elapsed/args.steps))/1e9/HBM_PEAK_GBS)
+        names = {"analyse": "kAnalyseFast" if M in (3072, 5120, 2560, 6144) else "kAnalyse", "predict": "kPredictA/B",
+                 "chain": "kVocoder" if C <= 2 else "kVocoderN", "synth": "kSynthFast" if M in (3072, 5120, 2560, 6144) else "kSynth", "emit": "kEmit"}
+        launch_count = {k: launches[k] for k in ("analyse", "predict", "chain", "synth", "emit")}
+        dom = max(launch_count, key=lambda k: ms[k])  # the class with the largest stand-alone time per step
+        avg_ms_alone = ms[dom]/max(launch_count[dom], 1) or float("nan")
+        avg_ms_in_place = avg_ms_alone
+        if dom == "chain" and live_launches.get("chain_live", 0) > 0:  # in place, over the timed steps (agrees with rocprofv3 --stats)
+            avg_ms_in_place = live_ms["chain_live"]/live_launches["chain_live"]
+        chops_per_launch = chops_per_step/max(launch_count[dom], 1)
+        own_key = {"analyse": "analyse", "chain": "chain", "synth": "synth+emit", "emit": "synth+emit", "predict": "chain"}[dom]
+
+        def gbs(nbytes, millis):
+            return nbytes/(millis*1e-3)/1e9 if millis == millis and millis > 0 else None
+        kernel_achieved = gbs(own[own_key]*chops_per_launch, avg_ms_in_place)
+        whole_bytes_on_kernel = gbs(bytes_per_chop*chops_per_launch, avg_ms_in_place)
+        step_mean_ms = elapsed/args.steps*1e3
+        pipeline_achieved = gbs(bytes_per_chop*chops_per_step, step_mean_ms)
+        sha = library_sha16()
+        traffic, traffic_source = measured_traffic(sha)
+        per_class = {}
+        rows = [("analyse", names["analyse"], ms["analyse"], launch_count["analyse"]), ("chain", names["chain"], ms["chain"], launch_count["chain"]),
+                ("synth+emit", names["synth"] + " + kEmit", ms["synth"] + ms["emit"], launch_count["synth"])]
+        for key, label, alone, count in rows:
+            if count:
+                per_class[label] = dict(ms_per_step_alone=round(alone, 3), launches_per_step=count, own_algorithmic_bytes_per_channel_hop=own[key],
+                                        own_frac_alone=gbs(own[key]*chops_per_step, alone)/HBM_PEAK_GBS)
+        roofline = dict(
+            bound="hbm", scope="whole hot path: every kernel of one process() step, pipelined (the figure north_star's '% of HBM peak' asks for)",
+            achieved=pipeline_achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=(pipeline_achieved/HBM_PEAK_GBS if pipeline_achieved else None),
+            traffic=(traffic.get("bytes_per_step") if traffic else None), traffic_source=traffic_source,
+            algorithmic_bytes_per_channel_hop=bytes_per_chop, channel_hops_per_step=chops_per_step,
+            step_ms=dict(mean_wall=step_mean_ms, median=step_ms[len(step_ms)//2], min=step_ms[0], max=step_ms[-1], n=len(step_ms),
+                         note="mean_wall = host clock around the K steps / K (the figure `value` uses); median/min/max = device-side period of each step (event stamps)"),
+            pipeline_frac=(pipeline_achieved/HBM_PEAK_GBS if pipeline_achieved else None),
+            dominant_kernel=dict(
+                kernel=names[dom], chosen_by="largest stand-alone time per step", avg_launch_ms=avg_ms_in_place, avg_launch_ms_alone=avg_ms_alone,
+                launches_per_step=launch_count[dom], channel_hops_per_launch=chops_per_launch,
+                own_algorithmic_bytes_per_channel_hop=own[own_key], kernel_achieved=kernel_achieved,
+                kernel_frac=(kernel_achieved/HBM_PEAK_GBS if kernel_achieved else None),
+                whole_path_bytes_over_this_kernel_frac=(whole_bytes_on_kernel/HBM_PEAK_GBS if whole_bytes_on_kernel else None),
+                note="kernel_frac prices this kernel's launch time with ITS OWN share of the algorithmic bytes; the last field is the round-1/2 "
+                     "figure (whole-path bytes over one kernel's time), kept for continuity -- it is not a statement about this kernel",
+                traffic=(traffic.get("kernels", {}).get(names[dom]) if traffic else None)),
+            kernels=per_class, kernel_ms_per_step_alone={k: round(v, 3) for k, v in ms.items()}, library_sha16=sha)
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
@@ -288,6 +384,9 @@ def main():
         except Exception as e:  # the baseline is reported, never required
             cpu = dict(error=str(e))
     if rank == 0:
+        sharding = "streams/%d, no collective" % world
+        if args.oversubscribe:
+            sharding = "OVERSUBSCRIBED: %d ranks on ONE device (cuda:0), %d streams each, no collective on the data path; %s for barrier + all_reduce" % (world, S, args.dist_backend)
         line = {
             "metric": "Msamples/sec (in+out) at 48kHz stereo presetDefault",
             "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -298,7 +397,7 @@ def main():
                        if args.config == "2" else "BASELINE config %s (not the headline): %d streams x %d ch per GPU, %d Hz, preset %s, %.0f s per step"
                        % (args.config, S, C, sr_cfg, preset, args.seconds),
                        "streams_total": world*S, "channels": C, "block": B, "interval": I, "fft": batch.fftSamples(),
-                       "hops_per_stream_per_step": hops_per_stream, "sharding": "streams/%d, no collective" % world,
+                       "hops_per_stream_per_step": hops_per_stream, "sharding": sharding,
                        "rank0_cpu_affinity": ("%d CPUs from %d" % (len(affinity), affinity[0])) if affinity else None},
             "realtime_x": world*S*args.seconds*args.steps/elapsed,
             "channels": C,
