@@ -182,6 +182,9 @@ long long smst_batch_debug_allocation_events(const smst_batch *b);
 /* output map of the stream's newest hop (2*bands floats: inputBin, freqGrad per bin; signalsmith-stretch.h:587-590,
  * :882-917).  Returns 1 if that hop had a frequency map, 0 if not (dst untouched), negative on error. */
 int smst_batch_debug_get_map(smst_batch *b, int stream, float *dst);
+/* the kernels' packed complex helpers (csrc/smst_complex.h, gfx950 inline assembly) evaluated on the device: in = n x
+ * (a.re, a.im, b.re, b.im, c.re, c.im, fraction), out = n x (a*b, a*conj(b), a*b + c, a + (b - a)*fraction) as 8 floats. */
+int smst_debug_complex_selftest(int device, const float *in, float *out, int n);
 
 #ifdef __cplusplus
 }

@@ -15,7 +15,9 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIBRARY_PATH = os.path.join(_HERE, "libsmst_hip.so")
+# SMST_LIBRARY: measurement hook -- another BUILD of the same library (an A/B variant, an instrumented trace build under
+# variants/), never another implementation; unset in every product use
+LIBRARY_PATH = os.environ.get("SMST_LIBRARY") or os.path.join(_HERE, "libsmst_hip.so")
 CSRC_DIR = os.path.join(_HERE, "csrc")
 
 MEM_HOST, MEM_DEVICE = 0, 1
@@ -95,6 +97,7 @@ _SIGNATURES = {
     "smst_batch_debug_allocation_events": (_ll, [C.c_void_p]),
     "smst_batch_wait_for_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "smst_batch_signal_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "smst_debug_complex_selftest": (C.c_int, [C.c_int, _fp, _fp, C.c_int]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 
@@ -108,6 +111,8 @@ class StretchError(RuntimeError):
 def bind(cdll):
     """Attach the include/smst.h prototypes to a loaded library object."""
     for name, (res, args) in _SIGNATURES.items():
+        if name.startswith("smst_debug_") and os.environ.get("SMST_LIBRARY") and not hasattr(cdll, name):
+            continue  # an A/B build of an older revision may lack the newest test hook
         f = getattr(cdll, name)
         f.restype = res
         f.argtypes = args
@@ -160,6 +165,15 @@ def _is_torch(x):
 def _int_array(values, n):
     a = np.ascontiguousarray(np.broadcast_to(np.asarray(values, dtype=np.int32), (n,)))
     return a, a.ctypes.data_as(_ip)
+
+
+def complex_selftest(values, device=0, lib=None):
+    """values: [n, 7] float32 (a, b, c complex + a fraction) -> [n, 8] (a*b, a*conj(b), a*b + c, lerp) from the device helpers."""
+    lib = lib if lib is not None else load_library()
+    v = np.ascontiguousarray(values, np.float32).reshape(-1, 7)
+    out = np.zeros((v.shape[0], 8), np.float32)
+    _check(lib, lib.smst_debug_complex_selftest(device, v.ctypes.data_as(_fp), out.ctypes.data_as(_fp), v.shape[0]))
+    return out
 
 
 class StretchBatch:

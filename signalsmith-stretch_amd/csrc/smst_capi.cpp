@@ -145,6 +145,22 @@ int smst_batch_debug_set_carry(smst_batch *b, int stream, const float *sums, con
 long long smst_batch_debug_allocation_events(const smst_batch *b) { if (!b || !b->engine) return fail("null batch"); return (long long)b->engine->allocationEvents() + b->stagingAllocs; }
 int smst_batch_wait_for_stream(smst_batch *b, void *hipStream) { BATCH_CALL(b->engine->waitForStream(static_cast<hipStream_t>(hipStream))) }
 int smst_batch_signal_stream(smst_batch *b, void *hipStream) { BATCH_CALL(b->engine->signalStream(static_cast<hipStream_t>(hipStream))) }
+int smst_debug_complex_selftest(int device, const float *in, float *out, int n) {
+	SMST_TRY
+	if (n < 1 || !in || !out) throw smst::Error("complex self-test: bad arguments");
+	if (hipSetDevice(device) != hipSuccess) throw smst::Error("hipSetDevice failed", true);
+	float *dIn = nullptr, *dOut = nullptr;
+	if (hipMalloc(reinterpret_cast<void **>(&dIn), (size_t)n*7*sizeof(float)) != hipSuccess) throw smst::Error("hipMalloc failed", true);
+	if (hipMalloc(reinterpret_cast<void **>(&dOut), (size_t)n*8*sizeof(float)) != hipSuccess) { hipFree(dIn); throw smst::Error("hipMalloc failed", true); }
+	hipError_t e = hipMemcpy(dIn, in, (size_t)n*7*sizeof(float), hipMemcpyHostToDevice);
+	if (e == hipSuccess) { smst::launchComplexSelfTest(dIn, dOut, n, nullptr); e = hipGetLastError(); }
+	if (e == hipSuccess) e = hipMemcpy(out, dOut, (size_t)n*8*sizeof(float), hipMemcpyDeviceToHost);
+	hipFree(dIn);
+	hipFree(dOut);
+	if (e != hipSuccess) throw smst::Error(std::string("complex self-test: ") + hipGetErrorString(e), true);
+	return 0;
+	SMST_CATCH
+}
 int smst_batch_debug_get_map(smst_batch *b, int stream, float *dst) {
 	if (!b || !b->engine) return fail("null batch");
 	SMST_TRY

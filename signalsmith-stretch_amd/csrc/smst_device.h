@@ -88,6 +88,7 @@ void launchPassThrough(const DevBatch &d, const IoArgs &io, const int *passFlags
 void launchResetStreams(const DevBatch &d, const int *flags, int allBits, const float *seedWp, hipStream_t st); // flags: per-stream bit masks or null = allBits for every stream
 void launchSeekHistory(const DevBatch &d, const IoArgs &io, const int *seekFlags, hipStream_t st);
 void launchAddPreRoll(const DevBatch &d, const float *preRoll, int length, const int *offsets, hipStream_t st);
+void launchComplexSelfTest(const float *in, float *out, int n, hipStream_t st); // smst_complex.h against its documented formulas (test hook)
 void launchFlushTail(const DevBatch &d, const IoArgs &io, const int *tailOffset, const int *outOffset, hipStream_t st);
 
 } // namespace smst

@@ -12,18 +12,20 @@
 //     over (stream, hop, channel).
 #include <hip/hip_runtime.h>
 #include "smst_device.h"
+#include <smst_complex.h> // angle brackets: tests/emu shadows this header for the CPU stand-in
 
 namespace smst {
 
 // ------------------------------------------------------------------------------------------------------
 // small helpers
 // ------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ float2 cmul(float2 a, float2 b) { // a*b          (reference _impl::mul<false>, :17-26)
-	return make_float2(a.x*b.x - a.y*b.y, a.x*b.y + a.y*b.x);
-}
-__device__ __forceinline__ float2 cmulc(float2 a, float2 b) { // a*conj(b)   (reference _impl::mul<true>)
-	return make_float2(b.x*a.x + b.y*a.y, b.x*a.y - b.y*a.x);
-}
+// cmul(a, b) = a*b, cmulc(a, b) = a*conj(b), cfma(a, b, c) = a*b + c, clerp(lo, hi, fr): smst_complex.h (two packed-f32 VALU
+// instructions each; reference _impl::mul<false/true>, :17-26)
+// The FFT kernels keep the plain C++ products: they are bound by their memory operations, not by VALU issue, and the opaque
+// assembly statements cost them the compiler's load / compute interleaving (kSynthFast 2.93 -> 3.42 ms per step with the packed
+// helpers, same box)
+__device__ __forceinline__ float2 cmulPlain(float2 a, float2 b) { return make_float2(a.x*b.x - a.y*b.y, a.x*b.y + a.y*b.x); }
+__device__ __forceinline__ float2 cmulcPlain(float2 a, float2 b) { return make_float2(b.x*a.x + b.y*a.y, b.x*a.y - b.y*a.x); }
 // |a|^2 with three separate roundings, never a fused multiply-add: the compiler otherwise contracts this differently from
 // one call site to the next (mul+fma here, packed mul + add there), and the SAME energy is computed at several sites
 // (carried Prediction.energy in kCarryFeed vs the producers' on-the-fly value) that must agree bit for bit
@@ -144,9 +146,9 @@ __device__ float2 *fftLds(float2 *src, float2 *dst, const FftPlan &plan, const f
 				float2 jb = (SIGN < 0) ? mulNegI(bme) : mulI(bme);
 				const int ti = p*twScale;
 				out[0] = cadd(apc, bpe);
-				out[s] = cmul(cadd(amc, jb), twiddle<SIGN>(tw, ti));
-				out[2*s] = cmul(csub(apc, bpe), twiddle<SIGN>(tw, 2*ti));
-				out[3*s] = cmul(csub(amc, jb), twiddle<SIGN>(tw, 3*ti));
+				out[s] = cmulPlain(cadd(amc, jb), twiddle<SIGN>(tw, ti));
+				out[2*s] = cmulPlain(csub(apc, bpe), twiddle<SIGN>(tw, 2*ti));
+				out[3*s] = cmulPlain(csub(amc, jb), twiddle<SIGN>(tw, 3*ti));
 			}
 			shift += 2;
 		} else if (r == 2) {
@@ -158,7 +160,7 @@ __device__ float2 *fftLds(float2 *src, float2 *dst, const FftPlan &plan, const f
 				float2 *out = dst + q0 + ((2*p) << shift);
 				float2 a = in[0], b = in[inStride];
 				out[0] = cadd(a, b);
-				out[s] = cmul(csub(a, b), twiddle<SIGN>(tw, p*twScale));
+				out[s] = cmulPlain(csub(a, b), twiddle<SIGN>(tw, p*twScale));
 			}
 			shift += 1;
 		} else if (r == 3) { // last pass: m == 1, p == 0, all twiddles are 1
@@ -315,7 +317,7 @@ __device__ __forceinline__ void fftFast(float2 *lds, const float4 *__restrict__ 
 				const float4 pr = wA[(n - 1) >> 1];
 				float2 w = ((n - 1) & 1) ? make_float2(pr.z, pr.w) : make_float2(pr.x, pr.y);
 				if (SIGN > 0) w.y = -w.y;
-				val = cmul(val, w);
+				val = cmulPlain(val, w);
 			}
 			lds[17*t + n] = val; // padded index of 16 t + n
 		}
@@ -341,7 +343,7 @@ __device__ __forceinline__ void fftFast(float2 *lds, const float4 *__restrict__ 
 				const float4 pr = wB[(n - 1) >> 1];
 				float2 w = ((n - 1) & 1) ? make_float2(pr.z, pr.w) : make_float2(pr.x, pr.y);
 				if (SIGN > 0) w.y = -w.y;
-				val = cmul(val, w);
+				val = cmulPlain(val, w);
 			}
 			lds[q0 + 256*p + 16*n] = val;
 		}
@@ -456,7 +458,7 @@ __global__ __launch_bounds__(16*R3 > 256 ? 16*R3 : 256) void kSynthFast(DevBatch
 			return synTab[m];
 		},
 		[&](int m, float2 u, float4 r) {
-			const float2 v = cmulc(u, make_float2(r.x, r.y)); // * e^{+i pi m / N}
+			const float2 v = cmulcPlain(u, make_float2(r.x, r.y)); // * e^{+i pi m / N}
 			if (m < B - halfB) frame[m + halfB] = (2*v.x)*r.z;
 			if (m >= H - halfB) frame[m - H + halfB] = (2*v.y)*r.w;
 		});
@@ -530,7 +532,7 @@ __global__ __launch_bounds__(256) void kAnalyse(DevBatch d, IoArgs io, int sBase
 			float v = (src >= 0) ? x[src] : hist[d.histLen + src];
 			im = v*win[i];
 		}
-		bufA[m] = cmul(make_float2(re, im), d.halfTw[m]);
+		bufA[m] = cmulPlain(make_float2(re, im), d.halfTw[m]);
 	}
 	__syncthreads();
 	float2 *res = fftLds<-1>(bufA, bufB, d.plan, d.twH);
@@ -1363,7 +1365,7 @@ __device__ __forceinline__ BandPair pairAt(const float2 *row, int idx, int M) {
 }
 __device__ __forceinline__ float2 lerpBand(const float2 *row, LerpIndex li, int M) { // getFractional, :553-557
 	const BandPair p = pairAt(row, li.lo, M);
-	return make_float2(p.lo.x + (p.hi.x - p.lo.x)*li.fr, p.lo.y + (p.hi.y - p.lo.y)*li.fr);
+	return clerp(p.lo, p.hi, li.fr);
 }
 __device__ __forceinline__ float2 rotAt(const float2 *rot, int M, int idx, bool rotate) { // hop rotation of bin idx, 1 outside / when off
 	const int ci = min(max(idx, 0), M - 1);
@@ -1406,7 +1408,8 @@ __global__ __launch_bounds__(256) void kPredictA(DevBatch d, int sBase, int hopB
 // the lock  makeOutput(out_m * P_c conj(P_m), P_c, sqrt(E_c))  itself (:791-800).  STEREO: the one locked channel's
 // makeOutput is folded into the record -- |out_m|^2 = E_m by construction (:602), so the norm of the lock's phase is
 // E_m |P_o conj(P_m)|^2 and the producer can scale the twist itself:
-//   9..11  P_m, sqrt(E_m)                     (the maximum channel's own makeOutput)
+//   9..11  Fb = P_m * sqrt(E_m) / sqrt(|P_m|^2 + 1e-15), sqrt(E_m)   (the maximum channel's own makeOutput: Fb is what it returns when
+//          the prediction is below the noise floor, :598-601 -- formed here, off the serial path, from the same operations)
 //   12,13  T' = P_o conj(P_m) * sqrt(E_o) / sqrt(E_m |P_o conj(P_m)|^2)        (0 if that norm is below the noise floor)
 //   14,15  F  = P_o * sqrt(E_o) / sqrt(|P_o|^2 + 1e-15)  in that weak case, else 0   (the fallback to the input, :598-601)
 // and the recurrence wave computes  out_o = out_m T' + F : one complex multiply-add instead of two multiplies, a norm, a
@@ -1421,7 +1424,9 @@ __device__ __forceinline__ void recordChannelFields(float (&f)[NFLOATS], const f
 		const float nT = eM*cnorm(T);
 		const bool weak = nT <= 1e-15f;
 		const float g = __builtin_amdgcn_sqrtf(eO)*__builtin_amdgcn_rsqf(weak ? cnorm(Po) + 1e-15f : nT);
-		f[9] = Pm.x; f[10] = Pm.y; f[11] = __builtin_amdgcn_sqrtf(eM);
+		const float sM = __builtin_amdgcn_sqrtf(eM);
+		const float2 Fb = cscale(Pm, sM*__builtin_amdgcn_rsqf(cnorm(Pm) + 1e-15f));
+		f[9] = Fb.x; f[10] = Fb.y; f[11] = sM;
 		f[12] = weak ? 0.0f : T.x*g; f[13] = weak ? 0.0f : T.y*g;
 		f[14] = weak ? Po.x*g : 0.0f; f[15] = weak ? Po.y*g : 0.0f;
 	} else {
@@ -1432,7 +1437,7 @@ __device__ __forceinline__ void recordChannelFields(float (&f)[NFLOATS], const f
 // stereo: the locked channel's output from the maximum channel's (see recordChannelFields)
 template <int NFLOATS>
 __device__ __forceinline__ float2 lockedOutput(float2 om, const float (&f)[NFLOATS]) {
-	return cadd(cmul(om, make_float2(f[12], f[13])), make_float2(f[14], f[15]));
+	return cfma(om, make_float2(f[12], f[13]), make_float2(f[14], f[15]));
 }
 
 // storeMap: mapAt has just computed the entry (kFeedScanA) and it goes to the map row; otherwise mapAt reads that row.
@@ -1474,6 +1479,16 @@ __device__ __forceinline__ void feedPredictionRows(const DevBatch &d, const HopD
 			}
 		}
 	}
+}
+
+// previous-hop part of the prediction,  prevOut[b+1]*Cc + prevOut[b+L]*Dc : THE definition every recurrence kernel uses (first
+// operation of its accumulation), and what FOLD0 records carry in Cc's place
+__device__ __forceinline__ float2 prevHopTerms(float2 p1, float2 Cc, float2 pL, float2 Dc) { return cfma(pL, Dc, cmul(p1, Cc)); }
+__device__ __forceinline__ void foldCarriedTaps(const CarriedOutput &prev, int mc, int b, int M, int L, float2 &Cc, float2 &Dc) {
+	// taps beyond the last bin multiply coefficients that are already zero (:765,:776): any finite value does
+	const float2 p1 = prev[(size_t)mc*M + min(b + 1, M - 1)], pL = prev[(size_t)mc*M + min(b + L, M - 1)];
+	Cc = prevHopTerms(p1, Cc, pL, Dc);
+	Dc = make_float2(0.f, 0.f);
 }
 
 // One record of the bin recurrence = everything hop k needs at bin b, with the maximum-energy channel m(b)
@@ -1534,7 +1549,7 @@ __device__ __forceinline__ float2 twistAt(const RecordSource<CH, PLAIN> &src, in
 		const float2 one = make_float2(1.f, 0.f);
 		const float2 qLo = cmul(pvp.lo, (rotate && loIn) ? rp.lo : one);
 		const float2 qHi = cmul(pvp.hi, (rotate && hiIn) ? rp.hi : one);
-		Q = make_float2(qLo.x + (qHi.x - qLo.x)*li.fr, qLo.y + (qHi.y - qLo.y)*li.fr);
+		Q = clerp(qLo, qHi, li.fr);
 	}
 	const float4 pe = src.PE(mc, bc);
 	const float2 Px = make_float2(pe.x, pe.y);
@@ -1556,7 +1571,11 @@ __device__ __forceinline__ float2 twistAt(const RecordSource<CH, PLAIN> &src, in
 // selected afterwards, so no load address depends on loaded data (one memory round trip per record instead of two).
 // ROT_LDS: the hop-rotation table is read from `rotLds` (a copy in LDS) instead of d.rot -- three of a mapped record's 18
 // gathers per twist pair go to the table, and the texture-address unit is what bounds the gathering producers.
-template <int CH, bool PLAIN, bool LOCK, bool SPEC, int NFLOATS, bool ROT_LDS = false>
+// FOLD0 (kVocoder): hop 0 of a tile takes its previous-hop taps from the CARRIED Band.output, which is known before the kernel
+// starts -- so its record carries  Cc := prevOut[b+1]*Cc + prevOut[b+L]*Dc  (formed with the very helper calls, in the very
+// order, the recurrence uses: bit-identical) and Dc := 0, and the recurrence wave's lane 0 holds the constant taps (1, 0) and
+// (0, 0).  Nothing on the serial path reads the carried state any more (it was two LDS reads a step plus a staging window).
+template <int CH, bool PLAIN, bool LOCK, bool SPEC, int NFLOATS, bool ROT_LDS = false, bool FOLD0 = false>
 __device__ __forceinline__ void computeRecord(const DevBatch &d, const HopDesc &hd, const HopDesc &hp, int s, int sg, int k, int b, float (&f)[NFLOATS],
                                               const float2 *rotLds = nullptr) {
 	const float2 *rot;
@@ -1630,6 +1649,9 @@ __device__ __forceinline__ void computeRecord(const DevBatch &d, const HopDesc &
 	} else {
 		twists(mc, Pm, A, B, Cc, Dc);
 	}
+	if constexpr (FOLD0) {
+		if (k == 0) foldCarriedTaps(carriedOutput(d, sg), mc, b, M, L, Cc, Dc);
+	}
 	f[0] = A.x; f[1] = A.y; f[2] = B.x; f[3] = B.y; f[4] = Cc.x; f[5] = Cc.y; f[6] = Dc.x; f[7] = Dc.y;
 	f[8] = __int_as_float(mc);
 	static_assert(!LOCK, "the separate lock-twist fields are gone: stereo records carry the scaled twist (recordChannelFields)");
@@ -1696,6 +1718,14 @@ __device__ __forceinline__ float2 makeOutput(float2 phase, float2 input, float s
 	const float2 ph = weak ? input : phase;
 	const float g = sqrtEnergy*__builtin_amdgcn_rsqf(weak ? nIn : n);
 	return cscale(ph, g);
+}
+
+// stereo: the same with the fallback value precomputed by the record producer (recordChannelFields): two selects instead of
+// a norm, an add, three selects on the serial path
+__device__ __forceinline__ float2 makeOutputFb(float2 phase, float2 fallback, float sqrtEnergy) {
+	const float n = cnorm(phase);
+	const float2 o = cscale(phase, sqrtEnergy*__builtin_amdgcn_rsqf(n)); // n == 0: inf / nan, discarded by the select
+	return (n <= 1e-15f) ? fallback : o;
 }
 
 template <int CH>
@@ -1785,11 +1815,10 @@ __global__ __launch_bounds__(64) void kChain(DevBatch d, int sBase, int hopBase)
 				const int aL = (k == 0) ? stageBase + mc*128 + ((b + L) & 127) : (ringRow + ((b + L) & Rm))*64 + k - 1;
 				const float2 p1 = lds[a1];
 				const float2 pL = lds[aL];
-				float2 phi = cmul(oL, make_float2(f[2], f[3]));
-				phi = cadd(phi, cmul(p1, make_float2(f[4], f[5])));
-				phi = cadd(phi, cmul(pL, make_float2(f[6], f[7])));
-				phi = cadd(phi, cmul(o1, make_float2(f[0], f[1])));
-				const float2 om = makeOutput(phi, pm, sm); // :788
+				float2 phi = prevHopTerms(p1, make_float2(f[4], f[5]), pL, make_float2(f[6], f[7])); // previous hop's part first (what FOLD0 records pre-compute)
+				phi = cfma(oL, make_float2(f[2], f[3]), phi);
+				phi = cfma(o1, make_float2(f[0], f[1]), phi); // the newest operand last: two dependent instructions behind it
+				const float2 om = (CH == 2) ? makeOutputFb(phi, pm, sm) : makeOutput(phi, pm, sm); // :788 (stereo records carry the fallback output in pm's place)
 				const float2 olock = (CH == 2) ? lockedOutput(om, f) : om; // stereo: see recordChannelFields
 #pragma unroll
 				for (int c = 0; c < CH; ++c) {
@@ -1874,7 +1903,7 @@ __device__ __forceinline__ float2 loadEnergyPair(const DevBatch &d, const float 
 
 template <int CH, int L, int NB, int NP>
 __device__ __forceinline__ void vocoderProduceStaged(const DevBatch &d, int s, int sg, int nh, int pIndex, int k, int totalBlocks,
-                                                     float4 *recs, volatile int *sync, const HopDesc *hopsLds, float2 *sbuf) {
+                                                     float4 *recs, volatile int *sync, const HopDesc *hopsLds, float2 *sbuf, const CarriedOutput &stOut) {
 	using G = StageGeom<CH, L>;
 	constexpr int NF = 9 + 3*CH, NCH = (NF + 3)/4, BS = 8, lag = L + 1;
 	static_assert(NP%8 == 0, "one producer wave per group of 8 rows");
@@ -1979,14 +2008,31 @@ __device__ __forceinline__ void vocoderProduceStaged(const DevBatch &d, int s, i
 	const float tf = hd.timeFactor;
 	const float2 *mine = sbuf + (r + 1)*G::ROWLEN, *above = sbuf + r*G::ROWLEN;
 	constexpr int NPB = NP/8;
+	// Hop 0's previous-hop taps are the carried Band.output (FOLD0, see computeRecord): the wave that owns row 0 fetches them with
+	// its windows, one block ahead (lanes 0..7 = row 0, steps 0..7; the other lanes load in-range values they never use)
+	float2 car1[CH], carL[CH], carNext1[CH], carNextL[CH];
+#pragma unroll
+	for (int c = 0; c < CH; ++c) car1[c] = carL[c] = carNext1[c] = carNextL[c] = make_float2(0.f, 0.f);
+	auto issueCarried = [&](int nn) {
+		const int b = BS*nn + st; // row 0: no skew
+#pragma unroll
+		for (int c = 0; c < CH; ++c) {
+			carNext1[c] = stOut[(size_t)c*M + min(b + 1, M - 1)];
+			carNextL[c] = stOut[(size_t)c*M + min(b + L, M - 1)];
+		}
+	};
 	int n = pIndex >> 3;
-	if (n < totalBlocks) issue(n);
+	if (n < totalBlocks) { issue(n); if (it == 0) issueCarried(n); }
 	for (; n < totalBlocks; n += NPB) {
 		park(n);
+		if (it == 0) {
+#pragma unroll
+			for (int c = 0; c < CH; ++c) { car1[c] = carNext1[c]; carL[c] = carNextL[c]; }
+		}
 		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 		__builtin_amdgcn_wave_barrier();
 		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-		if (n + NPB < totalBlocks) issue(n + NPB);
+		if (n + NPB < totalBlocks) { issue(n + NPB); if (it == 0) issueCarried(n + NPB); }
 		const int slot = n%NB;
 		// (waiting only before the store, as the gathering producers do, was slower here: 8.2 -> 8.5 ms per step -- records
 		// computed early take issue slots from the recurrence wave exactly when it is not waiting for them)
@@ -2001,7 +2047,7 @@ __device__ __forceinline__ void vocoderProduceStaged(const DevBatch &d, int s, i
 			auto IN = [&](int c, int x) { return mine[c*2*G::PIN + (x - b0 + 2*L)]; };
 			auto lerpIN = [&](int c, LerpIndex li) {
 				const float2 low = IN(c, li.lo), high = IN(c, li.lo + 1);
-				return make_float2(low.x + (high.x - low.x)*li.fr, low.y + (high.y - low.y)*li.fr);
+				return clerp(low, high, li.fr);
 			};
 			float2 p[CH];
 			float e[CH];
@@ -2039,6 +2085,13 @@ __device__ __forceinline__ void vocoderProduceStaged(const DevBatch &d, int s, i
 			if (!(b >= L)) B = zero;
 			if (!(b < M - 1)) Cc = zero;
 			if (!(b < M - L)) Dc = zero;
+			if (it == 0) { // FOLD0: row 0's record carries the previous-hop part ready-made (wave-uniform branch, lane select inside)
+				float2 c1 = car1[0], cL = carL[0];
+#pragma unroll
+				for (int c = 1; c < CH; ++c) if (c == mc) { c1 = car1[c]; cL = carL[c]; }
+				const float2 K = prevHopTerms(c1, Cc, cL, Dc);
+				if (r == 0) { Cc = K; Dc = zero; }
+			}
 			f[0] = A.x; f[1] = A.y; f[2] = B.x; f[3] = B.y; f[4] = Cc.x; f[5] = Cc.y; f[6] = Dc.x; f[7] = Dc.y;
 			f[8] = __int_as_float(mc);
 			recordChannelFields<CH>(f, p, e, mc);
@@ -2058,6 +2111,7 @@ constexpr int kVocBlockSteps = 8, kVocBlocks = 3, kVocBlocksStaged = 2, kVocWave
 // lane groups, and 2*CH*64 float2 is a multiple of the 32 banks (an 8-way conflict on every writer read with the first layout)
 constexpr int kVocOutPitch = 66;
 
+__device__ __forceinline__ float2 selectPair(bool pick, float2 a, float2 b) { return make_float2(pick ? a.x : b.x, pick ? a.y : b.y); }
 __device__ __forceinline__ float2 fromLaneBelow(float2 v, float2 lane0) { // lane k receives lane k-1's v; lane 0 keeps its `lane0`
 	// DPP wave_shr:1 without bound_ctrl: a lane with no source lane keeps the old value of the destination register
 	return make_float2(__int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(lane0.x), __float_as_int(v.x), 0x138, 0xf, 0xf, false)),
@@ -2074,8 +2128,7 @@ __global__ __launch_bounds__(64*kVocWaves) __attribute__((amdgpu_waves_per_eu(4,
 	static_assert(BS == 8 && L >= 1 && L <= 7, "history registers are indexed by step & 7");
 	extern __shared__ __attribute__((aligned(16))) unsigned char smemRaw[];
 	float4 *recs = reinterpret_cast<float4 *>(smemRaw);                 // [(slot*BS + st)*NCH + j][64 lanes]
-	float2 *stage = reinterpret_cast<float2 *>(recs + NB*BS*NCH*64);    // [CH][128]: carried Band.output, 128-bin window
-	volatile int *sync = reinterpret_cast<volatile int *>(stage + CH*128); // [0..NB) units produced, [NB] blocks consumed
+	volatile int *sync = reinterpret_cast<volatile int *>(recs + NB*BS*NCH*64); // [0..NB) units produced, [NB] blocks consumed
 	int *rowClass = const_cast<int *>(sync) + 16;                                  // [2][64]: the writer's two classes of rows
 	HopDesc *hopsLds = reinterpret_cast<HopDesc *>(rowClass + 128);                // the tile's 64 hop descriptors
 	float2 *outRing = reinterpret_cast<float2 *>(hopsLds + 64);                    // [kVocOutBlocks][BS][CH][64]: results on their way to HBM
@@ -2091,11 +2144,7 @@ __global__ __launch_bounds__(64*kVocWaves) __attribute__((amdgpu_waves_per_eu(4,
 	const int totalBlocks = chunks*(64/BS);
 	const CarriedOutput stOut = carriedOutput(d, sg);
 
-	// prologue (all waves): stage bins [0,128) of the carried Band.output, clear the hand-off words, cache the hop table
-	for (int i = threadIdx.x; i < CH*128; i += blockDim.x) {
-		const int c = i >> 7, bb = i & 127;
-		stage[i] = (bb < M) ? stOut[(size_t)c*M + bb] : make_float2(0.f, 0.f);
-	}
+	// prologue (all waves): clear the hand-off words, cache the hop table
 	if (threadIdx.x <= NB + 2) sync[threadIdx.x] = 0;
 	if (threadIdx.x < 64) hopsLds[threadIdx.x] = d.hops[(size_t)sg*d.hopStride + hopBase + threadIdx.x];
 	float2 *rotLds = outRing + (size_t)kVocOutBlocks*BS*CH*kVocOutPitch; // [M] hop rotation table (ROTL; the staged kernel keeps its windows here)
@@ -2169,7 +2218,7 @@ __global__ __launch_bounds__(64*kVocWaves) __attribute__((amdgpu_waves_per_eu(4,
 		if constexpr (STAGED) {
 			using G = StageGeom<CH, L>;
 			float2 *sbuf = outRing + (size_t)kVocOutBlocks*BS*CH*kVocOutPitch + (size_t)pIndex*G::ROWS*G::ROWLEN;
-			vocoderProduceStaged<CH, L, NB, NP>(d, s, sg, nh, pIndex, k, totalBlocks, recs, sync, hopsLds, sbuf);
+			vocoderProduceStaged<CH, L, NB, NP>(d, s, sg, nh, pIndex, k, totalBlocks, recs, sync, hopsLds, sbuf, stOut);
 			return;
 		}
 		const int st = k & 7, r = k >> 3; // 8 adjacent lanes = 8 consecutive bins of one row: 64-byte contiguous global loads
@@ -2182,7 +2231,7 @@ __global__ __launch_bounds__(64*kVocWaves) __attribute__((amdgpu_waves_per_eu(4,
 			float f[NCH*4];
 #pragma unroll
 			for (int j = 0; j < NCH*4; ++j) f[j] = 0.0f;
-			if (row < nh && b >= 0 && b < M && d.debugMode != 1) computeRecord<CH, PLAIN, false, false, NCH*4, ROTL>(d, hopsLds[row], hopsLds[row > 0 ? row - 1 : 0], s, sg, row, b, f, rotLds);
+			if (row < nh && b >= 0 && b < M && d.debugMode != 1) computeRecord<CH, PLAIN, false, false, NCH*4, ROTL, true>(d, hopsLds[row], hopsLds[row > 0 ? row - 1 : 0], s, sg, row, b, f, rotLds);
 			while (n - ldsPeek(&sync[NB]) >= NB) __builtin_amdgcn_s_sleep(2); // slot still being read (waited for AFTER the pass is computed)
 			asm volatile("" ::: "memory");
 #pragma unroll
@@ -2197,115 +2246,90 @@ __global__ __launch_bounds__(64*kVocWaves) __attribute__((amdgpu_waves_per_eu(4,
 
 	// ---------------- consumer (wave 0) ----------------
 	__builtin_amdgcn_s_setprio(3);
-	const int kLag = lag*k;
-	float2 pf[CH];
-	float2 h[8][CH];   // this lane's outputs of the last 8 steps
-	float2 sv1[CH], svL[CH]; // lane 0: carried outputs at bins b+1 and b+L of the coming step ...
-	float2 sw1[CH], swL[CH]; // ... and of the step after it: read TWO steps ahead (one step ahead the LDS latency, 100 cycles, sat on the serial path: the compiler hoists the next step's DPP moves, which take these as their `old` operand, into the current step)
+	float2 h[8][CH]; // this lane's outputs of the last 8 steps
+	// Previous-hop taps: lane k receives lane k-1's history registers by DPP.  Lane 0's previous hop is the carried state, which
+	// its records have folded in (FOLD0): its taps are the constants (1, 0) and (0, 0).  A wave_shr:1 never writes lane 0, so the
+	// constants are set ONCE, here, and each tap register is the `old` operand of the next DPP move into itself -- no LDS read,
+	// no staging window and no register copy for lane 0 on the serial path.
+	float2 tap1[CH], tapL[CH];
 #pragma unroll
 	for (int c = 0; c < CH; ++c) {
-		pf[c] = make_float2(0.f, 0.f);
 #pragma unroll
 		for (int i = 0; i < 8; ++i) h[i][c] = make_float2(0.f, 0.f);
-		sv1[c] = stage[c*128 + ((1 - kLag) & 127)];
-		svL[c] = stage[c*128 + ((L - kLag) & 127)];
-		sw1[c] = stage[c*128 + ((2 - kLag) & 127)];
-		swL[c] = stage[c*128 + ((L + 1 - kLag) & 127)];
+		tap1[c] = make_float2(k == 0 ? 1.f : 0.f, 0.f);
+		tapL[c] = make_float2(0.f, 0.f);
 	}
-
 	// the two hand-off words the NEXT block waits for are read during the current block's last step (an LDS round trip each,
 	// 200 clock cycles, sat on the serial path at every block boundary -- cycle trace); the poll loops remain for the rare miss
 	int seenProduced = ldsPeek(&sync[0]), seenWritten = 0;
-	for (int ch = 0; ch < chunks; ++ch) {
-		const int tb = ch << 6;
-		if (ch > 0) {
+	for (int n = 0; n < totalBlocks; ++n) {
+		const int slot = n%NB;
+		const int need = 8*(n/NB + 1);
+		while (seenProduced < need) { __builtin_amdgcn_s_sleep(1); seenProduced = ldsPeek(&sync[slot]); }
+		asm volatile("" ::: "memory");
+		const float4 *blockRecs = recs + (size_t)slot*BS*NCH*64;
+		while (n - seenWritten >= 2) { __builtin_amdgcn_s_sleep(1); seenWritten = ldsPeek(&sync[NB + 2]); } // the writer still owns this result slot
+		asm volatile("" ::: "memory");
+		float2 *blockOut = outRing + (size_t)(n%kVocOutBlocks)*BS*CH*kVocOutPitch + k;
+		float4 q[2][NCH]; // two register sets alternate, so the next step's record loads never overwrite live values
 #pragma unroll
-			for (int c = 0; c < CH; ++c) stage[c*128 + ((tb + 64 + k) & 127)] = pf[c];
-		}
-		{
-			const int bb = tb + 128 + k;
-			const int bc = (bb < M) ? bb : M - 1;
+		for (int j = 0; j < NCH; ++j) q[0][j] = blockRecs[j*64 + k];
+#pragma unroll
+		for (int i = 0; i < BS; ++i) {
+			if (d.debugMode == 2) break; // experiment: consumer only acknowledges blocks
+			if (i + 1 < BS) {
+#pragma unroll
+				for (int j = 0; j < NCH; ++j) q[(i + 1) & 1][j] = blockRecs[((i + 1)*NCH + j)*64 + ((k + (i + 1)) & 63)];
+			} else { // last step: look at the next block's hand-off words now, their latency hides under this step
+				seenProduced = ldsPeek(&sync[(n + 1)%NB]);
+				seenWritten = ldsPeek(&sync[NB + 2]);
+			}
+			float f[NCH*4];
+#pragma unroll
+			for (int j = 0; j < NCH; ++j) { f[4*j] = q[i & 1][j].x; f[4*j + 1] = q[i & 1][j].y; f[4*j + 2] = q[i & 1][j].z; f[4*j + 3] = q[i & 1][j].w; }
+			const int mc = __float_as_int(f[8]); // 0 .. CH-1: every record of the ring was written by a producer (all-zero outside the tile)
+			// taps: own history (bins b-1, b-L), and lane k-1's history: it runs L+1 bins ahead, so ITS b-L and b-1 taps are this
+			// lane's previous-hop taps at b+1 and b+L
 #pragma unroll
 			for (int c = 0; c < CH; ++c) {
-				float2 v = stOut[(size_t)c*M + bc];
-				pf[c] = (bb < M) ? v : make_float2(0.f, 0.f);
+				tap1[c] = fromLaneBelow(h[(i + 8 - L) & 7][c], tap1[c]);
+				tapL[c] = fromLaneBelow(h[(i + 7) & 7][c], tapL[c]);
 			}
-		}
-		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-		__builtin_amdgcn_wave_barrier();
-		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-		for (int blk = 0; blk < 64/BS; ++blk) {
-			const int n = ch*(64/BS) + blk;
-			const int slot = n%NB;
-			const int need = 8*(n/NB + 1);
-			while (seenProduced < need) { __builtin_amdgcn_s_sleep(1); seenProduced = ldsPeek(&sync[slot]); }
-			asm volatile("" ::: "memory");
-			const float4 *blockRecs = recs + (size_t)slot*BS*NCH*64;
-			while (n - seenWritten >= 2) { __builtin_amdgcn_s_sleep(1); seenWritten = ldsPeek(&sync[NB + 2]); } // the writer still owns this result slot
-			asm volatile("" ::: "memory");
-			float2 *blockOut = outRing + (size_t)(n%kVocOutBlocks)*BS*CH*kVocOutPitch + k;
-			float4 q[2][NCH]; // two register sets alternate, so the next step's record loads never overwrite live values
+			// the maximum channel's taps: explicit per-component selects (v_cndmask) -- written as an `if` the compiler makes a branch of
+			// it, with a register copy in front of every tap that must survive (14 moves against 8 selects)
+			float2 o1 = h[(i + 7) & 7][0], oL = h[(i + 8 - L) & 7][0], p1 = tap1[0], pL = tapL[0];
 #pragma unroll
-			for (int j = 0; j < NCH; ++j) q[0][j] = blockRecs[j*64 + k];
-#pragma unroll
-			for (int i = 0; i < BS; ++i) {
-				if (d.debugMode == 2) break; // experiment: consumer only acknowledges blocks
-				const int t = tb + blk*BS + i;
-				if (i + 1 < BS) {
-#pragma unroll
-					for (int j = 0; j < NCH; ++j) q[(i + 1) & 1][j] = blockRecs[((i + 1)*NCH + j)*64 + ((k + (i + 1)) & 63)];
-				} else { // last step: look at the next block's hand-off words now, their latency hides under this step
-					seenProduced = ldsPeek(&sync[(n + 1)%NB]);
-					seenWritten = ldsPeek(&sync[NB + 2]);
-				}
-				float f[NCH*4];
-#pragma unroll
-				for (int j = 0; j < NCH; ++j) { f[4*j] = q[i & 1][j].x; f[4*j + 1] = q[i & 1][j].y; f[4*j + 2] = q[i & 1][j].z; f[4*j + 3] = q[i & 1][j].w; }
-				const int b = t - kLag;
-				const int mc = __float_as_int(f[8]); // 0 .. CH-1: every record of the ring was written by a producer (all-zero outside the tile)
-				// taps: own history, and lane k-1's history (lane 0: the staged carried state)
-				float2 o1 = h[(i + 7) & 7][0], oL = h[(i + 8 - L) & 7][0];
-				float2 p1 = fromLaneBelow(oL, sv1[0]), pL = fromLaneBelow(o1, svL[0]); // lane 0: the staged carried state
-				const float2 pm = make_float2(f[9], f[10]); // mono: the channel's; stereo: the maximum channel's (recordChannelFields)
-				const float sm = f[11];
-#pragma unroll
-				for (int c = 1; c < CH; ++c) {
-					const float2 o1c = h[(i + 7) & 7][c], oLc = h[(i + 8 - L) & 7][c];
-					const float2 p1c = fromLaneBelow(oLc, sv1[c]), pLc = fromLaneBelow(o1c, svL[c]);
-					if (c == mc) { o1 = o1c; oL = oLc; p1 = p1c; pL = pLc; }
-				}
-				// next step's staged values (only lane 0 uses them): bins (b+1)+1 and (b+1)+L
+			for (int c = 1; c < CH; ++c) {
+				const bool pick = c == mc;
+				o1 = selectPair(pick, h[(i + 7) & 7][c], o1);
+				oL = selectPair(pick, h[(i + 8 - L) & 7][c], oL);
+				p1 = selectPair(pick, tap1[c], p1);
+				pL = selectPair(pick, tapL[c], pL);
+			}
+			const float2 pm = make_float2(f[9], f[10]); // mono: the channel's input; stereo: the maximum channel's fallback output (recordChannelFields)
+			const float sm = f[11];
+			float2 phi = prevHopTerms(p1, make_float2(f[4], f[5]), pL, make_float2(f[6], f[7])); // previous hop's part first (what FOLD0 records pre-compute)
+			phi = cfma(oL, make_float2(f[2], f[3]), phi);
+			phi = cfma(o1, make_float2(f[0], f[1]), phi); // the newest operand last: two dependent instructions behind it
+			const float2 om = (CH == 2) ? makeOutputFb(phi, pm, sm) : makeOutput(phi, pm, sm); // :788
+			if (CH == 2) { // one locked channel (:791-800), its makeOutput folded into the record
+				const float2 olock = lockedOutput(om, f);
+				// cells outside the tile (inactive hop, bin outside [0, M)) have all-zero records, which give exactly zero here
+				const float2 oc0 = mc ? olock : om, oc1 = mc ? om : olock;
+				h[i][0] = oc0;
+				h[i][CH - 1] = oc1;
+				blockOut[(i*CH)*kVocOutPitch] = oc0;
+				blockOut[(i*CH + CH - 1)*kVocOutPitch] = oc1;
+			} else {
 #pragma unroll
 				for (int c = 0; c < CH; ++c) {
-					sv1[c] = sw1[c];
-					svL[c] = swL[c];
-					sw1[c] = stage[c*128 + ((b + 3) & 127)];
-					swL[c] = stage[c*128 + ((b + 2 + L) & 127)];
-				}
-				float2 phi = cmul(oL, make_float2(f[2], f[3]));
-				phi = cadd(phi, cmul(p1, make_float2(f[4], f[5])));
-				phi = cadd(phi, cmul(pL, make_float2(f[6], f[7])));
-				phi = cadd(phi, cmul(o1, make_float2(f[0], f[1])));
-				const float2 om = makeOutput(phi, pm, sm); // :788
-				if (CH == 2) { // one locked channel (:791-800), its makeOutput folded into the record
-					const float2 olock = lockedOutput(om, f);
-					// cells outside the tile (inactive hop, bin outside [0, M)) have all-zero records, which give exactly zero here
-					const float2 oc0 = mc ? olock : om, oc1 = mc ? om : olock;
-					h[i][0] = oc0;
-					h[i][CH - 1] = oc1;
-					blockOut[(i*CH)*kVocOutPitch] = oc0;
-					blockOut[(i*CH + CH - 1)*kVocOutPitch] = oc1;
-				} else {
-#pragma unroll
-					for (int c = 0; c < CH; ++c) {
-						h[i][c] = om;
-						blockOut[(i*CH + c)*kVocOutPitch] = om;
-					}
+					h[i][c] = om;
+					blockOut[(i*CH + c)*kVocOutPitch] = om;
 				}
 			}
-			asm volatile("" ::: "memory");
-			if (k == 0) { ldsPost(&sync[NB], n + 1); ldsPost(&sync[NB + 1], n + 1); } // record slot may be refilled; results may be written out
 		}
+		asm volatile("" ::: "memory");
+		if (k == 0) { ldsPost(&sync[NB], n + 1); ldsPost(&sync[NB + 1], n + 1); } // record slot may be refilled; results may be written out
 	}
 }
 
@@ -2476,10 +2500,9 @@ __global__ __launch_bounds__(64*kVocWaves) __attribute__((amdgpu_waves_per_eu(4,
 				const float2 oL = ring[(ringRow + ((b - L) & Rm))*64 + k];
 				const float2 p1 = (k == 0) ? stage[mc*128 + ((b + 1) & 127)] : ring[(ringRow + ((b + 1) & Rm))*64 + k - 1];
 				const float2 pL = (k == 0) ? stage[mc*128 + ((b + L) & 127)] : ring[(ringRow + ((b + L) & Rm))*64 + k - 1];
-				float2 phi = cmul(oL, make_float2(f[2], f[3]));
-				phi = cadd(phi, cmul(p1, make_float2(f[4], f[5])));
-				phi = cadd(phi, cmul(pL, make_float2(f[6], f[7])));
-				phi = cadd(phi, cmul(o1, make_float2(f[0], f[1])));
+				float2 phi = prevHopTerms(p1, make_float2(f[4], f[5]), pL, make_float2(f[6], f[7])); // previous hop's part first (what FOLD0 records pre-compute)
+				phi = cfma(oL, make_float2(f[2], f[3]), phi);
+				phi = cfma(o1, make_float2(f[0], f[1]), phi); // the newest operand last: two dependent instructions behind it
 				const float2 om = makeOutput(phi, pm, sm); // :788
 #pragma unroll
 				for (int c = 0; c < CH; ++c) {
@@ -2624,11 +2647,10 @@ __global__ __launch_bounds__(128) void kVocoderOne(DevBatch d, int sBase, int ho
 						if (CH != 2) { pm = make_float2(f[9 + 3*c], f[10 + 3*c]); sm = f[11 + 3*c]; } // stereo records lead with the maximum channel
 					}
 				}
-				float2 phi = cmul(oL, make_float2(f[2], f[3]));
-				phi = cadd(phi, cmul(p1, make_float2(f[4], f[5])));
-				phi = cadd(phi, cmul(pL, make_float2(f[6], f[7])));
-				phi = cadd(phi, cmul(o1, make_float2(f[0], f[1])));
-				const float2 om = makeOutput(phi, pm, sm); // :788
+				float2 phi = prevHopTerms(p1, make_float2(f[4], f[5]), pL, make_float2(f[6], f[7])); // previous hop's part first (what FOLD0 records pre-compute)
+				phi = cfma(oL, make_float2(f[2], f[3]), phi);
+				phi = cfma(o1, make_float2(f[0], f[1]), phi); // the newest operand last: two dependent instructions behind it
+				const float2 om = (CH == 2) ? makeOutputFb(phi, pm, sm) : makeOutput(phi, pm, sm); // :788 (stereo records carry the fallback output in pm's place)
 				const float2 olock = (CH == 2) ? lockedOutput(om, f) : om; // stereo: see recordChannelFields
 #pragma unroll
 				for (int c = 0; c < CH; ++c) {
@@ -2675,7 +2697,7 @@ __global__ __launch_bounds__(256) void kSynth(DevBatch d, int sBase, int hopBase
 	float *frame = d.frames + ((size_t)((size_t)s*d.T + k)*d.C + c)*(size_t)B;
 	const float *__restrict__ win = d.window;
 	for (int m = threadIdx.x; m < H; m += blockDim.x) {
-		float2 v = cmulc(res[m], d.halfTw[m]); // * e^{+i pi m / N}
+		float2 v = cmulcPlain(res[m], d.halfTw[m]); // * e^{+i pi m / N}
 		if (m < B - halfB) {
 			int i = m + halfB;
 			frame[i] = (2*v.x)*win[i];
@@ -2949,6 +2971,22 @@ __global__ __launch_bounds__(256) void kAddPreRoll(DevBatch d, const float *__re
 	storeCarrySum(d, d.carryCur, e, loadCarrySum(d, d.carryCur, e) + v*d.carryWp[d.carryCur][(size_t)sg*CL + idx]);
 }
 
+// Self-test of smst_complex.h (the packed-f32 helpers are inline assembly: their operand selects and negations are checked
+// against the documented formulas on the device they ship for).  in: n triples (a, b, c) of complex values + one fraction each
+// (7 floats); out: cmul, cmulc, cfma, clerp (8 floats).
+__global__ __launch_bounds__(64) void kComplexSelfTest(const float *__restrict__ in, float *__restrict__ out, int n) {
+	const int i = blockIdx.x*blockDim.x + threadIdx.x;
+	if (i >= n) return;
+	const float *v = in + (size_t)7*i;
+	const float2 a = make_float2(v[0], v[1]), b = make_float2(v[2], v[3]), c = make_float2(v[4], v[5]);
+	const float2 r0 = cmul(a, b), r1 = cmulc(a, b), r2 = cfma(a, b, c), r3 = clerp(a, b, v[6]);
+	float *o = out + (size_t)8*i;
+	o[0] = r0.x; o[1] = r0.y; o[2] = r1.x; o[3] = r1.y; o[4] = r2.x; o[5] = r2.y; o[6] = r3.x; o[7] = r3.y;
+}
+void launchComplexSelfTest(const float *in, float *out, int n, hipStream_t st) {
+	hipLaunchKernelGGL(kComplexSelfTest, dim3((n + 63)/64), dim3(64), 0, st, in, out, n);
+}
+
 // ------------------------------------------------------------------------------------------------------
 // host-side launchers
 // ------------------------------------------------------------------------------------------------------
@@ -3017,7 +3055,7 @@ void launchPredictFused(const DevBatch &d, int sBase, int nStreams, int hopBase,
 template <int CH, int L>
 static void launchVocoderTL(const DevBatch &d, int sBase, int nStreams, int hopBase, bool plain, bool bounded, hipStream_t st) {
 	constexpr int NCH = (9 + 3*CH + 3)/4;
-	const size_t fixed = (size_t)CH*128*sizeof(float2) + 64 + 128*sizeof(int) + 64*sizeof(HopDesc) + (size_t)kVocOutBlocks*kVocBlockSteps*CH*kVocOutPitch*sizeof(float2);
+	const size_t fixed = 64 + 128*sizeof(int) + 64*sizeof(HopDesc) + (size_t)kVocOutBlocks*kVocBlockSteps*CH*kVocOutPitch*sizeof(float2);
 	const size_t lds = (size_t)kVocBlocks*kVocBlockSteps*NCH*64*sizeof(float4) + fixed;
 	if constexpr (L <= 5) {
 		if (plain && bounded && !d.noStage) {

@@ -665,3 +665,35 @@ def case_hop_magnitudes(lib, ref, cfg, channels, stretch, label, setup=None, hop
     assert rates["argmax"] >= min_argmax_agreement, (label, rates)
     assert rates["map"] >= min_map_agreement, (label, rates)
     return rates
+
+
+def complex_helper_expectation(v):
+    """The roundings csrc/smst_complex.h documents, in float32 with single-rounded fused multiply-adds (float64 products of
+    float32 operands are exact, one rounding on the way back)."""
+    f32, f64 = np.float32, np.float64
+    ax, ay, bx, by, cx, cy, fr = (v[:, i].astype(f32) for i in range(7))
+
+    def fma(x, y, z):
+        return (x.astype(f64)*y.astype(f64) + z.astype(f64)).astype(f32)
+
+    def mul(x, y):
+        return (x.astype(f64)*y.astype(f64)).astype(f32)
+    out = np.zeros((v.shape[0], 8), f32)
+    out[:, 0], out[:, 1] = fma(ay, -by, mul(ax, bx)), fma(ay, bx, mul(ax, by))
+    out[:, 2], out[:, 3] = fma(ay, by, mul(ax, bx)), fma(ay, bx, -mul(ax, by))
+    out[:, 4], out[:, 5] = fma(ay, -by, fma(ax, bx, cx)), fma(ay, bx, fma(ax, by, cy))
+    out[:, 6], out[:, 7] = fma(bx - ax, fr, ax), fma(by - ay, fr, ay)
+    return out
+
+
+def case_complex_helpers(lib):
+    g = np.random.Generator(np.random.PCG64(77))
+    v = g.standard_normal((4096, 7)).astype(np.float32)
+    v[:, 6] = g.uniform(0, 1, 4096)
+    v[:16, :6] = 0.0
+    got = package().complex_selftest(v, lib=lib)
+    want = complex_helper_expectation(v)
+    # the float64 emulation of a float32 fma double-rounds in rare cases: an ulp there, exact agreement on the rest
+    close = np.abs(got - want) <= np.spacing(np.abs(want).astype(np.float32))
+    assert close.all(), (got[~close][:4], want[~close][:4])
+    assert (got == want).mean() > 0.999

@@ -118,3 +118,8 @@ def test_freq_map_tables_are_per_stream(emu):
     err = np.sqrt(np.mean((y[1] - y[0])**2)/np.mean(y[0]**2))   # same linear map, resampled: same result up to the table's own rounding
     assert err < 1e-3, err
     assert np.sqrt(np.mean((y[0] - y_plain[0])**2)/np.mean(y_plain[0]**2)) > 0.1  # and the map does something
+
+
+def test_packed_complex_helpers_emu(emu):
+    """tests/emu/smst_complex.h (the CPU stand-in's twin of the product's inline-assembly header) follows the same formulas."""
+    pc.case_complex_helpers(emu)

@@ -502,3 +502,9 @@ def test_stream_ordering_without_host_sync(hip):
             total = (y - ref_out).abs().max()  # consumer on the same torch stream, ordered after the batch's kernels
         assert float(total) == 0.0, (trial, float(total))
     b.close()
+
+
+def test_packed_complex_helpers(hip):
+    """csrc/smst_complex.h is inline assembly (v_pk_mul_f32 / v_pk_fma_f32 with op_sel / neg modifiers): operand selects,
+    negations and the documented roundings, bit for bit, on the device."""
+    pc.case_complex_helpers(hip)

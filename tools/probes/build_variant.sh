@@ -1,0 +1,28 @@
+#!/bin/bash
+# Builds a VARIANT of the product library from a patched copy of csrc/ into signalsmith-stretch_amd/variants/<name>.so
+# (git-ignored; travels to the GPU box).  The product sources are never touched.
+# usage: tools/probes/build_variant.sh <name> [patch-script.py ...] [-- extra hipcc flags]     e.g.  build_variant.sh trace tools/probes/voc_trace_patch.py
+#        tools/probes/build_variant.sh base --git <rev>          (the library of another commit, for same-box A/B runs)
+set -e
+ROOT=$(cd "$(dirname "$0")/../.." && pwd)
+NAME=$1; shift
+TMP=$(mktemp -d /tmp/smst_variant.XXXXXX)
+mkdir -p $TMP/signalsmith-stretch_amd/csrc $TMP/include $ROOT/signalsmith-stretch_amd/variants
+if [ "$1" = "--git" ]; then
+  git -C $ROOT archive $2 signalsmith-stretch_amd/csrc include | tar -x -C $TMP
+  shift 2
+else
+  cp $ROOT/signalsmith-stretch_amd/csrc/*.{h,hip,cpp} $TMP/signalsmith-stretch_amd/csrc/
+  cp -r $ROOT/include/* $TMP/include/
+fi
+EXTRA=""
+while [ $# -gt 0 ]; do
+  if [ "$1" = "--" ]; then shift; EXTRA="$*"; break; fi
+  python3 "$1" $TMP/signalsmith-stretch_amd/csrc
+  shift
+done
+C=$TMP/signalsmith-stretch_amd/csrc
+hipcc --offload-arch=gfx950 -I$C -O3 -ffp-contract=on -std=c++17 -fPIC -shared -x hip -Wno-unused-result -Wno-unused-value $EXTRA \
+  $C/smst_kernels.hip $C/smst_engine.cpp $C/smst_capi.cpp -o $ROOT/signalsmith-stretch_amd/variants/$NAME.so 2>&1 | grep -E "error" || true
+ls -la $ROOT/signalsmith-stretch_amd/variants/$NAME.so
+rm -rf $TMP

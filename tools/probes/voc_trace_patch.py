@@ -1,5 +1,7 @@
 """Applies the timestamp instrumentation that tools/probes/voc_trace.py reads to a COPY of the kernel / engine sources:\n    cp csrc/smst_kernels.hip csrc/smst_engine.cpp /tmp/keep/ ; python tools/probes/voc_trace_patch.py ; hipcc ... -o variants/trace.so ; restore the sources.\nThe product sources never contain it."""
-p='/root/repo/signalsmith-stretch_amd/csrc/smst_kernels.hip'
+import sys
+SRC = sys.argv[1] if len(sys.argv) > 1 else '/root/repo/signalsmith-stretch_amd/csrc'  # a COPY of csrc/ (tools/probes/build_variant.sh makes one)
+p=SRC + '/smst_kernels.hip'
 s=open(p).read()
 anchor="// Staged producers (PLAIN tiles without random time factors, L <= 5)."
 assert anchor in s
@@ -12,9 +14,9 @@ rep("""	for (; n < totalBlocks; n += NPB) {
 		park(n);""","""	for (; n < totalBlocks; n += NPB) {
 		if (pIndex == 0) TR(0, n);
 		park(n);""")
-rep("""		if (n + NPB < totalBlocks) issue(n + NPB);
+rep("""		if (n + NPB < totalBlocks) { issue(n + NPB); if (it == 0) issueCarried(n + NPB); }
 		const int slot = n%NB;""","""		if (pIndex == 0) TR(1, n);
-		if (n + NPB < totalBlocks) issue(n + NPB);
+		if (n + NPB < totalBlocks) { issue(n + NPB); if (it == 0) issueCarried(n + NPB); }
 		const int slot = n%NB;""")
 rep("""		while (n - ldsPeek(&sync[NB]) >= NB) __builtin_amdgcn_s_sleep(2); // slot still being read
 		asm volatile("" ::: "memory");
@@ -33,24 +35,24 @@ rep("""#pragma unroll
 		if (k == 0) ldsCount(&sync[slot]);
 		if (pIndex == 0) TR(4, n);
 		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");""")
-rep("""			const int need = 8*(n/NB + 1);
-			while (seenProduced < need) { __builtin_amdgcn_s_sleep(1); seenProduced = ldsPeek(&sync[slot]); }
-			asm volatile("" ::: "memory");
-			const float4 *blockRecs = recs + (size_t)slot*BS*NCH*64;
-			while (n - seenWritten >= 2) { __builtin_amdgcn_s_sleep(1); seenWritten = ldsPeek(&sync[NB + 2]); } // the writer still owns this result slot
-			asm volatile("" ::: "memory");""","""			const int need = 8*(n/NB + 1);
-			TR(5, n);
-			while (seenProduced < need) { __builtin_amdgcn_s_sleep(1); seenProduced = ldsPeek(&sync[slot]); }
-			asm volatile("" ::: "memory");
-			TR(6, n);
-			const float4 *blockRecs = recs + (size_t)slot*BS*NCH*64;
-			while (n - seenWritten >= 2) { __builtin_amdgcn_s_sleep(1); seenWritten = ldsPeek(&sync[NB + 2]); } // the writer still owns this result slot
-			asm volatile("" ::: "memory");
-			TR(7, n);""")
-rep("""			asm volatile("" ::: "memory");
-			if (k == 0) { ldsPost(&sync[NB], n + 1); ldsPost(&sync[NB + 1], n + 1); } // record slot may be refilled; results may be written out""","""			asm volatile("" ::: "memory");
-			TR(8, n);
-			if (k == 0) { ldsPost(&sync[NB], n + 1); ldsPost(&sync[NB + 1], n + 1); } // record slot may be refilled; results may be written out""")
+rep("""		const int need = 8*(n/NB + 1);
+		while (seenProduced < need) { __builtin_amdgcn_s_sleep(1); seenProduced = ldsPeek(&sync[slot]); }
+		asm volatile("" ::: "memory");
+		const float4 *blockRecs = recs + (size_t)slot*BS*NCH*64;
+		while (n - seenWritten >= 2) { __builtin_amdgcn_s_sleep(1); seenWritten = ldsPeek(&sync[NB + 2]); } // the writer still owns this result slot
+		asm volatile("" ::: "memory");""","""		const int need = 8*(n/NB + 1);
+		TR(5, n);
+		while (seenProduced < need) { __builtin_amdgcn_s_sleep(1); seenProduced = ldsPeek(&sync[slot]); }
+		asm volatile("" ::: "memory");
+		TR(6, n);
+		const float4 *blockRecs = recs + (size_t)slot*BS*NCH*64;
+		while (n - seenWritten >= 2) { __builtin_amdgcn_s_sleep(1); seenWritten = ldsPeek(&sync[NB + 2]); } // the writer still owns this result slot
+		asm volatile("" ::: "memory");
+		TR(7, n);""")
+rep("""		asm volatile("" ::: "memory");
+		if (k == 0) { ldsPost(&sync[NB], n + 1); ldsPost(&sync[NB + 1], n + 1); } // record slot may be refilled; results may be written out""","""		asm volatile("" ::: "memory");
+		TR(8, n);
+		if (k == 0) { ldsPost(&sync[NB], n + 1); ldsPost(&sync[NB + 1], n + 1); } // record slot may be refilled; results may be written out""")
 rep("""			for (int n = 0; n <= totalBlocks + 1; ++n) {
 				if (n < totalBlocks) {
 					while (ldsPeek(&sync[NB + 1]) <= n) __builtin_amdgcn_s_sleep(2);
@@ -75,7 +77,7 @@ rep("""				asm volatile("" ::: "memory");
 		}
 		// 0..NP-1 over the producer waves.""")
 open(p,'w').write(s)
-p='/root/repo/signalsmith-stretch_amd/csrc/smst_engine.cpp'
+p=SRC + '/smst_engine.cpp'
 s=open(p).read()
 rep2_old="void Batch::debugGetState(int stream, int which, float *dst) {\n	SMST_HIP(hipSetDevice(dev));\n	SMST_HIP(hipStreamSynchronize(st));"
 assert rep2_old in s
