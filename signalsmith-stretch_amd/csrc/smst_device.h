@@ -20,6 +20,7 @@ struct DevBatch {
 	int noFeedFusion;             // SMST_NO_FEED_FUSION=1: pass A stays its own kernel (kPredictA) -- cross-check of the folded form
 	int feedSerial;               // SMST_FEED_SERIAL: bin-by-bin feed recurrences (kFeedSerial) instead of the scan form
 	int halfState;                // carried Band.output / Prediction.energy / overlap-add sums stored in fp16 (BASELINE config 5 "fp16 internal")
+	int noFastFft;                // SMST_NO_FAST_FFT: the generic radix-4/2/3/5 ladder even where a register-blocked FFT exists (cross-check)
 	int noStage;                  // SMST_NO_STAGE: producers of the fused kernel gather from HBM even where staging applies
 	FftPlan plan;
 	// constant tables

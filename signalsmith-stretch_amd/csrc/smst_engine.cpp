@@ -171,6 +171,7 @@ void Batch::construct(const FftPlan &plan, long seed) {
 	d.noFeedFusion = 0;
 	if (const char *env = std::getenv("SMST_NO_FEED_FUSION")) d.noFeedFusion = atoi(env);
 	d.noStage = std::getenv("SMST_NO_STAGE") != nullptr;
+	d.noFastFft = std::getenv("SMST_NO_FAST_FFT") != nullptr;
 	d.feedSerial = std::getenv("SMST_FEED_SERIAL") != nullptr;
 
 	// constant tables
@@ -231,7 +232,7 @@ void Batch::construct(const FftPlan &plan, long seed) {
 		d.win4 = static_cast<float4 *>(upload(w4.data(), M*sizeof(float4)));
 		d.synTab = static_cast<float4 *>(upload(st4.data(), M*sizeof(float4)));
 		d.twA = d.twB = nullptr;
-		if (M%256 == 0 && (M/256 == 12 || M/256 == 20)) {
+		if (M%256 == 0 && (M/256 == 10 || M/256 == 12 || M/256 == 20 || M/256 == 24)) { // the register-blocked FFT's sizes: 16 x 16 x R3
 			const int R3 = M/256, MA = 16*R3;
 			std::vector<float2> ta((size_t)15*MA), tb((size_t)15*R3);
 			for (int n = 1; n < 16; ++n) {

@@ -203,8 +203,9 @@ __device__ float2 *fftLds(float2 *src, float2 *dst, const FftPlan &plan, const f
 }
 
 // ------------------------------------------------------------------------------------------------------
-// Register-blocked FFT for H = 256*R3 (R3 = 12: 3072 bins = presetDefault at 44.1/48 kHz; R3 = 20: 5120 bins =
-// presetCheaper at 96 kHz): three Stockham stages 16 x 16 x R3, each butterfly held in registers, so the data
+// Register-blocked FFT for H = 256*R3: three Stockham stages 16 x 16 x R3, each butterfly held in registers, so the data
+// (R3 = 10: 2560 bins = presetCheaper at 44.1/48 kHz; 12: 3072 = presetDefault at 44.1/48 kHz; 20: 5120 = presetCheaper at 88.2/96 kHz;
+// 24: 6144 = presetDefault at 88.2/96 kHz -- every size signalsmith-stretch.h:63-68 produces up to 96 kHz; R3 = {2,4,8} x {3,5})
 // crosses LDS only twice (vs. six times in the generic radix-4 ladder) and the stage-A output is padded by one
 // element per 16 so that neither the 128-byte-strided writes nor the stage-B reads conflict on LDS banks.
 // Twiddles come from per-stage tables laid out [n][p] (coalesced across the threads of a stage).
@@ -269,25 +270,56 @@ __device__ __forceinline__ void dft5(float2 &a, float2 &b, float2 &c, float2 &d,
 	d = csub(t2, ju2);
 	e = csub(t1, ju1);
 }
-// R3-point DFT (R3 = 4*G, G = 3 or 5) in place; on return X[e + 4c] sits at v[c + G*e]
+// RA-point DFT over v[base + stride*j], j < RA (RA = 2, 4 or 8), in place, outputs in natural order
+template <int SIGN, int RA, int N>
+__device__ __forceinline__ void dftPow2(float2 (&v)[N], int base, int stride) {
+	if constexpr (RA == 2) {
+		const float2 a = v[base], b = v[base + stride];
+		v[base] = cadd(a, b);
+		v[base + stride] = csub(a, b);
+	} else if constexpr (RA == 4) {
+		dft4<SIGN>(v[base], v[base + stride], v[base + 2*stride], v[base + 3*stride]);
+	} else {
+		static_assert(RA == 8, "radix 2, 4 or 8");
+		// even / odd halves (each a natural-order 4-point DFT), then X[k] = E[k] + w8^k O[k], X[k+4] = E[k] - w8^k O[k]
+		float2 e0 = v[base], e1 = v[base + 2*stride], e2 = v[base + 4*stride], e3 = v[base + 6*stride];
+		float2 o0 = v[base + stride], o1 = v[base + 3*stride], o2 = v[base + 5*stride], o3 = v[base + 7*stride];
+		dft4<SIGN>(e0, e1, e2, e3);
+		dft4<SIGN>(o0, o1, o2, o3);
+		const float h = 0.70710678118654752440f;
+		o1 = mulConst<SIGN>(o1, h, h);
+		o2 = (SIGN < 0) ? mulNegI(o2) : mulI(o2);
+		o3 = mulConst<SIGN>(o3, -h, h);
+		v[base] = cadd(e0, o0); v[base + 4*stride] = csub(e0, o0);
+		v[base + stride] = cadd(e1, o1); v[base + 5*stride] = csub(e1, o1);
+		v[base + 2*stride] = cadd(e2, o2); v[base + 6*stride] = csub(e2, o2);
+		v[base + 3*stride] = cadd(e3, o3); v[base + 7*stride] = csub(e3, o3);
+	}
+}
+// R3-point DFT (R3 = RA*G: RA = 2, 4 or 8 and G = 3 or 5) in place; on return X[e + RA*c] sits at v[c + G*e]
+template <int R3> struct LastStage {
+	static constexpr int G = (R3%3 == 0) ? 3 : 5;
+	static constexpr int RA = R3/G;
+	static_assert(R3%G == 0 && (RA == 2 || RA == 4 || RA == 8), "last stage: {2,4,8} x {3,5} points");
+};
 template <int SIGN, int R3>
 __device__ __forceinline__ void dftLast(float2 (&v)[R3]) {
-	constexpr int G = R3/4;
+	constexpr int G = LastStage<R3>::G, RA = LastStage<R3>::RA;
 #pragma unroll
-	for (int i = 0; i < G; ++i) dft4<SIGN>(v[i], v[i + G], v[i + 2*G], v[i + 3*G]);
+	for (int i = 0; i < G; ++i) dftPow2<SIGN, RA>(v, i, G);
 	// t_i[e] (at v[i + G e]) *= w_R3^(i e)
 #pragma unroll
 	for (int i = 1; i < G; ++i) {
 #pragma unroll
-		for (int e = 1; e < 4; ++e) {
+		for (int e = 1; e < RA; ++e) {
 			// compile-time constant after unrolling
 			const float ang = 6.28318530717958647692f*float(i*e)/float(R3);
 			v[i + G*e] = mulConst<SIGN>(v[i + G*e], __builtin_cosf(ang), __builtin_sinf(ang));
 		}
 	}
 #pragma unroll
-	for (int e = 0; e < 4; ++e) {
-		if (G == 3) dft3<SIGN>(v[G*e], v[G*e + 1], v[G*e + 2]);
+	for (int e = 0; e < RA; ++e) {
+		if constexpr (G == 3) dft3<SIGN>(v[G*e], v[G*e + 1], v[G*e + 2]);
 		else dft5<SIGN>(v[G*e], v[G*e + 1], v[G*e + 2], v[G*e + 3 < R3 ? G*e + 3 : 0], v[G*e + 4 < R3 ? G*e + 4 : 0]);
 	}
 }
@@ -351,16 +383,16 @@ __device__ __forceinline__ void fftFast(float2 *lds, const float4 *__restrict__ 
 	__syncthreads();
 	// stage C: radix R3, stride 256, no twiddles
 	if (t < 256) {
-		constexpr int G = R3/4;
+		constexpr int G = LastStage<R3>::G, RA = LastStage<R3>::RA;
 		float2 u[R3];
 #pragma unroll
 		for (int k = 0; k < R3; ++k) u[k] = lds[t + 256*k];
-		constexpr int CHUNK = R3 <= 12 ? R3 : 5; // outputs prepared ahead of their stores (R3 = 20: four rounds, or the registers cost a wave of occupancy)
+		constexpr int CHUNK = R3 <= 12 ? R3 : (R3 == 24 ? 6 : 5); // outputs prepared ahead of their stores (R3 = 20 / 24: four rounds, or the registers cost a wave of occupancy)
 		decltype(prep(0)) ready[CHUNK];
 #pragma unroll
 		for (int i = 0; i < CHUNK; ++i) { // the first round's loads fly during the butterflies
 			const int e = i/G, c = i - G*e;
-			ready[i] = prep(t + 256*(e + 4*c));
+			ready[i] = prep(t + 256*(e + RA*c));
 		}
 		dftLast<SIGN, R3>(u);
 #pragma unroll
@@ -369,13 +401,13 @@ __device__ __forceinline__ void fftFast(float2 *lds, const float4 *__restrict__ 
 #pragma unroll
 				for (int i = 0; i < CHUNK; ++i) {
 					const int pos = p0 + i, e = pos/G, c = pos - G*e;
-					if (pos < R3) ready[i] = prep(t + 256*(e + 4*c));
+					if (pos < R3) ready[i] = prep(t + 256*(e + RA*c));
 				}
 			}
 #pragma unroll
 			for (int i = 0; i < CHUNK; ++i) {
 				const int pos = p0 + i, e = pos/G, c = pos - G*e;
-				if (pos < R3) store(t + 256*(e + 4*c), u[pos], ready[i]);
+				if (pos < R3) store(t + 256*(e + RA*c), u[pos], ready[i]);
 			}
 		}
 	}
@@ -2998,8 +3030,12 @@ void launchEnergy(const DevBatch &d, const IoArgs &io, int sBase, int nStreams, 
 void launchAnalyse(const DevBatch &d, const IoArgs &io, int sBase, int nStreams, int hopBase, int tileHops, hipStream_t st) {
 	const dim3 grid(tileHops, d.C*2, nStreams);
 	const size_t fastLds = ((size_t)d.M + d.M/16)*sizeof(float2);
-	if (d.M == 256*12) { hipLaunchKernelGGL(kAnalyseFast<12>, grid, dim3(256), fastLds, st, d, io, sBase, hopBase); return; }
-	if (d.M == 256*20) { hipLaunchKernelGGL(kAnalyseFast<20>, grid, dim3(320), fastLds, st, d, io, sBase, hopBase); return; }
+	if (!d.noFastFft) { // every preset: presetCheaper at 44.1 / 48 kHz, presetDefault at 44.1 / 48 kHz, presetCheaper at 88.2 / 96 kHz, presetDefault at 88.2 / 96 kHz
+		if (d.M == 256*10) { hipLaunchKernelGGL(kAnalyseFast<10>, grid, dim3(256), fastLds, st, d, io, sBase, hopBase); return; }
+		if (d.M == 256*12) { hipLaunchKernelGGL(kAnalyseFast<12>, grid, dim3(256), fastLds, st, d, io, sBase, hopBase); return; }
+		if (d.M == 256*20) { hipLaunchKernelGGL(kAnalyseFast<20>, grid, dim3(320), fastLds, st, d, io, sBase, hopBase); return; }
+		if (d.M == 256*24) { hipLaunchKernelGGL(kAnalyseFast<24>, grid, dim3(384), fastLds, st, d, io, sBase, hopBase); return; }
+	}
 	size_t lds = 2*(size_t)d.M*sizeof(float2);
 	hipLaunchKernelGGL(kAnalyse, grid, dim3(256), lds, st, d, io, sBase, hopBase);
 }
@@ -3176,8 +3212,12 @@ void launchChain(const DevBatch &d, int sBase, int nStreams, int hopBase, hipStr
 void launchSynth(const DevBatch &d, int sBase, int nStreams, int hopBase, int tileHops, hipStream_t st) {
 	const dim3 grid(tileHops, d.C, nStreams);
 	const size_t fastLds = ((size_t)d.M + d.M/16)*sizeof(float2);
-	if (d.M == 256*12) { hipLaunchKernelGGL(kSynthFast<12>, grid, dim3(256), fastLds, st, d, sBase, hopBase); return; }
-	if (d.M == 256*20) { hipLaunchKernelGGL(kSynthFast<20>, grid, dim3(320), fastLds, st, d, sBase, hopBase); return; }
+	if (!d.noFastFft) {
+		if (d.M == 256*10) { hipLaunchKernelGGL(kSynthFast<10>, grid, dim3(256), fastLds, st, d, sBase, hopBase); return; }
+		if (d.M == 256*12) { hipLaunchKernelGGL(kSynthFast<12>, grid, dim3(256), fastLds, st, d, sBase, hopBase); return; }
+		if (d.M == 256*20) { hipLaunchKernelGGL(kSynthFast<20>, grid, dim3(320), fastLds, st, d, sBase, hopBase); return; }
+		if (d.M == 256*24) { hipLaunchKernelGGL(kSynthFast<24>, grid, dim3(384), fastLds, st, d, sBase, hopBase); return; }
+	}
 	size_t lds = 2*(size_t)d.M*sizeof(float2);
 	hipLaunchKernelGGL(kSynth, grid, dim3(256), lds, st, d, sBase, hopBase);
 }

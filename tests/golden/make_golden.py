@@ -52,6 +52,16 @@ def main():
     # 8. noise, 1.5x (short horizon only is comparable)
     xn = synth_input(2, 2, n, sr)
     case("stretch_1p5_noise", xn, [dict(op="process", inStart=0, inLen=n, outLen=int(n*1.5))])
+    # 9.-11. (round 3) the other preset geometries and the widest stream the product takes:
+    # presetCheaper at 48 kHz (2560 bins: register-blocked FFT 16 x 16 x 10), split computation as the WASM ABI always uses it
+    case("cheaper_48k_stereo", x, [dict(op="process", inStart=0, inLen=n, outLen=int(n*1.25))], preset="cheaper")
+    # presetDefault at 96 kHz (6144 bins: 16 x 16 x 24), -3 st
+    x96 = synth_input(0, 2, 28800, 96000) + 0.5*synth_input(1, 2, 28800, 96000)
+    case("default_96k_stereo", x96, [dict(op="setTransposeSemitones", args=[-3, 0]),
+                                     dict(op="process", inStart=0, inLen=28800, outLen=28800)], sample_rate=96000)
+    # 8 channels (a sine, a chirp and a noise stream among them), 48 kHz presetDefault, 1.5x: the channel lock over 8 channels
+    x8 = np.concatenate([synth_input(0, 3, n, sr), synth_input(1, 3, n, sr)*0.7, synth_input(2, 2, n, sr)], axis=0)
+    case("eight_channels_1p5", x8, [dict(op="process", inStart=0, inLen=n, outLen=int(n*1.5))])
 
 
 def formant_revision_fixtures():
@@ -123,7 +133,23 @@ def scenarios_replay(obj, x, ops):
     return scenarios.replay(obj, x, ops)
 
 
+def only(names):
+    """(re)generate just the named fixtures: python tests/golden/make_golden.py only <name> ..."""
+    global case
+    real = case
+
+    def filtered(name, *a, **k):
+        if name in names:
+            real(name, *a, **k)
+    case = filtered
+    main()
+    case = real
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 2 and sys.argv[1] == "only":
+        only(set(sys.argv[2:]))
+        sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "formants":
         formant_revision_fixtures()
         sys.exit(0)

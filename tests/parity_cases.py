@@ -697,3 +697,32 @@ def case_complex_helpers(lib):
     close = np.abs(got - want) <= np.spacing(np.abs(want).astype(np.float32))
     assert close.all(), (got[~close][:4], want[~close][:4])
     assert (got == want).mean() > 0.999
+
+
+def case_fast_fft_close_to_generic(lib, monkeypatch, presets=(("cheaper", 48000), ("default", 96000), ("default", 48000), ("cheaper", 96000)), seconds=0.5):
+    """The register-blocked FFT (16 x 16 x R3; R3 = 10, 12, 20, 24: every preset geometry of signalsmith-stretch.h:63-68 up to
+    96 kHz) against the generic radix-4/2/3/5 ladder (SMST_NO_FAST_FFT=1) on the same input: two correct FFTs of the same data,
+    1.0x / 0 st so that no phase-vocoder feedback amplifies their rounding difference; both are the identity with delay."""
+    pkg = package()
+    worst = {}
+    for preset, sr in presets:
+        C, n = 2, int(seconds*sr)
+        x = np.stack([synth_input(s, C, n, sr) for s in (0, 1)])
+        outs = []
+        for generic in (False, True):
+            if generic:
+                monkeypatch.setenv("SMST_NO_FAST_FFT", "1")
+            else:
+                monkeypatch.delenv("SMST_NO_FAST_FFT", raising=False)
+            b = pkg.StretchBatch(2, C, preset=preset, sample_rate=sr, lib=lib)
+            outs.append(np.asarray(b.process(x, n)))
+            lat, skip = b.inputLatency() + b.outputLatency(), 2*b.blockSamples()
+            b.close()
+        monkeypatch.delenv("SMST_NO_FAST_FFT", raising=False)
+        d = rel_rms(outs[0], outs[1])
+        assert n - lat - skip > 2000
+        ident = rel_rms(outs[0][:, :, lat + skip:n], x[:, :, skip:n - lat])  # past the first hop (random time factors at 1.0x, see DESIGN)
+        worst["%s@%d" % (preset, sr)] = (d, ident)
+        assert d < 5e-6, (preset, sr, d)
+        assert ident < 2e-6, (preset, sr, ident)
+    return worst

@@ -19,6 +19,9 @@ GOLDEN_TOL = {
     "seek_chunks_stereo": 1e-5,
     "flush_short_stereo": 1e-5,
     "stretch_1p5_noise": 1e-3,
+    "cheaper_48k_stereo": 1e-3,
+    "default_96k_stereo": 1e-3,
+    "eight_channels_1p5": 1e-3,
 }
 
 

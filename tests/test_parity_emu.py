@@ -7,7 +7,7 @@ import scenarios
 
 
 @pytest.mark.parametrize("name", ["identity_mono_44k", "stretch_1p5_stereo", "pitch_p12_stereo", "cheaper_96k_3ch",
-                                  "flush_short_stereo"])
+                                  "flush_short_stereo", "cheaper_48k_stereo", "eight_channels_1p5"])
 def test_golden(emu, ref, name):
     pc.case_golden(emu, ref, name)
 
@@ -123,3 +123,7 @@ def test_freq_map_tables_are_per_stream(emu):
 def test_packed_complex_helpers_emu(emu):
     """tests/emu/smst_complex.h (the CPU stand-in's twin of the product's inline-assembly header) follows the same formulas."""
     pc.case_complex_helpers(emu)
+
+
+def test_fast_fft_close_to_generic_emu(emu, monkeypatch):
+    print(pc.case_fast_fft_close_to_generic(emu, monkeypatch, presets=(("cheaper", 48000), ("default", 96000)), seconds=0.45))

@@ -508,3 +508,8 @@ def test_packed_complex_helpers(hip):
     """csrc/smst_complex.h is inline assembly (v_pk_mul_f32 / v_pk_fma_f32 with op_sel / neg modifiers): operand selects,
     negations and the documented roundings, bit for bit, on the device."""
     pc.case_complex_helpers(hip)
+
+
+def test_fast_fft_every_preset_geometry(hip, monkeypatch):
+    """kAnalyseFast / kSynthFast<R3> for R3 = 10, 12, 20, 24 against the generic FFT ladder and the identity."""
+    print(pc.case_fast_fft_close_to_generic(hip, monkeypatch))
