@@ -127,3 +127,7 @@ def test_packed_complex_helpers_emu(emu):
 
 def test_fast_fft_close_to_generic_emu(emu, monkeypatch):
     print(pc.case_fast_fft_close_to_generic(emu, monkeypatch, presets=(("cheaper", 48000), ("default", 96000)), seconds=0.45))
+
+
+def test_random_time_factor_seeds_emu(emu, ref):
+    print(pc.case_random_time_factor_seeds(emu, ref, streams=3, seconds=0.4, level_tol=0.05))

@@ -405,6 +405,11 @@ def test_teacher_forced(hip, ref, label, cfg, C, stretch, setup):
     w = pc.case_teacher_forced(hip, ref, cfg, C, stretch, "forced " + label, setup=setup, warm_hops=10, forced_hops=8)
     w["equivalent_perturbation"] = 3**0.5*w["analysis"]
     _report("teacher_forced/" + label, w)
+    # a FIXED ceiling beside the bounds that follow the checker's own one-hop sensitivity (which reaches 1.75 on the chirp stream
+    # under formant compensation: 5 x that bounds nothing): Band.output without the 1 % of bins with the largest error, against
+    # the caps of SURVEY App. D.2 iii -- 5e-3 stretch / pitch only, 5e-2 with formant processing
+    assert w["spectrum_trimmed"] <= (pc.CAP_FORMANT if label == "config4b" else pc.CAP_TONAL), w
+    assert w["ring"] > 0 and (w["ring"] <= max(pc.TOL_FORCED_SAMPLES, pc.SELF_FACTOR*w["ring_self"]) or w["flips"] > 0), w
     assert w["equivalent_perturbation"] <= pc.PERTURBATION, w
     assert w["equivalent_perturbation"] >= pc.PERTURBATION/8, w  # ... and PERTURBATION is not much larger than it needs to be
 
@@ -414,6 +419,33 @@ def test_hop_magnitudes_noise_full_length(hip, ref):
     meaningless there after ~100 hops, |output_c[b]| per hop is not."""
     r = pc.case_hop_magnitudes(hip, ref, D48, 2, 1.5, "magnitudes config2 noise", hops=500, streams=(2, 5))
     _report("hop_magnitudes/config2-noise-10s", r)
+
+
+def test_hop_magnitudes_config2_subset_full_length(hip, ref):
+    """The same instrument on ALL eight streams of the config-2 parity subset (sine, chirp and noise, streams 0..7) over the
+    bench's full 10 s: every hop's |output_c[b]| within 1e-4 of the checker's."""
+    r = pc.case_hop_magnitudes(hip, ref, D48, 2, 1.5, "magnitudes config2 subset", hops=500, streams=tuple(range(8)))
+    _report("hop_magnitudes/config2-subset-8x10s", r)
+
+
+def test_hop_decisions_full_length(hip, ref):
+    """Configs 3 and 4b at the bench's own length (10 s: 333 and 250 hops) on six streams each (two of every signal type):
+    per-hop magnitudes, arg-max channel and output map."""
+    # tolerance 2e-4 (1e-4 on the plain path): with a frequency map |output|^2 is an interpolation of the input energies at
+    # map.inputBin, whose fp32 resolution near the top of the spectrum is 2.4e-4 bins; the chirp streams end there (19 kHz after
+    # 10 s), and one ulp of inputBin moves the interpolated energy of their peak bins by more than 1e-4 (measured worst hop:
+    # 1.07e-4, chirp stream, hop 322 of 333, maps agreeing within 2e-3 bins everywhere)
+    r = pc.case_hop_magnitudes(hip, ref, D48, 2, 1.0, "decisions config3 full", setup=_cfg3, hops=333, streams=tuple(range(6)), tol=2e-4)
+    _report("hop_decisions/config3-6x10s", r)
+    r = pc.case_hop_magnitudes(hip, ref, D48, 2, 0.75, "decisions config4b full", setup=_cfg4b, hops=250, streams=tuple(range(6)), tol=2e-4)
+    _report("hop_decisions/config4b-6x10s", r)
+
+
+def test_random_time_factor_seeds(hip, ref):
+    """> 2x stretch at presetDefault / 48 kHz on eight streams: level within 2 % of the checker, same-seed determinism across
+    instances and across batch / single-stream objects."""
+    r = pc.case_random_time_factor_seeds(hip, ref, streams=8, stretch=2.5, seconds=1.5)
+    _report("random_time_factor/d48-8streams-2.5x", r)
 
 
 def test_hop_decisions(hip, ref):
