@@ -15,6 +15,7 @@
 #include <random>
 #include <stdexcept>
 #include <type_traits>
+#include <utility>
 #include <vector>
 
 #include "../smst.h"
@@ -31,8 +32,40 @@ struct SignalsmithStretch {
 		if (smst_create(&handle, seed, defaultDevice()) != SMST_OK) throw std::runtime_error(smst_last_error());
 	}
 	~SignalsmithStretch() { smst_destroy(handle); }
-	SignalsmithStretch(const SignalsmithStretch &) = delete;
-	SignalsmithStretch &operator=(const SignalsmithStretch &) = delete;
+	// The reference is a plain struct: copyable (the copy carries the whole processing state and continues independently) and
+	// movable.  Here a copy is smst_clone -- a second set of device buffers -- and a move hands the handle over.
+	SignalsmithStretch(const SignalsmithStretch &other) : channels(other.channels) {
+		if (smst_clone(&handle, other.handle) != SMST_OK) throw std::runtime_error(smst_last_error());
+	}
+	SignalsmithStretch &operator=(const SignalsmithStretch &other) {
+		if (this != &other) {
+			smst_stretch *copy = nullptr;
+			if (smst_clone(&copy, other.handle) != SMST_OK) throw std::runtime_error(smst_last_error());
+			smst_destroy(handle);
+			handle = copy;
+			channels = other.channels;
+		}
+		return *this;
+	}
+	SignalsmithStretch(SignalsmithStretch &&other) noexcept : handle(other.handle), channels(other.channels),
+		inPlanar(std::move(other.inPlanar)), outPlanar(std::move(other.outPlanar)), inPtrs(std::move(other.inPtrs)), outPtrs(std::move(other.outPtrs)) {
+		other.handle = nullptr;
+		other.channels = 0;
+	}
+	SignalsmithStretch &operator=(SignalsmithStretch &&other) noexcept {
+		if (this != &other) {
+			smst_destroy(handle);
+			handle = other.handle;
+			channels = other.channels;
+			other.handle = nullptr;
+			other.channels = 0;
+		}
+		return *this;
+	}
+	// the GPU new objects are created on (no counterpart in the reference): SMST_DEVICE in the environment, or this setter
+	static void setDefaultDevice(int device) {
+		if (smst_set_default_device(device) != SMST_OK) throw std::runtime_error(smst_last_error());
+	}
 
 	int inputLatency() const { return smst_input_latency(handle); }
 	int outputLatency() const { return smst_output_latency(handle); }
@@ -110,7 +143,7 @@ private:
 	std::vector<const float *> inPtrs;
 	std::vector<float *> outPtrs;
 
-	static int defaultDevice() { return 0; }
+	static int defaultDevice() { return smst_default_device(); }
 	static void check(int rc) {
 		if (rc != SMST_OK) throw std::runtime_error(smst_last_error());
 	}

@@ -61,6 +61,15 @@ typedef struct smst_stretch smst_stretch;
 /* SignalsmithStretch() / SignalsmithStretch(long seed): signalsmith-stretch.h:38-39.  device = HIP ordinal. */
 int smst_create(smst_stretch **out, long seed, int device);
 void smst_destroy(smst_stretch *h);
+/* The reference object is a plain struct and therefore COPYABLE (signalsmith-stretch.h:34-35; e.g. a std::vector of them):
+ * a new handle with the configuration, every parameter and the complete processing state of `src` (input history,
+ * Band.input/.prevInput/.output, Prediction.energy, overlap-add ring, scheduler state) -- both continue identically from
+ * here, independently of each other.  An unconfigured `src` gives an unconfigured copy. */
+int smst_clone(smst_stretch **out, const smst_stretch *src);
+/* The device new single-stream objects of the C++ drop-in header are created on (the reference has no such notion): the
+ * environment variable SMST_DEVICE at first use, 0 if unset, or whatever smst_set_default_device() was given last. */
+int smst_default_device(void);
+int smst_set_default_device(int device);
 
 /* presetDefault / presetCheaper / configure: signalsmith-stretch.h:63-94; web/emscripten/main.cpp:43-51.
  * split: 0/1, or -1 for the preset's own default (false for default, true for cheaper). */
@@ -87,7 +96,10 @@ int smst_set_formant_factor(smst_stretch *h, float multiplier, int compensatePit
 int smst_set_formant_semitones(smst_stretch *h, float semitones, int compensatePitch);
 int smst_set_formant_base(smst_stretch *h, float baseFreq);
 /* setFreqMap (signalsmith-stretch.h:120-122) in table form: table[i] = map((i + 0.5)/(2n)), linear in between
- * and beyond; n = 0 removes the map. */
+ * and beyond; n = 0 removes the map.  In a batch the tables of all streams are stored at ONE resolution, the longest
+ * length any stream has been given: a longer table re-evaluates the rows already stored at its resolution, a shorter one
+ * is evaluated at the batch's (both exact up to rounding: the tables are piecewise linear); when no stream holds a table
+ * any more the next one starts afresh. */
 int smst_set_freq_map_table(smst_stretch *h, const float *table, int n);
 
 /* seek / process / flush: signalsmith-stretch.h:140-165, 210-423, 427-464; main.cpp:68-76 */

@@ -34,6 +34,9 @@ _SIGNATURES = {
     # single-stream
     "smst_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_long, C.c_int]),
     "smst_destroy": (None, [C.c_void_p]),
+    "smst_clone": (C.c_int, [C.POINTER(C.c_void_p), C.c_void_p]),
+    "smst_default_device": (C.c_int, []),
+    "smst_set_default_device": (C.c_int, [C.c_int]),
     "smst_preset_default": (C.c_int, [C.c_void_p, C.c_int, C.c_float, C.c_int]),
     "smst_preset_cheaper": (C.c_int, [C.c_void_p, C.c_int, C.c_float, C.c_int]),
     "smst_configure": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]),
@@ -410,6 +413,16 @@ class SignalsmithStretch:
             self.close()
         except Exception:
             pass
+
+    def clone(self):
+        """A copy of the object as the reference's (implicit) copy constructor makes one: configuration, parameters and the
+        complete processing state; both continue identically and independently (smst_clone)."""
+        other = SignalsmithStretch.__new__(SignalsmithStretch)
+        other.lib, other.channels = self.lib, self.channels
+        h = C.c_void_p()
+        _check(self.lib, self.lib.smst_clone(C.byref(h), self.h))
+        other.h = h
+        return other
 
     def presetDefault(self, channels, sample_rate, split=False):
         self.channels = channels

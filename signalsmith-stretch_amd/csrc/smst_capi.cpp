@@ -5,6 +5,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <memory>
 #include <string>
 #include <vector>
@@ -281,6 +282,39 @@ int smst_create(smst_stretch **out, long seed, int device) {
 	SMST_CATCH
 }
 void smst_destroy(smst_stretch *h) { delete h; }
+
+static int g_defaultDevice = -1;
+int smst_default_device(void) {
+	if (g_defaultDevice < 0) {
+		const char *env = std::getenv("SMST_DEVICE");
+		g_defaultDevice = env ? std::max(0, atoi(env)) : 0;
+	}
+	return g_defaultDevice;
+}
+int smst_set_default_device(int device) {
+	if (device < 0 || device >= smst_device_count()) return fail("device ordinal out of range");
+	g_defaultDevice = device;
+	return SMST_OK;
+}
+int smst_clone(smst_stretch **out, const smst_stretch *src) {
+	if (!out || !src) return fail("null pointer");
+	SMST_TRY
+	std::unique_ptr<smst_stretch> h(new smst_stretch());
+	h->seed = src->seed; h->device = src->device;
+	h->transposeFactor = src->transposeFactor; h->tonalityLimit = src->tonalityLimit; h->transposeSet = src->transposeSet;
+	h->formantFactor = src->formantFactor; h->formantComp = src->formantComp; h->formantBase = src->formantBase;
+	h->mapTable = src->mapTable;
+	if (src->batch) {
+		Batch &e = *src->batch->engine;
+		std::unique_ptr<smst_batch> b(new smst_batch());
+		b->engine.reset(new Batch(1, e.channels(), e.blockSamples(), e.intervalSamples(), e.splitComputation(), src->device, src->seed, e.halfPrecisionState()));
+		b->engine->copyStateFrom(e);
+		h->batch = std::move(b);
+	}
+	*out = h.release();
+	return SMST_OK;
+	SMST_CATCH
+}
 
 static void applyParams(smst_stretch *h) {
 	Batch &e = *h->batch->engine;

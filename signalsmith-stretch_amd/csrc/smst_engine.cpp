@@ -154,6 +154,7 @@ void Batch::construct(const FftPlan &plan, long seed) {
 	if (const char *env = std::getenv("SMST_NO_OVERLAP")) overlap = atoi(env) == 0;
 	noFuse = std::getenv("SMST_NO_FUSE") != nullptr;
 	noSingleHop = std::getenv("SMST_NO_SINGLE_HOP") != nullptr;
+	if (const char *env = std::getenv("SMST_CHECK_LAUNCHES")) checkLaunches = atoi(env) != 0;
 
 	d.S = S; d.C = C; d.B = B; d.I = I; d.M = M; d.N = N; d.L = L; d.T = kTileHops;
 	d.histLen = B + I;
@@ -290,6 +291,8 @@ void Batch::construct(const FftPlan &plan, long seed) {
 		callSets[i].hOutSamples = pinnedAlloc<int>(S);
 		callSets[i].hFlags = pinnedAlloc<int>(S);
 		callSets[i].hEnergy = pinnedAlloc<float>((size_t)S*kEnergyParts);
+		callSets[i].resetBits = devAlloc<int>(S);
+		callSets[i].hResetBits = pinnedAlloc<int>(S);
 	}
 	dSeedWp = devAlloc<float>(d.carryLen);
 	SMST_HIP(hipMemcpy(dSeedWp, seedCarryWp.data(), d.carryLen*sizeof(float), hipMemcpyHostToDevice));
@@ -440,6 +443,7 @@ void Batch::reset() { // signalsmith-stretch.h:49-60
 	SMST_HIP(hipSetDevice(dev));
 	SMST_HIP(hipMemsetAsync(d.stFreq, 0, (size_t)S*2*sizeof(float), st));
 	resetStreams(nullptr, 1 | 2 | 4 | 8);
+	for (auto &lh : lastHop) lh = LastHop();
 	d.histCur = 0;
 	d.carryCur = 0;
 	for (auto &sc : sched) {
@@ -491,26 +495,39 @@ void Batch::setFreqMapTable(int stream, const float *table, int n) { // table fo
 	if (n < 2) throw Error("frequency-map table needs at least 2 points");
 	if (stream >= S) throw Error("stream index out of range");
 	SMST_HIP(hipSetDevice(dev));
-	if (d.mapTableLen == 0) { // the first table fixes the batch's resolution; the tables are per stream and independent
+	// One resolution per batch = the LONGEST table any stream has been given so far: a longer table makes the batch's array grow
+	// and the rows it already holds are re-evaluated at the finer resolution (exact for the piecewise-linear functions they are, up
+	// to rounding); a shorter table is evaluated at the batch's resolution.  When no stream holds a table any more the next one
+	// starts afresh.  (Round 2 froze the first table's length: a 2-point table followed by a 1024-point one collapsed the latter.)
+	auto evaluate = [](const float *t, int tn, float freq) {
+		float pos = freq*2*float(tn) - 0.5f;
+		if (pos <= 0) return t[0] + (t[1] - t[0])*pos;
+		if (pos >= tn - 1) return t[tn - 1] + (t[tn - 1] - t[tn - 2])*(pos - (tn - 1));
+		const int lo = int(std::floor(pos));
+		return t[lo] + (t[lo + 1] - t[lo])*(pos - lo);
+	};
+	bool anyCustom = false;
+	for (int s = 0; s < S; ++s) anyCustom = anyCustom || params[s].hasCustomMap;
+	if (!anyCustom) d.mapTableLen = 0;
+	if (n > d.mapTableLen) {
+		std::vector<float> grown((size_t)S*n, 0.0f);
+		for (int s = 0; s < S && d.mapTableLen > 0; ++s) {
+			if (!params[s].hasCustomMap) continue;
+			for (int i = 0; i < n; ++i) grown[(size_t)s*n + i] = evaluate(hostMapTable.data() + (size_t)s*d.mapTableLen, d.mapTableLen, (i + 0.5f)/(2*float(n)));
+		}
+		SMST_HIP(hipStreamSynchronize(st)); // kernels of earlier calls may still read the old array
+		if (dMapTable) devFree(dMapTable);
 		dMapTable = devAlloc<float>((size_t)S*n);
-		hostMapTable.assign((size_t)S*n, 0.0f);
+		hostMapTable.swap(grown);
 		d.mapTableLen = n;
 		d.mapTable = dMapTable;
 	}
 	const int len = d.mapTableLen;
 	std::vector<float> resampled;
 	const float *src = table;
-	if (n != len) { // another length: evaluate the incoming table (its own interpolation rule) at this batch's sample points
+	if (n != len) { // a shorter table: evaluate it (its own interpolation rule) at this batch's sample points
 		resampled.resize(len);
-		for (int i = 0; i < len; ++i) {
-			const float freq = (i + 0.5f)/(2*float(len));
-			float pos = freq*2*float(n) - 0.5f;
-			float v;
-			if (pos <= 0) v = table[0] + (table[1] - table[0])*pos;
-			else if (pos >= n - 1) v = table[n - 1] + (table[n - 1] - table[n - 2])*(pos - (n - 1));
-			else { const int lo = int(std::floor(pos)); v = table[lo] + (table[lo + 1] - table[lo])*(pos - lo); }
-			resampled[i] = v;
-		}
+		for (int i = 0; i < len; ++i) resampled[i] = evaluate(table, n, (i + 0.5f)/(2*float(len)));
 		src = resampled.data();
 	}
 	forStreams(S, stream, [&](int s) {
@@ -520,6 +537,12 @@ void Batch::setFreqMapTable(int stream, const float *table, int n) { // table fo
 	SMST_HIP(hipStreamSynchronize(st)); // kernels of earlier calls may still read the old table
 	SMST_HIP(hipMemcpy(dMapTable, hostMapTable.data(), hostMapTable.size()*sizeof(float), hipMemcpyHostToDevice));
 	paramsDirty = true;
+}
+
+void Batch::checkLaunch(const char *what) {
+	if (!checkLaunches) return;
+	const hipError_t e = hipGetLastError();
+	if (e != hipSuccess) throw Error(std::string("launch failed (") + what + "): " + hipGetErrorString(e), true);
 }
 
 template <typename F> void Batch::timed(double &acc, F &&f) {
@@ -611,14 +634,16 @@ void Batch::process(const float *in, long long inSS, long long inCS, const int *
 
 	// K0, pass 1: silence gate (signalsmith-stretch.h:231-278) and the number of hops each stream fires in this call
 	int *passFlags = cs.hFlags;
+	int *clearBits = cs.hResetBits; // per CALL (pinned + its own device copy): a shared buffer could be overwritten by the next call's upload before this call's kResetStreams has run
 	bool anyPass = false, anyClear = false;
 	int maxHops = 0;
 	for (int s = 0; s < S; ++s) {
 		passFlags[s] = 0;
 		hopFirst[s] = 0;
 		hopCount[s] = 0;
-		resetBitsV[s] = 0;
+		clearBits[s] = 0;
 		if (active && !active[s]) continue;
+		lastHop[s].slot = -1; // smst_batch_debug_get_map reports the newest hop of THIS call only
 		StreamSched &sc = sched[s];
 		float e = 0;
 		for (int p = 0; p < kEnergyParts; ++p) e += cs.hEnergy[(size_t)s*kEnergyParts + p];
@@ -627,7 +652,7 @@ void Batch::process(const float *in, long long inSS, long long inCS, const int *
 				if (sc.silenceFirst) {
 					sc.silenceFirst = false;
 					sc.samplesSinceLast = SIZE_MAX; // blockProcess = {}
-					resetBitsV[s] = 2 | 4 | 8;      // Band.input / .prevInput / .output := 0
+					clearBits[s] = 2 | 4 | 8;       // Band.input / .prevInput / .output := 0
 					anyClear = true;
 				}
 				passFlags[s] = 1;
@@ -645,7 +670,10 @@ void Batch::process(const float *in, long long inSS, long long inCS, const int *
 		hopCount[s] = (nOut[s] > first) ? (nOut[s] - first + I - 1)/I : 0;
 		maxHops = std::max(maxHops, hopCount[s]);
 	}
-	if (anyClear) resetStreams(resetBitsV.data(), 0);
+	if (anyClear) { // asynchronous: the masks travel on `st`, ahead of the launch that reads them
+		SMST_HIP(hipMemcpyAsync(cs.resetBits, clearBits, S*sizeof(int), hipMemcpyHostToDevice, st));
+		launchResetStreams(d, cs.resetBits, 0, dSeedWp, st);
+	}
 	const int nTiles = std::max(1, (maxHops + T - 1)/T);
 	const int hopStride = nTiles*T;
 	const int nSub = (S + subS - 1)/subS;
@@ -840,6 +868,7 @@ void Batch::process(const float *in, long long inSS, long long inCS, const int *
 				// reader of the OLD state has run: in the fused path the producers inside kVocoder still read it
 				if (!fused) timed(timings.otherMs, [&] { launchCarryFeed(dd, sBase, ns, hopBase, th[2] != 0, sF); });
 			}
+			checkLaunch("analysis / feed-forward kernels");
 			if (!serial) {
 				SMST_HIP(hipEventRecord(evFeed[slot], sF));
 				SMST_HIP(hipStreamWaitEvent(sC, evFeed[slot], 0));
@@ -868,12 +897,14 @@ void Batch::process(const float *in, long long inSS, long long inCS, const int *
 					launchCarryOut(dd, sBase, ns, sC);
 				});
 			}
+			checkLaunch("bin recurrence");
 			if (!serial) {
 				SMST_HIP(hipEventRecord(evChain[slot], sC));
 				SMST_HIP(hipStreamWaitEvent(sS, evChain[slot], 0));
 			}
 			if (th[0]) timed(timings.synthMs, [&] { launchSynth(dd, sBase, ns, hopBase, tileHops, sS); if (profiling) ++timings.synthLaunches; });
 			timed(timings.emitMs, [&] { launchEmit(dd, io, sBase, ns, t, maxSpanV[(size_t)sub*nTiles + t], sS); if (profiling) ++timings.emitLaunches; });
+			checkLaunch("synthesis / emission");
 			if (!serial) SMST_HIP(hipEventRecord(evSynth[slot], sS));
 		}
 	}
@@ -987,7 +1018,7 @@ void Batch::flush(float *out, long long outSS, long long outCS, const int *outSa
 	IoArgs io{nullptr, out, 0, 0, outSS, outCS, dInSamples, dOutSamples};
 	launchFlushTail(d, io, dAux0, dAux1, st);
 	// stft.reset(0.1) + zero prevInput/output (:456-463)
-	for (int s = 0; s < S; ++s) resetBitsV[s] = on[s] ? (1 | 4 | 8) : 0;
+	for (int s = 0; s < S; ++s) { resetBitsV[s] = on[s] ? (1 | 4 | 8) : 0; if (on[s]) lastHop[s] = LastHop(); }
 	resetStreams(resetBitsV.data(), 0);
 	SMST_HIP(hipGetLastError());
 }
@@ -1035,6 +1066,41 @@ void Batch::outputSeek(const float *in, long long inSS, long long inCS, const in
 	SMST_HIP(hipStreamSynchronize(st));
 	launchAddPreRoll(d, dScratchOut, outLat, dAux0, st);
 	SMST_HIP(hipGetLastError());
+}
+
+// ---- copy -------------------------------------------------------------------------------------------------
+void Batch::copyStateFrom(Batch &o) {
+	if (o.S != S || o.C != C || o.B != B || o.I != I || o.split != split || o.halfState != halfState) throw Error("copyStateFrom: the two batches differ in geometry");
+	SMST_HIP(hipSetDevice(o.dev));
+	SMST_HIP(hipStreamSynchronize(o.st));
+	SMST_HIP(hipSetDevice(dev));
+	SMST_HIP(hipStreamSynchronize(st));
+	const size_t bandRows = (size_t)S*C*M, scale = halfState ? 2 : 1;
+	auto copy = [&](void *dst, const void *src, size_t bytes) { SMST_HIP(hipMemcpy(dst, src, bytes, hipMemcpyDefault)); };
+	copy(d.stInput, o.d.stInput, bandRows*sizeof(float2));
+	copy(d.stPrev, o.d.stPrev, bandRows*sizeof(float2));
+	copy(d.stOut, o.d.stOut, bandRows*sizeof(float2)/scale);
+	copy(d.stEnergy, o.d.stEnergy, bandRows*sizeof(float)/scale);
+	for (int h = 0; h < 2; ++h) {
+		copy(d.hist[h], o.d.hist[h], (size_t)S*C*d.histLen*sizeof(float));
+		copy(d.carrySum[h], o.d.carrySum[h], (size_t)S*C*d.carryLen*sizeof(float)/scale);
+		copy(d.carryWp[h], o.d.carryWp[h], (size_t)S*d.carryLen*sizeof(float));
+	}
+	copy(d.stFreq, o.d.stFreq, (size_t)S*2*sizeof(float));
+	d.histCur = o.d.histCur;
+	d.carryCur = o.d.carryCur;
+	sched = o.sched;
+	params = o.params;
+	paramsDirty = true;
+	if (o.d.mapTableLen > 0) {
+		if (dMapTable) devFree(dMapTable);
+		dMapTable = devAlloc<float>((size_t)S*o.d.mapTableLen);
+		hostMapTable = o.hostMapTable;
+		SMST_HIP(hipMemcpy(dMapTable, hostMapTable.data(), hostMapTable.size()*sizeof(float), hipMemcpyHostToDevice));
+		d.mapTableLen = o.d.mapTableLen;
+		d.mapTable = dMapTable;
+	}
+	for (auto &lh : lastHop) lh = LastHop();
 }
 
 // ---- test hooks -------------------------------------------------------------------------------------------

@@ -80,6 +80,9 @@ public:
 	void waitForStream(hipStream_t other);
 	void signalStream(hipStream_t other);
 	int subBatchStreams() const { return subS; }
+	// the object is copyable in the reference (a plain struct, signalsmith-stretch.h:34-35): same geometry required; every piece of
+	// carried state, the parameters and the scheduler state of `other` replace this batch's
+	void copyStateFrom(Batch &other);
 
 	// test hooks: copy state rows to the host (which: 0 input, 1 prevInput, 2 output -> 2*C*M floats; 3 energy -> C*M)
 	void debugGetState(int stream, int which, float *dst);
@@ -104,8 +107,8 @@ private:
 	// ... and so does their PINNED host staging (h*): nothing pageable is handed to an async copy, so the only host
 	// synchronisation of a call is the silence-gate readback
 	struct CallSet {
-		int *inSamples, *outSamples, *flags, *tileInfo; HopDesc *hops; EmitDesc *emit;
-		int *hInSamples, *hOutSamples, *hFlags, *hTileInfo; HopDesc *hHops; EmitDesc *hEmit; float *hEnergy;
+		int *inSamples, *outSamples, *flags, *tileInfo, *resetBits; HopDesc *hops; EmitDesc *emit;
+		int *hInSamples, *hOutSamples, *hFlags, *hTileInfo, *hResetBits; HopDesc *hHops; EmitDesc *hEmit; float *hEnergy;
 		size_t hopsCap, emitCap, tileInfoCap;
 		hipEvent_t done, tables; bool used;
 		std::vector<void *> retiredDevice, retiredPinned; // outgrown tables that the previous call may still read
@@ -144,7 +147,9 @@ private:
 	template <typename T> T *pinnedAlloc(size_t count);
 	void pinnedFree(void *p);
 	void releaseAll();
-	void resetStreams(const int *bitsHost, int allBits); // per-stream bit masks (kResetStreams) or null = allBits for all
+	void resetStreams(const int *bitsHost, int allBits); // per-stream bit masks (kResetStreams) or null = allBits for all; synchronous upload (reset / flush)
+	bool checkLaunches = false; // SMST_CHECK_LAUNCHES=1: hipGetLastError() after every launch group of process(), not only at its end
+	void checkLaunch(const char *what);
 	int *dResetBits = nullptr;
 	std::vector<int> resetBitsV;
 	float *dZeros = nullptr;

@@ -1561,10 +1561,24 @@ struct RecordSource {
 	}
 };
 
+// Prediction.energy of the previous hop at a bin: the carried state (fp32 or fp16, by ELEMENT INDEX through the accessor -- the
+// typed pointer into d.stEnergy addresses a half-sized allocation in fp16 mode), hop k-1's (P, E) entries, or -- plain tiles --
+// the squared magnitude of hop k-1's input spectrum
+struct PrevEnergy {
+	bool carried;        // the tile's first hop: the carried state, element carriedBase + bin
+	size_t carriedBase;
+	const float *row;    // inside a mapped tile: third float of hop k-1's 12-byte entries (stride 3)
+	const float2 *input; // inside a plain tile: hop k-1's input spectrum
+	__device__ __forceinline__ float at(const DevBatch &d, int bc) const {
+		if (carried) return loadCarriedEnergy(d, carriedBase + bc);
+		if (input) return cnorm(input[bc]);
+		return row[(size_t)bc*3];
+	}
+};
 // coefficient multiplying the previous hop's final output at bin bx (bx = b+1 or b+L), see the record description
 template <int CH, bool PLAIN>
 __device__ __forceinline__ float2 twistAt(const RecordSource<CH, PLAIN> &src, int mc, int bx, float2 mp, bool rotate, const float2 *in,
-                                          const float2 *pv, const float *EprevRow, int eprevStride, const float2 *inPrevHop, float tfDown, float stepMul,
+                                          const float2 *pv, const PrevEnergy &prevE, float tfDown, float stepMul,
                                           const float2 *rot) {
 	// bx may be one past the last bin for the callers' masked-out cases: every access below clamps; mp = mapAt(min(bx, M-1))
 	const DevBatch &d = src.d;
@@ -1587,10 +1601,7 @@ __device__ __forceinline__ float2 twistAt(const RecordSource<CH, PLAIN> &src, in
 	const float2 Px = make_float2(pe.x, pe.y);
 	const float2 TW = cmul(rotB, cmulc(Px, Q));
 	const float eNow = pe.z;
-	float ePrev;
-	if (PLAIN && inPrevHop) ePrev = cnorm(inPrevHop[bc]);
-	else if (d.halfState && eprevStride == 1) ePrev = loadCarriedEnergy(d, (size_t)(EprevRow - d.stEnergy) + bc); // the tile's first hop: carried fp16 state
-	else ePrev = EprevRow[(size_t)bc*eprevStride];
+	const float ePrev = prevE.at(d, bc);
 	const float den = fmaxf(ePrev, eNow) + 1e-15f; // :716
 	const float2 down = cmulc(Px, lerpBand(in, lerpIndex(mp.x - stepMul*tfDown), M));
 	const float2 r = cmulc(TW, down);
@@ -1655,15 +1666,16 @@ __device__ __forceinline__ void computeRecord(const DevBatch &d, const HopDesc &
 		const float2 *in = src.inRow(cm);
 		const float2 *pv = prevRow(d, hd, s, k, sg, cm);
 		// Prediction.energy of the previous hop: the carried state for the tile's first hop, else hop k-1's
-		// the carried state is a plain float row; inside the tile the energy is the third float of hop k-1's (P, E) entries
-		const float *EprevRow = (k == 0) ? d.stEnergy + stateRow(d, sg, cm) : (PLAIN ? nullptr : reinterpret_cast<const float *>(d.PE + rowOf(d, s, k - 1, cm)) + 2);
-		const int eprevStride = (k == 0) ? 1 : 3;
-		const float2 *inPrevHop = (PLAIN && k > 0) ? inputRow(d, hp, s, sg, cm) : nullptr;
+		PrevEnergy prevE;
+		prevE.carried = k == 0;
+		prevE.carriedBase = stateRow(d, sg, cm);
+		prevE.input = (PLAIN && k > 0) ? inputRow(d, hp, s, sg, cm) : nullptr;
+		prevE.row = (!PLAIN && k > 0) ? reinterpret_cast<const float *>(d.PE + rowOf(d, s, k - 1, cm)) + 2 : nullptr;
 		const float2 zero = make_float2(0.f, 0.f);
 		A = cmulc(Pcm, lerpBand(in, lerpIndex(mp.x - tfUp), M));
 		B = cmulc(Pcm, lerpBand(in, lerpIndex(mp.x - L*tfUp), M));
-		Cc = twistAt<CH, PLAIN>(src, cm, b + 1, mp1, rotate, in, pv, EprevRow, eprevStride, inPrevHop, tfDn, 1.0f, rot);
-		Dc = twistAt<CH, PLAIN>(src, cm, b + L, mpL, rotate, in, pv, EprevRow, eprevStride, inPrevHop, tfDn, float(L), rot);
+		Cc = twistAt<CH, PLAIN>(src, cm, b + 1, mp1, rotate, in, pv, prevE, tfDn, 1.0f, rot);
+		Dc = twistAt<CH, PLAIN>(src, cm, b + L, mpL, rotate, in, pv, prevE, tfDn, float(L), rot);
 		if (!(b > 0)) A = zero;      // :748
 		if (!(b >= L)) B = zero;     // :756
 		if (!(b < M - 1)) Cc = zero; // :765
@@ -1924,13 +1936,10 @@ struct StageGeom {
 	static constexpr int ROWS = 9; // local rows -1..7
 };
 
-// two adjacent entries of a carried Prediction.energy row (`row` points into d.stEnergy as if it were fp32; element index i)
-__device__ __forceinline__ float2 loadEnergyPair(const DevBatch &d, const float *row, int i) {
-	if (d.halfState) {
-		const size_t e = (size_t)(row - d.stEnergy) + i;
-		return make_float2(loadCarriedEnergy(d, e), loadCarriedEnergy(d, e + 1));
-	}
-	return *reinterpret_cast<const float2 *>(row + i);
+// two adjacent entries of the carried Prediction.energy, by element index (fp32: one 8-byte load)
+__device__ __forceinline__ float2 loadEnergyPair(const DevBatch &d, size_t e) {
+	if (d.halfState) return make_float2(loadCarriedEnergy(d, e), loadCarriedEnergy(d, e + 1));
+	return *reinterpret_cast<const float2 *>(d.stEnergy + e);
 }
 
 template <int CH, int L, int NB, int NP>
@@ -1945,8 +1954,8 @@ __device__ __forceinline__ void vocoderProduceStaged(const DevBatch &d, int s, i
 	const float2 *psrc[G::LOADS];
 	int pbin[G::LOADS], plds[G::LOADS];
 	bool pok[G::LOADS], pen[G::LOADS]; // piece wanted / piece is carried Prediction.energy (row above the tile's first hop)
-	const float *carriedEnergy = d.stEnergy + stateRow(d, sg, 0); // [C][M]
-	const float *penergy = carriedEnergy;
+	const size_t carriedEnergy = stateRow(d, sg, 0); // element index of the stream's carried Prediction.energy, [C][M]
+	size_t penergy = carriedEnergy;
 #pragma unroll
 	for (int i = 0; i < G::LOADS; ++i) {
 		const int q = k + 64*i;
@@ -1998,7 +2007,7 @@ __device__ __forceinline__ void vocoderProduceStaged(const DevBatch &d, int s, i
 			for (int i = 0; i < G::LOADS; ++i) {
 				const int sb = BS*n + pbin[i];
 				v[i] = *reinterpret_cast<const float4 *>(psrc[i] + sb); // 8-byte aligned; dword alignment suffices on gfx9
-				if (i == G::LOADS - 1 && pen[i]) ve = loadEnergyPair(d, penergy, sb);
+				if (i == G::LOADS - 1 && pen[i]) ve = loadEnergyPair(d, penergy + sb);
 			}
 			return;
 		}
@@ -2009,7 +2018,7 @@ __device__ __forceinline__ void vocoderProduceStaged(const DevBatch &d, int s, i
 			v[i] = *reinterpret_cast<const float4 *>(psrc[i] + cb); // 8-byte aligned; dword alignment suffices on gfx9
 			// pieces of the carried energy (row above hop 0; only the last slot can hold them) are 2 floats: kept in their own
 			// registers until park(), so that no select waits for the loads here
-			if (i == G::LOADS - 1 && pen[i]) ve = loadEnergyPair(d, penergy, cb);
+			if (i == G::LOADS - 1 && pen[i]) ve = loadEnergyPair(d, penergy + cb);
 		}
 	};
 	auto park = [&](int n) {

@@ -50,6 +50,16 @@ SOURCE = textwrap.dedent(r'''
         stretch.flush(outPtr, 512, 1.0f);
         bool ok = stretch.exact(in, 8192, out, 8192);  // :468
         static_assert(Stretch::version[0] == 1 && Stretch::version[1] == 3, "reference API version");   // :36
+        // the reference class is a plain struct: value semantics (:34-35)
+        Stretch copy(stretch);                         // copy constructor: carries the processing state
+        copy = seeded;                                 // copy assignment
+        Stretch moved(std::move(copy));                // move
+        moved = Stretch(7L);
+        std::vector<Stretch> pool(3);                  // containers of them
+        pool.push_back(stretch);
+        pool.emplace_back(99L);
+        static_assert(std::is_copy_constructible<Stretch>::value && std::is_nothrow_move_constructible<Stretch>::value, "value semantics");
+        Stretch::setDefaultDevice(0);
         return (a > 0 && ok && split) ? 0 : 1;
     }
 ''')

@@ -90,8 +90,8 @@ def test_half_state(emu, ref):
 
 
 def test_freq_map_tables_are_per_stream(emu):
-    """setFreqMap in table form: every stream keeps its own table, whatever its length (a table of another length than the
-    batch's first one is resampled).  Two tables of different length that describe the SAME linear map give the same
+    """setFreqMap in table form: every stream keeps its own table, whatever its length (the batch stores one resolution, the
+    longest table's; shorter ones are evaluated at it).  Two tables of different length that describe the SAME linear map give the same
     output, and neither disturbs a third stream that has no map (the reference's instances share nothing)."""
     import numpy as np
     from conftest import package, synth_input
@@ -113,7 +113,9 @@ def test_freq_map_tables_are_per_stream(emu):
     one.setFreqMapTable(t64)
     y_one = one.process(x[None], n)
     one.close()
-    assert np.array_equal(y[0], y_one[0])                       # stream 0 kept its map
+    # stream 0 kept its map: its 64-point row was re-evaluated at the longer table's resolution (one resolution per batch, the
+    # longest; include/smst.h) -- the same piecewise-linear function up to rounding
+    assert np.sqrt(np.mean((np.asarray(y[0]) - np.asarray(y_one[0]))**2)/np.mean(np.asarray(y_one[0])**2)) < 1e-4
     assert np.array_equal(y[2], y_plain[0])                     # stream 2 has none
     err = np.sqrt(np.mean((y[1] - y[0])**2)/np.mean(y[0]**2))   # same linear map, resampled: same result up to the table's own rounding
     assert err < 1e-3, err
@@ -131,3 +133,19 @@ def test_fast_fft_close_to_generic_emu(emu, monkeypatch):
 
 def test_random_time_factor_seeds_emu(emu, ref):
     print(pc.case_random_time_factor_seeds(emu, ref, streams=3, seconds=0.4, level_tol=0.05))
+
+
+def test_clone_emu(emu):
+    pc.case_clone(emu)
+
+
+def test_map_table_lengths_emu(emu):
+    pc.case_map_table_lengths(emu)
+
+
+def test_debug_map_is_of_the_last_call_emu(emu):
+    pc.case_debug_map_is_of_the_last_call(emu)
+
+
+def test_split_mid_interval_flush_emu(emu, ref):
+    print(pc.case_split_mid_interval_flush(emu, ref))

@@ -545,3 +545,19 @@ def test_packed_complex_helpers(hip):
 def test_fast_fft_every_preset_geometry(hip, monkeypatch):
     """kAnalyseFast / kSynthFast<R3> for R3 = 10, 12, 20, 24 against the generic FFT ladder and the identity."""
     print(pc.case_fast_fft_close_to_generic(hip, monkeypatch))
+
+
+def test_clone(hip):
+    pc.case_clone(hip)
+
+
+def test_map_table_lengths(hip):
+    pc.case_map_table_lengths(hip)
+
+
+def test_debug_map_is_of_the_last_call(hip):
+    pc.case_debug_map_is_of_the_last_call(hip)
+
+
+def test_split_mid_interval_flush(hip, ref):
+    print(pc.case_split_mid_interval_flush(hip, ref))
