@@ -20,6 +20,7 @@ struct DevBatch {
 	int noFeedFusion;             // SMST_NO_FEED_FUSION=1: pass A stays its own kernel (kPredictA) -- cross-check of the folded form
 	int feedSerial;               // SMST_FEED_SERIAL: bin-by-bin feed recurrences (kFeedSerial) instead of the scan form
 	int halfState;                // carried Band.output / Prediction.energy / overlap-add sums stored in fp16 (BASELINE config 5 "fp16 internal")
+	int fftLean;                  // register-blocked FFT kernels with the smaller tables (SMST_FFT_TABLES=full switches back: cross-check / A-B)
 	int noFastFft;                // SMST_NO_FAST_FFT: the generic radix-4/2/3/5 ladder even where a register-blocked FFT exists (cross-check)
 	int noStage;                  // SMST_NO_STAGE: producers of the fused kernel gather from HBM even where staging applies
 	FftPlan plan;
@@ -32,6 +33,8 @@ struct DevBatch {
 	const float4 *win4;        // (winA[m], winB[m]) interleaved: one 16-byte load per element in the fast analysis kernel
 	const float4 *synTab;      // (halfTw[m], window[m+B/2] or 0, window[m-M+B/2] or 0): one 16-byte load per synthesis output
 	const float4 *twA4, *twB4; // stage twiddles of the register-blocked FFT, rows (2i, 2i+1) paired: [8][16*R3], [8][R3]
+	const float4 *twA6;        // lean form of twA4: (w^1, w^2), (w^3, w^4), (w^8, w^12) per thread, [3][16*R3]
+	const float2 *win2, *syn2; // lean forms of win4 / synTab: the two window samples of an element only, [M]
 	const float *window;   // analysis == synthesis window (Kaiser, perfect reconstruction)
 	const float *wprod;    // window[i]^2 * N
 	// per-stream state

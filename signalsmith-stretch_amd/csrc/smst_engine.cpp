@@ -173,6 +173,8 @@ void Batch::construct(const FftPlan &plan, long seed) {
 	if (const char *env = std::getenv("SMST_NO_FEED_FUSION")) d.noFeedFusion = atoi(env);
 	d.noStage = std::getenv("SMST_NO_STAGE") != nullptr;
 	d.noFastFft = std::getenv("SMST_NO_FAST_FFT") != nullptr;
+	d.fftLean = 1;
+	if (const char *env = std::getenv("SMST_FFT_TABLES")) d.fftLean = std::string(env) != "full";
 	d.feedSerial = std::getenv("SMST_FEED_SERIAL") != nullptr;
 
 	// constant tables
@@ -232,7 +234,18 @@ void Batch::construct(const FftPlan &plan, long seed) {
 		}
 		d.win4 = static_cast<float4 *>(upload(w4.data(), M*sizeof(float4)));
 		d.synTab = static_cast<float4 *>(upload(st4.data(), M*sizeof(float4)));
+		{ // lean tables: the window samples alone (the modulation e^{-i pi m/N} is generated from halfTw[t] and constants)
+			std::vector<float2> w2(M), s2(M);
+			for (int m = 0; m < M; ++m) {
+				const float a = (m < B - halfB) ? win[m + halfB] : 0.0f, b = (m >= M - halfB) ? win[m - M + halfB] : 0.0f;
+				w2[m] = make_float2(a, b);
+				s2[m] = make_float2(a, b);
+			}
+			d.win2 = static_cast<float2 *>(upload(w2.data(), M*sizeof(float2)));
+			d.syn2 = static_cast<float2 *>(upload(s2.data(), M*sizeof(float2)));
+		}
 		d.twA = d.twB = nullptr;
+		d.twA4 = d.twB4 = d.twA6 = nullptr;
 		if (M%256 == 0 && (M/256 == 10 || M/256 == 12 || M/256 == 20 || M/256 == 24)) { // the register-blocked FFT's sizes: 16 x 16 x R3
 			const int R3 = M/256, MA = 16*R3;
 			std::vector<float2> ta((size_t)15*MA), tb((size_t)15*R3);
@@ -259,6 +272,14 @@ void Batch::construct(const FftPlan &plan, long seed) {
 					tb4[(size_t)i*R3 + p] = make_float4(lo.x, lo.y, hi.x, hi.y);
 				}
 			}
+			std::vector<float4> ta6((size_t)3*MA);
+			for (int p = 0; p < MA; ++p) {
+				auto tw = [&](int n) { return ta[(size_t)(n - 1)*MA + p]; };
+				ta6[p] = make_float4(tw(1).x, tw(1).y, tw(2).x, tw(2).y);
+				ta6[(size_t)MA + p] = make_float4(tw(3).x, tw(3).y, tw(4).x, tw(4).y);
+				ta6[(size_t)2*MA + p] = make_float4(tw(8).x, tw(8).y, tw(12).x, tw(12).y);
+			}
+			d.twA6 = static_cast<float4 *>(upload(ta6.data(), ta6.size()*sizeof(float4)));
 			d.twA4 = static_cast<float4 *>(upload(ta4.data(), ta4.size()*sizeof(float4)));
 			d.twB4 = static_cast<float4 *>(upload(tb4.data(), tb4.size()*sizeof(float4)));
 		}

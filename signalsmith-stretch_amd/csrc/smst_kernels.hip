@@ -328,7 +328,11 @@ __device__ __forceinline__ void dftLast(float2 (&v)[R3]) {
 // lds: H + H/16 float2.  All threads of the block must call this (it synchronises).
 // prep(idx) -> any value: called for ALL outputs of a thread before the first store(idx, value, prepared), so whatever it
 // loads is in flight together (a load placed inside `store` is not moved above the preceding stores by the compiler).
-template <int SIGN, int R3, typename Load, typename Prep, typename Store>
+// LEAN: fewer table bytes per frame (the tables are L2-resident, but 73 KB of them per frame crossed the CU's 64-B/clk vector
+// memory path beside 48 KB of data -- ablation in DESIGN.md: tables held constant took 0.9 ms per step off the analysis and 0.4 off
+// the synthesis).  The 15 stage-A twiddles w^n come from six loaded ones (w^1..w^4, w^8, w^12: three 16-byte loads instead of
+// eight) and nine products of two of them: one extra rounding each.
+template <int SIGN, int R3, bool LEAN, typename Load, typename Prep, typename Store>
 __device__ __forceinline__ void fftFast(float2 *lds, const float4 *__restrict__ twA, const float4 *__restrict__ twB, Load load, Prep prep, Store store) {
 	constexpr int MA = 16*R3;
 	const int t = threadIdx.x;
@@ -337,20 +341,34 @@ __device__ __forceinline__ void fftFast(float2 *lds, const float4 *__restrict__ 
 	if (t < MA) {
 #pragma unroll
 		for (int k = 0; k < 16; ++k) v[k] = load(t + MA*k, k);
-		float4 wA[8]; // the 15 stage twiddles, two per 16-byte load, in flight during the butterflies
+		float2 w[16]; // w[n] = w_H^(n t) (conjugated for the inverse transform)
+		if constexpr (LEAN) {
+			const float4 a = twA[t], b = twA[MA + t], c = twA[2*MA + t]; // (w1, w2) (w3, w4) (w8, w12)
+			const float sg = (SIGN > 0) ? -1.0f : 1.0f;
+			w[1] = make_float2(a.x, sg*a.y); w[2] = make_float2(a.z, sg*a.w); w[3] = make_float2(b.x, sg*b.y); w[4] = make_float2(b.z, sg*b.w);
+			w[8] = make_float2(c.x, sg*c.y); w[12] = make_float2(c.z, sg*c.w);
 #pragma unroll
-		for (int i = 0; i < 8; ++i) wA[i] = twA[i*MA + t];
+			for (int hi = 4; hi <= 12; hi += 4) {
+#pragma unroll
+				for (int lo = 1; lo < 4; ++lo) w[hi + lo] = cmulPlain(w[hi], w[lo]);
+			}
+		} else {
+			float4 wA[8]; // the 15 stage twiddles, two per 16-byte load, in flight during the butterflies
+#pragma unroll
+			for (int i = 0; i < 8; ++i) wA[i] = twA[i*MA + t];
+#pragma unroll
+			for (int n = 1; n < 16; ++n) {
+				const float4 pr = wA[(n - 1) >> 1];
+				w[n] = ((n - 1) & 1) ? make_float2(pr.z, pr.w) : make_float2(pr.x, pr.y);
+				if (SIGN > 0) w[n].y = -w[n].y;
+			}
+		}
 		dft16<SIGN>(v);
 #pragma unroll
 		for (int pos = 0; pos < 16; ++pos) {
 			const int n = (pos >> 2) + 4*(pos & 3);
 			float2 val = v[pos];
-			if (n > 0) {
-				const float4 pr = wA[(n - 1) >> 1];
-				float2 w = ((n - 1) & 1) ? make_float2(pr.z, pr.w) : make_float2(pr.x, pr.y);
-				if (SIGN > 0) w.y = -w.y;
-				val = cmulPlain(val, w);
-			}
+			if (n > 0) val = cmulPlain(val, w[n]);
 			lds[17*t + n] = val; // padded index of 16 t + n
 		}
 	}
@@ -388,11 +406,11 @@ __device__ __forceinline__ void fftFast(float2 *lds, const float4 *__restrict__ 
 #pragma unroll
 		for (int k = 0; k < R3; ++k) u[k] = lds[t + 256*k];
 		constexpr int CHUNK = R3 <= 12 ? R3 : (R3 == 24 ? 6 : 5); // outputs prepared ahead of their stores (R3 = 20 / 24: four rounds, or the registers cost a wave of occupancy)
-		decltype(prep(0)) ready[CHUNK];
+		decltype(prep(0, 0)) ready[CHUNK];
 #pragma unroll
 		for (int i = 0; i < CHUNK; ++i) { // the first round's loads fly during the butterflies
 			const int e = i/G, c = i - G*e;
-			ready[i] = prep(t + 256*(e + RA*c));
+			ready[i] = prep(t + 256*(e + RA*c), e + RA*c);
 		}
 		dftLast<SIGN, R3>(u);
 #pragma unroll
@@ -401,19 +419,19 @@ __device__ __forceinline__ void fftFast(float2 *lds, const float4 *__restrict__ 
 #pragma unroll
 				for (int i = 0; i < CHUNK; ++i) {
 					const int pos = p0 + i, e = pos/G, c = pos - G*e;
-					if (pos < R3) ready[i] = prep(t + 256*(e + RA*c));
+					if (pos < R3) ready[i] = prep(t + 256*(e + RA*c), e + RA*c);
 				}
 			}
 #pragma unroll
 			for (int i = 0; i < CHUNK; ++i) {
 				const int pos = p0 + i, e = pos/G, c = pos - G*e;
-				if (pos < R3) store(t + 256*(e + RA*c), u[pos], ready[i]);
+				if (pos < R3) store(t + 256*(e + RA*c), u[pos], ready[i], e + RA*c);
 			}
 		}
 	}
 }
 
-template <int R3>
+template <int R3, bool LEAN>
 __global__ __launch_bounds__(16*R3 > 256 ? 16*R3 : 256) __attribute__((amdgpu_waves_per_eu(4, 4))) void kAnalyseFast(DevBatch d, IoArgs io, int sBase, int hopBase) {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smemRaw[];
 	float2 *lds = reinterpret_cast<float2 *>(smemRaw);
@@ -431,8 +449,8 @@ __global__ __launch_bounds__(16*R3 > 256 ? 16*R3 : 256) __attribute__((amdgpu_wa
 	const float *hist = d.hist[d.histCur] + ((size_t)(sBase + s)*d.C + c)*(size_t)d.histLen + d.histLen;
 	const float2 *__restrict__ winA = d.winA, *__restrict__ winB = d.winB;
 	float2 *dst = (which ? d.Xprev : d.Xcur) + rowOf(d, s, k, c);
-	auto prep = [](int) { return 0; };
-	auto store = [&](int j, float2 u, int) {
+	auto prep = [](int, int) { return 0; };
+	auto store = [&](int j, float2 u, int, int) {
 		const int kk = 2*j;
 		if (kk < H) dst[kk] = u;
 		else dst[N - 1 - kk] = cconj(u);
@@ -442,8 +460,26 @@ __global__ __launch_bounds__(16*R3 > 256 ? 16*R3 : 256) __attribute__((amdgpu_wa
 		// the usual case (both presets): the whole window lies in this call's input, and the two halves of the packed
 		// input change validity exactly at element-slot boundaries: slot 0 has no imaginary part, slot 15 no real part
 		const float *x0 = x + base + halfB, *x1 = x + base - H + halfB;
+		if constexpr (LEAN) {
+			// the folded window (w_re, w_im)(m) * e^{-i pi m/N} as TWO floats per element and the modulation generated: element
+			// m = t + MA*slot, and e^{-i pi MA/N} = e^{-i pi/32} whatever the size, so the modulation is halfTw[t] times one of
+			// sixteen constants (8 bytes per element instead of 16; six more multiply-adds per element, one more rounding)
+			const float2 *__restrict__ win2 = d.win2;
+			const float2 hb = d.halfTw[min((int)threadIdx.x, MA - 1)];
+			fftFast<-1, R3, true>(lds, d.twA6, d.twB4,
+				[&](int m, int slot) {
+					const float2 w = win2[m];
+					float2 z = make_float2(0.f, 0.f);
+					if (slot < 15) z.x = x0[m]*w.x;
+					if (slot > 0) z.y = x1[m]*w.y;
+					const float ang = 3.14159265358979323846f*float(slot)/32.0f; // compile-time constant after unrolling
+					const float2 h = cmulPlain(hb, make_float2(__builtin_cosf(ang), -__builtin_sinf(ang)));
+					return cmulPlain(z, h);
+				}, prep, store);
+			return;
+		}
 		const float4 *__restrict__ win4 = d.win4;
-		fftFast<-1, R3>(lds, d.twA4, d.twB4,
+		fftFast<-1, R3, false>(lds, d.twA4, d.twB4,
 			[&](int m, int slot) {
 				// same roundings as the general path below: round(xi*b + round(xr*a)), with the absent half an exact zero
 				const float4 w = win4[m]; // (winA, winB) in one 16-byte load
@@ -454,7 +490,7 @@ __global__ __launch_bounds__(16*R3 > 256 ? 16*R3 : 256) __attribute__((amdgpu_wa
 			}, prep, store);
 		return;
 	}
-	fftFast<-1, R3>(lds, d.twA4, d.twB4,
+	fftFast<-1, R3, LEAN>(lds, LEAN ? d.twA6 : d.twA4, d.twB4,
 		[&](int m, int) {
 			float xr = 0, xi = 0;
 			if (m < B - halfB) { int src = base + m + halfB; xr = (src >= 0) ? x[src] : hist[src]; }
@@ -464,7 +500,7 @@ __global__ __launch_bounds__(16*R3 > 256 ? 16*R3 : 256) __attribute__((amdgpu_wa
 		}, prep, store);
 }
 
-template <int R3>
+template <int R3, bool LEAN>
 __global__ __launch_bounds__(16*R3 > 256 ? 16*R3 : 256) void kSynthFast(DevBatch d, int sBase, int hopBase) {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smemRaw[];
 	float2 *lds = reinterpret_cast<float2 *>(smemRaw);
@@ -474,8 +510,33 @@ __global__ __launch_bounds__(16*R3 > 256 ? 16*R3 : 256) void kSynthFast(DevBatch
 	const int B = d.B, H = d.M, N = d.N, halfB = B/2;
 	const float2 *X = d.OUT + rowOf(d, s, k, c);
 	float *__restrict__ frame = d.frames + ((size_t)((size_t)s*d.T + k)*d.C + c)*(size_t)B;
+	auto loadBin = [&](int j, int) {
+		// one load at a selected address, conjugated afterwards: with a load in each arm of the conditional the
+		// compiler emitted 16 loads each followed by s_waitcnt vmcnt(0) -- sixteen memory round trips per FFT
+		const int kk = 2*j;
+		const bool upper = kk >= H;
+		float2 v = X[upper ? N - 1 - kk : kk];
+		if (upper) v.y = -v.y;
+		return v;
+	};
+	if constexpr (LEAN) {
+		// an output needs e^{+i pi m/N} and its two window samples: the windows as one 8-byte load, the modulation generated --
+		// m = t + 256 j, so it is halfTw[t] times one of R3 constants e^{-i pi j/(2 R3)} (conjugated in the product below)
+		const float2 *__restrict__ syn2 = d.syn2;
+		const float2 hb = d.halfTw[min((int)threadIdx.x, 255)];
+		fftFast<+1, R3, true>(lds, d.twA6, d.twB4, loadBin,
+			[&](int m, int) { return syn2[m]; },
+			[&](int m, float2 u, float2 w, int j) {
+				const float ang = 3.14159265358979323846f*float(j)/float(2*R3); // compile-time constant after unrolling
+				const float2 h = cmulPlain(hb, make_float2(__builtin_cosf(ang), -__builtin_sinf(ang)));
+				const float2 v = cmulcPlain(u, h); // * e^{+i pi m / N}
+				if (m < B - halfB) frame[m + halfB] = (2*v.x)*w.x;
+				if (m >= H - halfB) frame[m - H + halfB] = (2*v.y)*w.y;
+			});
+		return;
+	}
 	const float4 *__restrict__ synTab = d.synTab;
-	fftFast<+1, R3>(lds, d.twA4, d.twB4,
+	fftFast<+1, R3, false>(lds, d.twA4, d.twB4,
 		[&](int j, int) {
 			// one load at a selected address, conjugated afterwards: with a load in each arm of the conditional the
 			// compiler emitted 16 loads each followed by s_waitcnt vmcnt(0) -- sixteen memory round trips per FFT
@@ -485,11 +546,11 @@ __global__ __launch_bounds__(16*R3 > 256 ? 16*R3 : 256) void kSynthFast(DevBatch
 			if (upper) v.y = -v.y;
 			return v;
 		},
-		[&](int m) { // everything an output needs from memory in ONE 16-byte load (twiddle + its two window samples),
+		[&](int m, int) { // everything an output needs from memory in ONE 16-byte load (twiddle + its two window samples),
 			// requested for all of a thread's outputs before the first store
 			return synTab[m];
 		},
-		[&](int m, float2 u, float4 r) {
+		[&](int m, float2 u, float4 r, int) {
 			const float2 v = cmulcPlain(u, make_float2(r.x, r.y)); // * e^{+i pi m / N}
 			if (m < B - halfB) frame[m + halfB] = (2*v.x)*r.z;
 			if (m >= H - halfB) frame[m - H + halfB] = (2*v.y)*r.w;
@@ -3040,10 +3101,10 @@ void launchAnalyse(const DevBatch &d, const IoArgs &io, int sBase, int nStreams,
 	const dim3 grid(tileHops, d.C*2, nStreams);
 	const size_t fastLds = ((size_t)d.M + d.M/16)*sizeof(float2);
 	if (!d.noFastFft) { // every preset: presetCheaper at 44.1 / 48 kHz, presetDefault at 44.1 / 48 kHz, presetCheaper at 88.2 / 96 kHz, presetDefault at 88.2 / 96 kHz
-		if (d.M == 256*10) { hipLaunchKernelGGL(kAnalyseFast<10>, grid, dim3(256), fastLds, st, d, io, sBase, hopBase); return; }
-		if (d.M == 256*12) { hipLaunchKernelGGL(kAnalyseFast<12>, grid, dim3(256), fastLds, st, d, io, sBase, hopBase); return; }
-		if (d.M == 256*20) { hipLaunchKernelGGL(kAnalyseFast<20>, grid, dim3(320), fastLds, st, d, io, sBase, hopBase); return; }
-		if (d.M == 256*24) { hipLaunchKernelGGL(kAnalyseFast<24>, grid, dim3(384), fastLds, st, d, io, sBase, hopBase); return; }
+		if (d.M == 256*10) { if (d.fftLean) hipLaunchKernelGGL((kAnalyseFast<10, true>), grid, dim3(256), fastLds, st, d, io, sBase, hopBase); else hipLaunchKernelGGL((kAnalyseFast<10, false>), grid, dim3(256), fastLds, st, d, io, sBase, hopBase); return; }
+		if (d.M == 256*12) { if (d.fftLean) hipLaunchKernelGGL((kAnalyseFast<12, true>), grid, dim3(256), fastLds, st, d, io, sBase, hopBase); else hipLaunchKernelGGL((kAnalyseFast<12, false>), grid, dim3(256), fastLds, st, d, io, sBase, hopBase); return; }
+		if (d.M == 256*20) { if (d.fftLean) hipLaunchKernelGGL((kAnalyseFast<20, true>), grid, dim3(320), fastLds, st, d, io, sBase, hopBase); else hipLaunchKernelGGL((kAnalyseFast<20, false>), grid, dim3(320), fastLds, st, d, io, sBase, hopBase); return; }
+		if (d.M == 256*24) { if (d.fftLean) hipLaunchKernelGGL((kAnalyseFast<24, true>), grid, dim3(384), fastLds, st, d, io, sBase, hopBase); else hipLaunchKernelGGL((kAnalyseFast<24, false>), grid, dim3(384), fastLds, st, d, io, sBase, hopBase); return; }
 	}
 	size_t lds = 2*(size_t)d.M*sizeof(float2);
 	hipLaunchKernelGGL(kAnalyse, grid, dim3(256), lds, st, d, io, sBase, hopBase);
@@ -3222,10 +3283,10 @@ void launchSynth(const DevBatch &d, int sBase, int nStreams, int hopBase, int ti
 	const dim3 grid(tileHops, d.C, nStreams);
 	const size_t fastLds = ((size_t)d.M + d.M/16)*sizeof(float2);
 	if (!d.noFastFft) {
-		if (d.M == 256*10) { hipLaunchKernelGGL(kSynthFast<10>, grid, dim3(256), fastLds, st, d, sBase, hopBase); return; }
-		if (d.M == 256*12) { hipLaunchKernelGGL(kSynthFast<12>, grid, dim3(256), fastLds, st, d, sBase, hopBase); return; }
-		if (d.M == 256*20) { hipLaunchKernelGGL(kSynthFast<20>, grid, dim3(320), fastLds, st, d, sBase, hopBase); return; }
-		if (d.M == 256*24) { hipLaunchKernelGGL(kSynthFast<24>, grid, dim3(384), fastLds, st, d, sBase, hopBase); return; }
+		if (d.M == 256*10) { if (d.fftLean) hipLaunchKernelGGL((kSynthFast<10, true>), grid, dim3(256), fastLds, st, d, sBase, hopBase); else hipLaunchKernelGGL((kSynthFast<10, false>), grid, dim3(256), fastLds, st, d, sBase, hopBase); return; }
+		if (d.M == 256*12) { if (d.fftLean) hipLaunchKernelGGL((kSynthFast<12, true>), grid, dim3(256), fastLds, st, d, sBase, hopBase); else hipLaunchKernelGGL((kSynthFast<12, false>), grid, dim3(256), fastLds, st, d, sBase, hopBase); return; }
+		if (d.M == 256*20) { if (d.fftLean) hipLaunchKernelGGL((kSynthFast<20, true>), grid, dim3(320), fastLds, st, d, sBase, hopBase); else hipLaunchKernelGGL((kSynthFast<20, false>), grid, dim3(320), fastLds, st, d, sBase, hopBase); return; }
+		if (d.M == 256*24) { if (d.fftLean) hipLaunchKernelGGL((kSynthFast<24, true>), grid, dim3(384), fastLds, st, d, sBase, hopBase); else hipLaunchKernelGGL((kSynthFast<24, false>), grid, dim3(384), fastLds, st, d, sBase, hopBase); return; }
 	}
 	size_t lds = 2*(size_t)d.M*sizeof(float2);
 	hipLaunchKernelGGL(kSynth, grid, dim3(256), lds, st, d, sBase, hopBase);
