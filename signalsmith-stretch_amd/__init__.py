@@ -114,8 +114,8 @@ class StretchError(RuntimeError):
 def bind(cdll):
     """Attach the include/smst.h prototypes to a loaded library object."""
     for name, (res, args) in _SIGNATURES.items():
-        if name.startswith("smst_debug_") and os.environ.get("SMST_LIBRARY") and not hasattr(cdll, name):
-            continue  # an A/B build of an older revision may lack the newest test hook
+        if os.environ.get("SMST_LIBRARY") and not hasattr(cdll, name):
+            continue  # an A/B build of an older revision may lack the newest entry points
         f = getattr(cdll, name)
         f.restype = res
         f.argtypes = args

@@ -20,7 +20,7 @@ struct DevBatch {
 	int noFeedFusion;             // SMST_NO_FEED_FUSION=1: pass A stays its own kernel (kPredictA) -- cross-check of the folded form
 	int feedSerial;               // SMST_FEED_SERIAL: bin-by-bin feed recurrences (kFeedSerial) instead of the scan form
 	int halfState;                // carried Band.output / Prediction.energy / overlap-add sums stored in fp16 (BASELINE config 5 "fp16 internal")
-	int fftLean;                  // register-blocked FFT kernels with the smaller tables (SMST_FFT_TABLES=full switches back: cross-check / A-B)
+	int fftLean;                  // SMST_FFT_TABLES=lean: register-blocked FFT kernels with the smaller tables (opt-in experiment, see smst_engine.cpp)
 	int noFastFft;                // SMST_NO_FAST_FFT: the generic radix-4/2/3/5 ladder even where a register-blocked FFT exists (cross-check)
 	int noStage;                  // SMST_NO_STAGE: producers of the fused kernel gather from HBM even where staging applies
 	FftPlan plan;
@@ -83,6 +83,8 @@ void launchVocoder(const DevBatch &d, int sBase, int nStreams, int hopBase, bool
 bool fusedSupported(const DevBatch &d);
 bool singleHopSupported(const DevBatch &d);
 void launchVocoderOne(const DevBatch &d, int sBase, int nStreams, int hopBase, bool plain, hipStream_t st); // tiles in which no stream has more than one hop
+bool acrossSupported(const DevBatch &d);
+void launchVocoderAcross(const DevBatch &d, int sBase, int nStreams, int hopBase, bool plain, hipStream_t st); // the same tiles, mono / stereo: lanes of the recurrence wave = streams
 void launchSynth(const DevBatch &d, int sBase, int nStreams, int hopBase, int tileHops, hipStream_t st);
 void launchEmit(const DevBatch &d, const IoArgs &io, int sBase, int nStreams, int tileIndex, int maxSpan, hipStream_t st);
 void launchCarryFeed(const DevBatch &d, int sBase, int nStreams, int hopBase, bool anyFormants, hipStream_t st);

@@ -154,6 +154,7 @@ void Batch::construct(const FftPlan &plan, long seed) {
 	if (const char *env = std::getenv("SMST_NO_OVERLAP")) overlap = atoi(env) == 0;
 	noFuse = std::getenv("SMST_NO_FUSE") != nullptr;
 	noSingleHop = std::getenv("SMST_NO_SINGLE_HOP") != nullptr;
+	noAcross = std::getenv("SMST_NO_ACROSS") != nullptr;
 	if (const char *env = std::getenv("SMST_CHECK_LAUNCHES")) checkLaunches = atoi(env) != 0;
 
 	d.S = S; d.C = C; d.B = B; d.I = I; d.M = M; d.N = N; d.L = L; d.T = kTileHops;
@@ -173,8 +174,11 @@ void Batch::construct(const FftPlan &plan, long seed) {
 	if (const char *env = std::getenv("SMST_NO_FEED_FUSION")) d.noFeedFusion = atoi(env);
 	d.noStage = std::getenv("SMST_NO_STAGE") != nullptr;
 	d.noFastFft = std::getenv("SMST_NO_FAST_FFT") != nullptr;
-	d.fftLean = 1;
-	if (const char *env = std::getenv("SMST_FFT_TABLES")) d.fftLean = std::string(env) != "full";
+	// lean FFT tables (8-byte window entries + generated modulation, six stage twiddles instead of fifteen) are OPT-IN: they take 0.2 ms
+	// off a 16.3-ms step, and their one extra rounding per element (spectra 1.2e-7 away from the full tables') flipped a peak decision
+	// of a noise stream in tests/test_parity_gpu.py::test_batch_ragged -- parity first
+	d.fftLean = 0;
+	if (const char *env = std::getenv("SMST_FFT_TABLES")) d.fftLean = std::string(env) == "lean";
 	d.feedSerial = std::getenv("SMST_FEED_SERIAL") != nullptr;
 
 	// constant tables
@@ -904,7 +908,8 @@ void Batch::process(const float *in, long long inSS, long long inCS, const int *
 					SMST_HIP(hipEventRecord(liveA, sC));
 				}
 				timed(timings.chainMs, [&] {
-					if (fused && tileHops == 1 && singleHop) launchVocoderOne(dd, sBase, ns, hopBase, plain, sC);
+					if (fused && tileHops == 1 && singleHop && !noAcross && acrossSupported(dd)) launchVocoderAcross(dd, sBase, ns, hopBase, plain, sC);
+					else if (fused && tileHops == 1 && singleHop) launchVocoderOne(dd, sBase, ns, hopBase, plain, sC);
 					else if (fused) launchVocoder(dd, sBase, ns, hopBase, plain, !th[4], sC);
 					else launchChain(dd, sBase, ns, hopBase, sC);
 					if (profiling) ++timings.chainLaunches;

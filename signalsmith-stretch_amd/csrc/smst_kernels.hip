@@ -490,13 +490,25 @@ __global__ __launch_bounds__(16*R3 > 256 ? 16*R3 : 256) __attribute__((amdgpu_wa
 			}, prep, store);
 		return;
 	}
+	// the general case (a window that reaches into the carried history, or a block size whose halves do not fall on slot boundaries):
+	// bounds-checked sample fetches, THE SAME ARITHMETIC as the fast case above, element for element -- a hop analysed in a short
+	// call (history) and the same hop inside one long call must give the same bits (chunking invariance)
+	const float2 hbG = d.halfTw[min((int)threadIdx.x, MA - 1)];
 	fftFast<-1, R3, LEAN>(lds, LEAN ? d.twA6 : d.twA4, d.twB4,
-		[&](int m, int) {
+		[&](int m, int slot) {
 			float xr = 0, xi = 0;
 			if (m < B - halfB) { int src = base + m + halfB; xr = (src >= 0) ? x[src] : hist[src]; }
 			if (m >= H - halfB) { int src = base + m - H + halfB; xi = (src >= 0) ? x[src] : hist[src]; }
-			const float2 a = winA[m], b = winB[m];
-			return make_float2(fmaf(xi, b.x, xr*a.x), fmaf(xi, b.y, xr*a.y));
+			if constexpr (LEAN) {
+				const float2 w = d.win2[m];
+				const float2 z = make_float2(xr*w.x, xi*w.y);
+				const float ang = 3.14159265358979323846f*float(slot)/32.0f; // compile-time constant after unrolling
+				const float2 h = cmulPlain(hbG, make_float2(__builtin_cosf(ang), -__builtin_sinf(ang)));
+				return cmulPlain(z, h);
+			} else {
+				const float2 a = winA[m], b = winB[m];
+				return make_float2(fmaf(xi, b.x, xr*a.x), fmaf(xi, b.y, xr*a.y));
+			}
 		}, prep, store);
 }
 
@@ -2220,13 +2232,20 @@ __device__ __forceinline__ float2 fromLaneBelow(float2 v, float2 lane0) { // lan
 	                   __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(lane0.y), __float_as_int(v.y), 0x138, 0xf, 0xf, false)));
 }
 
-template <int CH, bool PLAIN, int L, bool STAGED, bool ROTL = false>
-__global__ __launch_bounds__(64*kVocWaves) __attribute__((amdgpu_waves_per_eu(4, 4))) void kVocoder(DevBatch d, int sBase, int hopBase) {
+// ACROSS (single-hop tiles, the real-time calling pattern: every stream fires at most one hop per call): the 64 lanes of the
+// recurrence wave are 64 STREAMS (up to acrossRows of them per workgroup) instead of 64 hops of one stream.  Every row is the
+// first hop of its tile, so every record carries its previous-hop terms ready-made (FOLD0) and no lane needs another lane's
+// output: no skew (lag 0), no DPP, M steps per launch.  kVocoderOne runs one chain per WAVE (64 lanes computing the same
+// values); at 4096 streams that is four chain waves per SIMD and 1.57 ms per hop quantum.  Same records, same arithmetic:
+// bit-identical to the other recurrence kernels.
+template <int CH, bool PLAIN, int L, bool STAGED, bool ROTL = false, bool ACROSS = false>
+__global__ __launch_bounds__(64*kVocWaves) __attribute__((amdgpu_waves_per_eu(4, 4))) void kVocoder(DevBatch d, int sBase, int hopBase, int acrossRows, int acrossStreams) {
 	static_assert(!STAGED || (PLAIN && L <= 5), "staged producers: identity map, bounded windows");
+	static_assert(!ACROSS || !STAGED, "rows that are streams gather their operands");
 	static_assert(!ROTL || (!PLAIN && !STAGED), "the LDS copy of the rotation table serves the gathering producers of mapped tiles");
 	constexpr int NF = 9 + 3*CH, NCH = (NF + 3)/4, BS = kVocBlockSteps, NB = STAGED ? kVocBlocksStaged : kVocBlocks;
 	constexpr int NP = STAGED ? kVocStagedProducers : kVocWaves - 2;
-	constexpr int lag = L + 1;
+	constexpr int lag = ACROSS ? 0 : L + 1;
 	static_assert(BS == 8 && L >= 1 && L <= 7, "history registers are indexed by step & 7");
 	extern __shared__ __attribute__((aligned(16))) unsigned char smemRaw[];
 	float4 *recs = reinterpret_cast<float4 *>(smemRaw);                 // [(slot*BS + st)*NCH + j][64 lanes]
@@ -2236,19 +2255,31 @@ __global__ __launch_bounds__(64*kVocWaves) __attribute__((amdgpu_waves_per_eu(4,
 	float2 *outRing = reinterpret_cast<float2 *>(hopsLds + 64);                    // [kVocOutBlocks][BS][CH][64]: results on their way to HBM
 	// sync words: [0..NB) units produced per slot, [NB] blocks consumed, [NB+1] result blocks ready, [NB+2] result blocks written
 
-	const int s = blockIdx.x, sg = sBase + s;
-	const int nh = d.nHops[s];
-	if (nh == 0) return;
+	// rows of the workgroup: hops 0 .. nh-1 of stream s, or (ACROSS) hop 0 of streams s .. s+nh-1
+	const int s = ACROSS ? blockIdx.x*acrossRows : blockIdx.x, sg = sBase + s;
+	const int nh = ACROSS ? min(acrossRows, acrossStreams - s) : d.nHops[s];
+	if (nh <= 0) return;
 	const int wave = threadIdx.x >> 6, k = threadIdx.x & 63;
 	const int M = d.M;
 	const int steps = M + lag*(nh - 1);
 	const int chunks = (steps + 63) >> 6;
 	const int totalBlocks = chunks*(64/BS);
 	const CarriedOutput stOut = carriedOutput(d, sg);
+	auto rowStream = [&](int row) { return ACROSS ? s + row : s; }; // sub-batch-local stream of a row
+	auto rowHop = [&](int row) { return ACROSS ? 0 : row; };         // tile-local hop of a row
 
 	// prologue (all waves): clear the hand-off words, cache the hop table
 	if (threadIdx.x <= NB + 2) sync[threadIdx.x] = 0;
-	if (threadIdx.x < 64) hopsLds[threadIdx.x] = d.hops[(size_t)sg*d.hopStride + hopBase + threadIdx.x];
+	if (threadIdx.x < 64) {
+		if constexpr (ACROSS) {
+			HopDesc hd{};
+			const int row = threadIdx.x;
+			if (row < nh && d.nHops[s + row] > 0) hd = d.hops[(size_t)(sg + row)*d.hopStride + hopBase];
+			hopsLds[row] = hd; // streams without a hop in this call: flags == 0, all-zero records, nothing written
+		} else {
+			hopsLds[threadIdx.x] = d.hops[(size_t)sg*d.hopStride + hopBase + threadIdx.x];
+		}
+	}
 	float2 *rotLds = outRing + (size_t)kVocOutBlocks*BS*CH*kVocOutPitch; // [M] hop rotation table (ROTL; the staged kernel keeps its windows here)
 	if constexpr (ROTL) {
 		for (int i = threadIdx.x; i < M; i += blockDim.x) rotLds[i] = d.rot[i];
@@ -2289,7 +2320,7 @@ __global__ __launch_bounds__(64*kVocWaves) __attribute__((amdgpu_waves_per_eu(4,
 					const int row = rowClass[q*64 + (idx < count[q] ? idx : 0)];
 					const int G = (n - ((lag*row + 7) >> 3) - 1) >> 1;
 					const int b = 16*G + 2*part;
-					const bool ok = idx < count[q] && row < nh && G >= 0 && 16*G < M;
+					const bool ok = idx < count[q] && row < nh && G >= 0 && 16*G < M && (!ACROSS || (hopsLds[row].flags & HOP_ACTIVE));
 					const int t0 = b + lag*row, t1 = t0 + 1; // the steps at which the two bins were produced
 					const int r0 = t0 >= 0 ? (t0 >> 3)%kVocOutBlocks : 0, r1 = t1 >= 0 ? (t1 >> 3)%kVocOutBlocks : 0;
 #pragma unroll
@@ -2298,7 +2329,7 @@ __global__ __launch_bounds__(64*kVocWaves) __attribute__((amdgpu_waves_per_eu(4,
 						if (b >= M) v0 = make_float2(0.f, 0.f);
 						if (b + 1 >= M) v1 = make_float2(0.f, 0.f);
 						if (ok) {
-							float2 *dst = d.OUT + rowOf(d, s, row, c) + b;
+							float2 *dst = d.OUT + rowOf(d, rowStream(row), rowHop(row), c) + b;
 							dst[0] = v0;
 							dst[1] = v1;
 						}
@@ -2333,7 +2364,13 @@ __global__ __launch_bounds__(64*kVocWaves) __attribute__((amdgpu_waves_per_eu(4,
 			float f[NCH*4];
 #pragma unroll
 			for (int j = 0; j < NCH*4; ++j) f[j] = 0.0f;
-			if (row < nh && b >= 0 && b < M && d.debugMode != 1) computeRecord<CH, PLAIN, false, false, NCH*4, ROTL, true>(d, hopsLds[row], hopsLds[row > 0 ? row - 1 : 0], s, sg, row, b, f, rotLds);
+			if (row < nh && b >= 0 && b < M && d.debugMode != 1) {
+				if constexpr (ACROSS) {
+					if (hopsLds[row].flags & HOP_ACTIVE) computeRecord<CH, PLAIN, false, false, NCH*4, ROTL, true>(d, hopsLds[row], hopsLds[row], s + row, sg + row, 0, b, f, rotLds);
+				} else {
+					computeRecord<CH, PLAIN, false, false, NCH*4, ROTL, true>(d, hopsLds[row], hopsLds[row > 0 ? row - 1 : 0], s, sg, row, b, f, rotLds);
+				}
+			}
 			while (n - ldsPeek(&sync[NB]) >= NB) __builtin_amdgcn_s_sleep(2); // slot still being read (waited for AFTER the pass is computed)
 			asm volatile("" ::: "memory");
 #pragma unroll
@@ -2358,7 +2395,7 @@ __global__ __launch_bounds__(64*kVocWaves) __attribute__((amdgpu_waves_per_eu(4,
 	for (int c = 0; c < CH; ++c) {
 #pragma unroll
 		for (int i = 0; i < 8; ++i) h[i][c] = make_float2(0.f, 0.f);
-		tap1[c] = make_float2(k == 0 ? 1.f : 0.f, 0.f);
+		tap1[c] = make_float2((ACROSS || k == 0) ? 1.f : 0.f, 0.f); // ACROSS: every lane is a first hop
 		tapL[c] = make_float2(0.f, 0.f);
 	}
 	// the two hand-off words the NEXT block waits for are read during the current block's last step (an LDS round trip each,
@@ -2394,8 +2431,10 @@ __global__ __launch_bounds__(64*kVocWaves) __attribute__((amdgpu_waves_per_eu(4,
 			// lane's previous-hop taps at b+1 and b+L
 #pragma unroll
 			for (int c = 0; c < CH; ++c) {
-				tap1[c] = fromLaneBelow(h[(i + 8 - L) & 7][c], tap1[c]);
-				tapL[c] = fromLaneBelow(h[(i + 7) & 7][c], tapL[c]);
+				if constexpr (!ACROSS) {
+					tap1[c] = fromLaneBelow(h[(i + 8 - L) & 7][c], tap1[c]);
+					tapL[c] = fromLaneBelow(h[(i + 7) & 7][c], tapL[c]);
+				}
 			}
 			// the maximum channel's taps: explicit per-component selects (v_cndmask) -- written as an `if` the compiler makes a branch of
 			// it, with a register copy in front of every tap that must survive (14 moves against 8 selects)
@@ -3167,15 +3206,44 @@ static void launchVocoderTL(const DevBatch &d, int sBase, int nStreams, int hopB
 		if (plain && bounded && !d.noStage) {
 			using G = StageGeom<CH, L>;
 			const size_t ldsStaged = (size_t)kVocBlocksStaged*kVocBlockSteps*NCH*64*sizeof(float4) + fixed + (size_t)kVocStagedProducers*G::ROWS*G::ROWLEN*sizeof(float2);
-			hipLaunchKernelGGL((kVocoder<CH, true, L, true>), dim3(nStreams), dim3(64*kVocWaves), ldsStaged, st, d, sBase, hopBase);
+			hipLaunchKernelGGL((kVocoder<CH, true, L, true>), dim3(nStreams), dim3(64*kVocWaves), ldsStaged, st, d, sBase, hopBase, 0, 0);
 			return;
 		}
 	}
-	if (plain) { hipLaunchKernelGGL((kVocoder<CH, true, L, false>), dim3(nStreams), dim3(64*kVocWaves), lds, st, d, sBase, hopBase); return; }
+	if (plain) { hipLaunchKernelGGL((kVocoder<CH, true, L, false>), dim3(nStreams), dim3(64*kVocWaves), lds, st, d, sBase, hopBase, 0, 0); return; }
 	// mapped tiles: the hop rotation table beside the rings when the CU's 160 KB hold it (presetDefault: 3073 bins, 24 KB)
 	const size_t ldsRot = lds + (size_t)d.M*sizeof(float2);
-	if (ldsRot <= (size_t)160*1024) hipLaunchKernelGGL((kVocoder<CH, false, L, false, true>), dim3(nStreams), dim3(64*kVocWaves), ldsRot, st, d, sBase, hopBase);
-	else hipLaunchKernelGGL((kVocoder<CH, false, L, false>), dim3(nStreams), dim3(64*kVocWaves), lds, st, d, sBase, hopBase);
+	if (ldsRot <= (size_t)160*1024) hipLaunchKernelGGL((kVocoder<CH, false, L, false, true>), dim3(nStreams), dim3(64*kVocWaves), ldsRot, st, d, sBase, hopBase, 0, 0);
+	else hipLaunchKernelGGL((kVocoder<CH, false, L, false>), dim3(nStreams), dim3(64*kVocWaves), lds, st, d, sBase, hopBase, 0, 0);
+}
+// single-hop tiles, mono / stereo: rows of the recurrence wave are streams (kVocoder ACROSS).  Rows per workgroup: enough to cover the
+// streams with one workgroup per CU (a multiple of 8: a producer pass is 8 rows x 8 steps), at most 64
+template <int CH, int L>
+static void launchVocoderAcrossL(const DevBatch &d, int sBase, int nStreams, int hopBase, bool plain, hipStream_t st) {
+	constexpr int NCH = (9 + 3*CH + 3)/4;
+	const size_t fixed = 64 + 128*sizeof(int) + 64*sizeof(HopDesc) + (size_t)kVocOutBlocks*kVocBlockSteps*CH*kVocOutPitch*sizeof(float2);
+	const size_t lds = (size_t)kVocBlocks*kVocBlockSteps*NCH*64*sizeof(float4) + fixed;
+	int rows = ((nStreams + 255)/256 + 7) & ~7;
+	rows = rows < 8 ? 8 : (rows > 64 ? 64 : rows);
+	const dim3 grid((nStreams + rows - 1)/rows);
+	if (plain) { hipLaunchKernelGGL((kVocoder<CH, true, L, false, false, true>), grid, dim3(64*kVocWaves), lds, st, d, sBase, hopBase, rows, nStreams); return; }
+	const size_t ldsRot = lds + (size_t)d.M*sizeof(float2);
+	if (ldsRot <= (size_t)160*1024) hipLaunchKernelGGL((kVocoder<CH, false, L, false, true, true>), grid, dim3(64*kVocWaves), ldsRot, st, d, sBase, hopBase, rows, nStreams);
+	else hipLaunchKernelGGL((kVocoder<CH, false, L, false, false, true>), grid, dim3(64*kVocWaves), lds, st, d, sBase, hopBase, rows, nStreams);
+}
+template <int CH>
+static void launchVocoderAcrossT(const DevBatch &d, int sBase, int nStreams, int hopBase, bool plain, hipStream_t st) {
+	switch (d.L) {
+	case 2: launchVocoderAcrossL<CH, 2>(d, sBase, nStreams, hopBase, plain, st); break;
+	case 3: launchVocoderAcrossL<CH, 3>(d, sBase, nStreams, hopBase, plain, st); break;
+	case 4: launchVocoderAcrossL<CH, 4>(d, sBase, nStreams, hopBase, plain, st); break;
+	default: launchVocoderAcrossL<CH, 5>(d, sBase, nStreams, hopBase, plain, st); break;
+	}
+}
+bool acrossSupported(const DevBatch &d) { return d.C <= 2 && d.lag == d.L + 1 && d.L >= 2 && d.L <= 5; }
+void launchVocoderAcross(const DevBatch &d, int sBase, int nStreams, int hopBase, bool plain, hipStream_t st) {
+	if (d.C == 1) launchVocoderAcrossT<1>(d, sBase, nStreams, hopBase, plain, st);
+	else launchVocoderAcrossT<2>(d, sBase, nStreams, hopBase, plain, st);
 }
 template <int CH>
 static void launchVocoderT(const DevBatch &d, int sBase, int nStreams, int hopBase, bool plain, bool bounded, hipStream_t st) {

@@ -876,3 +876,33 @@ def case_split_mid_interval_flush(lib, ref):
     figures["long flush, first interval"] = rel_rms(fa[:, :I], fb[:, :I])
     assert figures["long flush, first interval"] < 1e-4, figures  # one more block of the phase vocoder ran: its own sensitivity (GPU: 2e-5)
     return figures
+
+
+def case_across_equals_single_hop(lib, monkeypatch, streams=21, channel_counts=(1, 2), setup=None):
+    """Single-hop tiles, mono / stereo: the recurrence runs with its lanes across STREAMS (kVocoder ACROSS); SMST_NO_ACROSS=1 runs
+    one chain per stream (kVocoderOne).  Same records, same arithmetic: bit-identical, for a stream count that is no multiple of
+    the rows per workgroup and with streams that take no hop in a call (ragged sample counts)."""
+    pkg = package()
+    geometry = dict(block=512, interval=128, split=False)
+    for C in channel_counts:
+        outs = []
+        for no_across in (False, True):
+            if no_across:
+                monkeypatch.setenv("SMST_NO_ACROSS", "1")
+            else:
+                monkeypatch.delenv("SMST_NO_ACROSS", raising=False)
+            b = pkg.StretchBatch(streams, C, lib=lib, **geometry)
+            if setup:
+                setup(b)
+            xs = np.stack([synth_input(s, C, 128*24, 48000) for s in range(streams)])
+            parts = []
+            for k in range(22):
+                nin = np.array([128 if (s + k) % 5 else 0 for s in range(streams)], np.int32)   # every fifth stream idles in a call
+                nout = np.array([128 if (s + k) % 5 else 0 for s in range(streams)], np.int32)
+                y = np.array(b.process(xs[:, :, 128*k:128*(k + 1)], nout, in_samples=nin), copy=True)
+                parts.append(y)
+            b.close()
+            outs.append(np.concatenate(parts, axis=2))
+        monkeypatch.delenv("SMST_NO_ACROSS", raising=False)
+        assert np.abs(outs[0]).max() > 0.05
+        assert np.array_equal(outs[0], outs[1]), (C, float(np.abs(outs[0] - outs[1]).max()))

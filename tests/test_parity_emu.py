@@ -149,3 +149,8 @@ def test_debug_map_is_of_the_last_call_emu(emu):
 
 def test_split_mid_interval_flush_emu(emu, ref):
     print(pc.case_split_mid_interval_flush(emu, ref))
+
+
+def test_across_equals_single_hop_emu(emu, monkeypatch):
+    pc.case_across_equals_single_hop(emu, monkeypatch, streams=11)
+    pc.case_across_equals_single_hop(emu, monkeypatch, streams=5, channel_counts=(2,), setup=lambda b: b.setTransposeSemitones(5, 0.2))

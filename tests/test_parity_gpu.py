@@ -561,3 +561,8 @@ def test_debug_map_is_of_the_last_call(hip):
 
 def test_split_mid_interval_flush(hip, ref):
     print(pc.case_split_mid_interval_flush(hip, ref))
+
+
+def test_across_equals_single_hop(hip, monkeypatch):
+    pc.case_across_equals_single_hop(hip, monkeypatch, streams=300)
+    pc.case_across_equals_single_hop(hip, monkeypatch, streams=5, channel_counts=(2,), setup=lambda b: b.setTransposeSemitones(5, 0.2))
