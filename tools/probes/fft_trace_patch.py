@@ -1,11 +1,14 @@
-"""Instrumentation for tools/probes/fft_trace.py: apply to a COPY of csrc/smst_kernels.hip + smst_engine.cpp, build, restore."""
-p='/root/repo/signalsmith-stretch_amd/csrc/smst_kernels.hip'
+"""Instrumentation for tools/probes/fft_trace.py; applied to a COPY of csrc/ by tools/probes/build_variant.sh:
+    tools/probes/build_variant.sh fft_trace tools/probes/fft_trace_patch.py"""
+import sys
+SRC = sys.argv[1]
+p=SRC + '/smst_kernels.hip'
 s=open(p).read()
 def rep(old,new,count=1):
     global s
     assert s.count(old)==count, (s.count(old), old[:70])
     s=s.replace(old,new)
-anchor="template <int SIGN, int R3, typename Load, typename Prep, typename Store>\n__device__ __forceinline__ void fftFast("
+anchor="template <int SIGN, int R3, bool LEAN, typename Load, typename Prep, typename Store>\n__device__ __forceinline__ void fftFast("
 assert anchor in s
 s=s.replace(anchor,"__device__ unsigned long long gTrace[12*400 + 8];\nvoid traceRead(void *dst) { hipMemcpyFromSymbol(dst, HIP_SYMBOL(gTrace), sizeof(gTrace)); }\n__device__ int gTraceOn;\n#define TRA(slot) do { if (SIGN < 0 && threadIdx.x == 0) { const unsigned w = blockIdx.x + gridDim.x*(blockIdx.y + gridDim.y*blockIdx.z); if (w % 97 == 0 && (w/97) < 400) gTrace[(slot)*400 + w/97] = clock64(); } } while (0)\n"+anchor,1)
 rep("""	float2 v[16];
@@ -38,11 +41,11 @@ rep("""			lds[q0 + 256*p + 16*n] = val;
 	TRA(4);
 	__syncthreads();
 	TRA(5);""")
-rep("""				if (pos < R3) store(t + 256*(e + 4*c), u[pos], ready[i]);
+rep("""				if (pos < R3) store(t + 256*(e + RA*c), u[pos], ready[i], e + RA*c);
 			}
 		}
 	}
-}""","""				if (pos < R3) store(t + 256*(e + 4*c), u[pos], ready[i]);
+}""","""				if (pos < R3) store(t + 256*(e + RA*c), u[pos], ready[i], e + RA*c);
 			}
 		}
 		TRA(6);
@@ -51,7 +54,7 @@ rep("""				if (pos < R3) store(t + 256*(e + 4*c), u[pos], ready[i]);
 	}
 }""")
 open(p,'w').write(s)
-p='/root/repo/signalsmith-stretch_amd/csrc/smst_engine.cpp'
+p=SRC + '/smst_engine.cpp'
 s=open(p).read()
 o="void Batch::debugGetState(int stream, int which, float *dst) {\n	SMST_HIP(hipSetDevice(dev));\n	SMST_HIP(hipStreamSynchronize(st));"
 assert o in s

@@ -5,35 +5,36 @@ p=SRC + '/smst_kernels.hip'
 s=open(p).read()
 anchor="// Staged producers (PLAIN tiles without random time factors, L <= 5)."
 assert anchor in s
-s=s.replace(anchor,"__device__ unsigned long long gTrace[12*400 + 8];\nvoid traceRead(void *dst) { hipMemcpyFromSymbol(dst, HIP_SYMBOL(gTrace), sizeof(gTrace)); }\n#define TR(slot, n) do { if (s == 0 && k == 0 && (n) < 400) { gTrace[(slot)*400 + (n)] = clock64(); if ((slot) == 5 && ((n) == 100 || (n) == 300)) gTrace[12*400 + ((n) == 300)] = wall_clock64(); } } while (0)\n"+anchor,1)
+s=s.replace(anchor,"__device__ unsigned long long gTrace[14*400 + 8];\nvoid traceRead(void *dst) { hipMemcpyFromSymbol(dst, HIP_SYMBOL(gTrace), sizeof(gTrace)); }\n#define TR(slot, n) do { if (s == 0 && k == 0 && (n) < 400) { gTrace[(slot)*400 + (n)] = clock64(); if ((slot) == 5 && ((n) == 100 || (n) == 300)) gTrace[14*400 + ((n) == 300)] = wall_clock64(); } } while (0)\n"+anchor,1)
 def rep(old,new):
     global s
     assert old in s, old[:60]
     s=s.replace(old,new)
 rep("""	for (; n < totalBlocks; n += NPB) {
 		park(n);""","""	for (; n < totalBlocks; n += NPB) {
-		if (pIndex == 0) TR(0, n);
+		if (it == 0) TR(0, n);
 		park(n);""")
 rep("""		if (n + NPB < totalBlocks) { issue(n + NPB); if (it == 0) issueCarried(n + NPB); }
-		const int slot = n%NB;""","""		if (pIndex == 0) TR(1, n);
+		const int slot = n%NB;""","""		if (it == 0) TR(1, n);
 		if (n + NPB < totalBlocks) { issue(n + NPB); if (it == 0) issueCarried(n + NPB); }
+		if (it == 0) TR(12, n);
 		const int slot = n%NB;""")
 rep("""		while (n - ldsPeek(&sync[NB]) >= NB) __builtin_amdgcn_s_sleep(2); // slot still being read
 		asm volatile("" ::: "memory");
 		const int b0 = BS*n - lag*row, b = b0 + st;""","""		while (n - ldsPeek(&sync[NB]) >= NB) __builtin_amdgcn_s_sleep(2); // slot still being read
 		asm volatile("" ::: "memory");
-		if (pIndex == 0) TR(2, n);
+		if (it == 0) TR(2, n);
 		const int b0 = BS*n - lag*row, b = b0 + st;""")
 rep("""#pragma unroll
 		for (int j = 0; j < NCH; ++j) recs[((slot*BS + st)*NCH + j)*64 + ((row + st) & 63)] = make_float4(f[4*j], f[4*j + 1], f[4*j + 2], f[4*j + 3]);
 		asm volatile("" ::: "memory");
 		if (k == 0) ldsCount(&sync[slot]);
-		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");""","""		if (pIndex == 0) TR(3, n);
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");""","""		if (it == 0) TR(3, n);
 #pragma unroll
 		for (int j = 0; j < NCH; ++j) recs[((slot*BS + st)*NCH + j)*64 + ((row + st) & 63)] = make_float4(f[4*j], f[4*j + 1], f[4*j + 2], f[4*j + 3]);
 		asm volatile("" ::: "memory");
 		if (k == 0) ldsCount(&sync[slot]);
-		if (pIndex == 0) TR(4, n);
+		if (it == 0) TR(4, n);
 		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");""")
 rep("""		const int need = 8*(n/NB + 1);
 		while (seenProduced < need) { __builtin_amdgcn_s_sleep(1); seenProduced = ldsPeek(&sync[slot]); }
