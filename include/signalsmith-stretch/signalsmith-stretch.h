@@ -24,7 +24,10 @@ namespace signalsmith { namespace stretch {
 
 template <typename Sample = float, class RandomEngine = void>
 struct SignalsmithStretch {
-	static_assert(std::is_same<Sample, float>::value, "the gfx950 implementation computes in fp32 only");
+	// Sample: the type of the caller's buffers and parameters, as in the reference (:34).  The device computes in fp32 whatever it is:
+	// SignalsmithStretch<double> compiles and runs -- samples and parameters are converted at this boundary -- and gives the
+	// float instantiation's results; it does NOT give the reference's double-precision ones.
+	static_assert(std::is_floating_point<Sample>::value, "Sample is float or double (the gfx950 implementation computes in fp32)");
 	static constexpr size_t version[3] = {1, 3, 2};
 
 	SignalsmithStretch() : SignalsmithStretch(long(std::random_device{}())) {}

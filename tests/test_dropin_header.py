@@ -60,6 +60,14 @@ SOURCE = textwrap.dedent(r'''
         pool.emplace_back(99L);
         static_assert(std::is_copy_constructible<Stretch>::value && std::is_nothrow_move_constructible<Stretch>::value, "value semantics");
         Stretch::setDefaultDevice(0);
+        // Sample = double (:34): accepted at the interface -- buffers and parameters are converted, the device computes in fp32
+        signalsmith::stretch::SignalsmithStretch<double> wide(5L);
+        wide.presetDefault(2, 48000.0);
+        wide.setTransposeSemitones(3.0, 0.2);
+        wide.setFreqMap([](double f) { return f*1.1; });
+        std::vector<std::vector<double>> inD(2, std::vector<double>(4096)), outD(2, std::vector<double>(6144));
+        wide.process(inD, 4096, outD, 6144);
+        wide.flush(outD, 100, 1.0);
         return (a > 0 && ok && split) ? 0 : 1;
     }
 ''')
