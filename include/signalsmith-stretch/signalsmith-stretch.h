@@ -3,7 +3,7 @@
 // signalsmith-stretch.h:1), forwarding every call to the C ABI in include/smst.h (libsmst_hip.so).
 // Existing callers (e.g. the reference's cmd/main.cpp:44-82) compile unchanged against this header.
 //
-// Differences a caller can observe are listed in DESIGN.md ("deviations"): only Sample=float exists; setFreqMap
+// Differences a caller can observe are listed in DESIGN.md ("deviations"): the arithmetic is fp32 whatever Sample is; setFreqMap
 // samples the std::function into a 4096-point table; the RandomEngine parameter is accepted and ignored (the
 // >2x-stretch randomisation uses a counter-based generator on the device).
 #ifndef SIGNALSMITH_STRETCH_H
