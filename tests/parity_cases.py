@@ -146,6 +146,78 @@ def case_api_surface(lib, ref, cfg=SMALL, scale=1):
     assert not ok_a and not ok_b and np.abs(a).max() == 0
 
 
+def case_random_call_sequences(lib, ref, seeds=range(6), cfg=SMALL, calls=14):
+    """API fuzz: a seeded random walk over the public members -- process() with ragged chunks at changing ratios (0.75 ... 1.6) and
+    input-only calls, setTransposeSemitones / setTransposeFactor / setFormantFactor / setFormantBase between calls, seek(), flush() of
+    up to one interval, reset() -- replayed on the product, the checker and the perturbed checkers (check_scenario).  Short walks (a
+    few dozen hops), so the sample-domain comparison stays informative; 1-3 channels.  Left out on purpose: whatever draws from the
+    reference's implementation-defined RandomEngine (output without input and any other stretch beyond 2x, flushes longer than an
+    interval): case_random_time_factor* cover those by level and determinism."""
+    sr = 48000
+    seeds = list(seeds)
+    uninformative = []
+    for seed in seeds:
+        C = 1 + seed % 3
+        formants = seed % 4 == 3
+        x = synth_input(seed, C, 40000, sr) + 0.4*synth_input(seed + 7, C, 40000, sr)
+
+        def play(o, xx, seed=seed, formants=formants):
+            rng = np.random.default_rng(1000 + seed)
+            pos, outs = 0, []
+            ratio = 1.0
+            # split computation: the reference spreads a block's steps over the interval, the product completes the block at the
+            # interval's first sample (DESIGN section 8) -- parameter changes, seeks, flushes and resets BETWEEN interval boundaries
+            # are a documented deviation there, so a split-mode walk sets its parameters once and then only processes
+            split = bool(cfg.get("split", False))
+            if split:
+                o.setTransposeSemitones(float(rng.integers(-7, 8)), float(rng.choice([0.0, 0.15])))
+                if formants:
+                    o.setFormantFactor(float(rng.choice([0.9, 1.15])), bool(rng.integers(0, 2)))
+                ratio = float(rng.choice([0.75, 1.0, 1.3, 1.6]))
+            for call in range(calls):
+                kind = rng.choice(["process", "process", "process", "param", "flush", "seek", "reset", "empty"], p=[0.3, 0.2, 0.15, 0.15, 0.06, 0.05, 0.04, 0.05])
+                if split and kind in ("param", "flush", "seek", "reset"):
+                    kind = "process"
+                if kind == "param":
+                    which = int(rng.integers(0, 4 if formants else 2))
+                    if which == 0:
+                        o.setTransposeSemitones(float(rng.integers(-7, 8)), float(rng.choice([0.0, 0.15])))
+                    elif which == 1:
+                        o.setTransposeFactor(float(rng.choice([0.8, 1.0, 1.25])), 0.0)
+                    elif which == 2:
+                        o.setFormantFactor(float(rng.choice([0.9, 1.0, 1.15])), bool(rng.integers(0, 2)))
+                    else:
+                        o.setFormantBase(float(rng.choice([0.0, 150.0/sr])))
+                    ratio = float(rng.choice([0.75, 1.0, 1.3, 1.6]))
+                elif kind == "flush":  # at most one interval: a longer flush draws from the implementation-defined RandomEngine (DESIGN section 2 ii)
+                    outs.append(o.flush(int(rng.integers(1, o.intervalSamples() + 1))))
+                elif kind == "seek":
+                    n = int(rng.integers(50, 700))
+                    o.seek(xx[:, pos:pos + n], float(rng.choice([0.8, 1.0, 1.2])))
+                    pos += n
+                elif kind == "reset":
+                    o.reset()
+                elif kind == "empty":  # input without output (output without input is a stretch beyond 2x: random time factors, no parity)
+                    n = int(rng.integers(1, 200))
+                    outs.append(o.process(xx[:, pos:pos + n], 0))
+                    pos += n
+                else:
+                    n = int(rng.integers(1, 900))
+                    outs.append(o.process(xx[:, pos:pos + n], max(1, int(n*ratio))))
+                    pos += n
+            outs.append(o.process(xx[:, pos:pos + 1500], 1800))  # every walk ends with sound coming out
+            return np.concatenate([np.asarray(v) for v in outs], axis=1)
+        try:
+            check_scenario(lib, ref, cfg, x, play, "random walk %d (%d ch%s)" % (seed, C, ", formants" if formants else ""),
+                           cap=CAP_FORMANT if formants else CAP_TONAL)
+        except AssertionError as e:
+            if "informative" not in str(e):
+                raise
+            uninformative.append(seed)  # the checker's own response to a 1e-6 perturbation exceeds the cap from the first horizon on: nothing to assert
+    assert len(uninformative) <= max(1, len(seeds)//5), uninformative
+    return dict(walks=len(seeds), uninformative=uninformative)
+
+
 def case_realtime_quanta(lib, ref, cfg=SMALL, quantum=128, quanta=70):
     """The two calling patterns of the reference's AudioWorklet wrapper (web/web-wrapper.js:255-315), SURVEY.md 8(f)
     rank 3: (i) live input, process(quantum, quantum) per render quantum; (ii) buffered playback, where every quantum

@@ -154,3 +154,7 @@ def test_split_mid_interval_flush_emu(emu, ref):
 def test_across_equals_single_hop_emu(emu, monkeypatch):
     pc.case_across_equals_single_hop(emu, monkeypatch, streams=11)
     pc.case_across_equals_single_hop(emu, monkeypatch, streams=5, channel_counts=(2,), setup=lambda b: b.setTransposeSemitones(5, 0.2))
+
+
+def test_random_call_sequences_emu(emu, ref):
+    pc.case_random_call_sequences(emu, ref, seeds=range(6))

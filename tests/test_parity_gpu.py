@@ -566,3 +566,9 @@ def test_split_mid_interval_flush(hip, ref):
 def test_across_equals_single_hop(hip, monkeypatch):
     pc.case_across_equals_single_hop(hip, monkeypatch, streams=300)
     pc.case_across_equals_single_hop(hip, monkeypatch, streams=5, channel_counts=(2,), setup=lambda b: b.setTransposeSemitones(5, 0.2))
+
+
+def test_random_call_sequences(hip, ref):
+    """API fuzz against the checker: seeded random walks over process / parameter setters / seek / flush / reset."""
+    pc.case_random_call_sequences(hip, ref, seeds=range(12))
+    pc.case_random_call_sequences(hip, ref, seeds=range(100, 104), cfg=pc.SMALL_SPLIT)
