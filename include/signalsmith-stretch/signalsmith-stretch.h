@@ -4,8 +4,9 @@
 // Existing callers (e.g. the reference's cmd/main.cpp:44-82) compile unchanged against this header.
 //
 // Differences a caller can observe are listed in DESIGN.md ("deviations"): the arithmetic is fp32 whatever Sample is; setFreqMap
-// samples the std::function into a 4096-point table; the RandomEngine parameter is accepted and ignored (the
-// >2x-stretch randomisation uses a counter-based generator on the device).
+// samples the std::function into a 4096-point table; a RandomEngine template argument is accepted and ignored:
+// the >2x-stretch randomisation always uses the DEFAULT engine of a g++ build of the reference (libstdc++'s minstd_rand0), seeded as
+// the reference seeds it -- same seed, same draws.
 #ifndef SIGNALSMITH_STRETCH_H
 #define SIGNALSMITH_STRETCH_H
 

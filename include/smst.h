@@ -58,7 +58,11 @@ int smst_device_count(void);
  * ------------------------------------------------------------------------------------------------------- */
 typedef struct smst_stretch smst_stretch;
 
-/* SignalsmithStretch() / SignalsmithStretch(long seed): signalsmith-stretch.h:38-39.  device = HIP ordinal. */
+/* SignalsmithStretch() / SignalsmithStretch(long seed): signalsmith-stretch.h:38-39.  device = HIP ordinal.
+ * seed: the reference seeds its std::default_random_engine with it (:39, :616) and draws the per-bin time factors of stretches beyond
+ * 2x from that engine (:639-640).  This library carries the same engine -- libstdc++'s (minstd_rand0 through
+ * uniform_real_distribution<float>), i.e. the one a g++ build of the reference has -- so an instance created with seed S makes the
+ * draws a reference instance constructed with S makes.  Stream s of a batch is the instance of seed + s. */
 int smst_create(smst_stretch **out, long seed, int device);
 void smst_destroy(smst_stretch *h);
 /* The reference object is a plain struct and therefore COPYABLE (signalsmith-stretch.h:34-35; e.g. a std::vector of them):

@@ -219,6 +219,16 @@ void Batch::construct(const FftPlan &plan, long seed) {
 	d.twH = static_cast<float2 *>(upload(tw.data(), M*sizeof(float2)));
 	d.halfTw = static_cast<float2 *>(upload(half.data(), M*sizeof(float2)));
 	d.rot = static_cast<float2 *>(upload(rot.data(), M*sizeof(float2)));
+	{
+		std::vector<unsigned> pw(2*(size_t)M);
+		unsigned long long x = 1;
+		for (size_t j = 0; j < pw.size(); ++j) {
+			x = x*16807ull % 2147483647ull;
+			pw[j] = unsigned(x);
+		}
+		lcgHopJump = pw[2*(size_t)M - 3]; // 16807^(2M - 2): the draws of one randomised hop
+		d.lcgPow = static_cast<unsigned *>(upload(pw.data(), pw.size()*sizeof(unsigned)));
+	}
 	d.window = static_cast<float *>(upload(win.data(), B*sizeof(float)));
 	{ // folded analysis tables and, for H = 256*R3, the stage twiddles of the register-blocked FFT
 		const int halfB = B/2;
@@ -334,7 +344,12 @@ void Batch::construct(const FftPlan &plan, long seed) {
 
 	sched.assign(S, StreamSched());
 	lastHop.assign(S, LastHop());
-	for (int s = 0; s < S; ++s) sched[s].seed = unsigned(seed)*2654435761u + unsigned(s)*40503u + 12345u;
+	// std::default_random_engine (libstdc++: minstd_rand0) of a reference instance constructed with seed + s (:39; smst_kernels.hip: engineDraw)
+	for (int s = 0; s < S; ++s) {
+		const unsigned long long u = (unsigned long long)(seed + s); // `long` -> the engine's unsigned 64-bit result_type
+		sched[s].seed = unsigned(u % 2147483647ull);
+		if (sched[s].seed == 0) sched[s].seed = 1;
+	}
 	StreamParams p{};
 	p.freqMultiplier = 1; p.freqTonalityLimit = 0.5f; // :513
 	p.formantMultiplier = 1; p.invFormantMultiplier = 1; p.formantBaseFreq = 0; p.formantCompensation = 0; p.hasCustomMap = 0;
@@ -472,10 +487,9 @@ void Batch::reset() { // signalsmith-stretch.h:49-60
 	d.histCur = 0;
 	d.carryCur = 0;
 	for (auto &sc : sched) {
-		unsigned seed = sc.seed, counter = sc.rngCounter;
+		const unsigned seed = sc.seed; // reset() leaves the reference's randomEngine alone
 		sc = StreamSched();
 		sc.seed = seed;
-		sc.rngCounter = counter;
 	}
 }
 
@@ -783,7 +797,8 @@ void Batch::process(const float *in, long long inSS, long long inCS, const int *
 				if (tf > kMaxCleanStretch) flags |= HOP_RANDOM_TF; // :639
 				hd.timeFactor = tf;
 				hd.flags = flags;
-				hd.seed = sc.seed ^ (sc.rngCounter++*0x9E3779B1u);
+				hd.seed = sc.seed; // the engine's state before this hop's draws
+				if (flags & HOP_RANDOM_TF) sc.seed = unsigned((unsigned long long)sc.seed*lcgHopJump % 2147483647ull); // 2M - 2 draws later
 				const int tile = j/T;
 				const bool lastInTile = lastNew >= 0 && lastNew/T == tile;
 				hd.inSrc = newSpectrum ? j%T : (lastInTile ? lastNew%T : SRC_STATE);

@@ -17,8 +17,7 @@ struct StreamSched { // reference members: signalsmith-stretch.h:494-529
 	float seekTimeFactor = 1;           // :529
 	size_t silenceCounter = 0;          // :510
 	bool silenceFirst = true;           // :511
-	unsigned rngCounter = 0;
-	unsigned seed = 0;
+	unsigned seed = 0;                  // randomEngine, :616 -- the state of libstdc++'s minstd_rand0 (smst_kernels.hip: engineDraw)
 };
 
 struct BatchTimings { // filled when profiling is enabled (hipEvent pairs around each kernel class)
@@ -125,6 +124,7 @@ private:
 	size_t wsBytes = 0;
 	DevBatch d{};
 	std::vector<StreamSched> sched;
+	unsigned lcgHopJump = 1; // 16807^(2M - 2) mod (2^31 - 1): what one randomised hop advances a stream's engine by
 	struct LastHop { int slot = -1, local = -1, subLocal = 0; bool mapped = false; };
 	std::vector<LastHop> lastHop; // where each stream's newest hop sits in the tile workspaces (debugGetMap)
 	std::vector<StreamParams> params;

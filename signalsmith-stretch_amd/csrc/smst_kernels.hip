@@ -103,12 +103,27 @@ __device__ __forceinline__ BlockCoord xcdAwareBlock() {
 	return r;
 }
 
-// counter-based uniform in [0,1) (replaces std::default_random_engine of :616,:640 -- implementation-defined
-// in the reference, so no parity is possible there)
-__device__ __forceinline__ float hashUniform(unsigned seed, unsigned a, unsigned b) {
-	unsigned x = seed ^ (a*0x9E3779B9u) ^ (b*0x85EBCA6Bu + 0xC2B2AE35u);
-	x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
-	return (x >> 8)*(1.0f/16777216.0f);
+// The reference draws its random time factors (stretch beyond 2x: :639-640, :749, :769) from std::default_random_engine through
+// std::uniform_real_distribution<float>: implementation-defined, but DEFINED for the build a Linux user of the reference has --
+// libstdc++: minstd_rand0, x <- 16807 x mod (2^31 - 1), seeded with `seed mod (2^31 - 1)` (0 becomes 1); the distribution is
+// (generate_canonical<float, 24>() * (b - a)) + a with generate_canonical = float(x - 1) / 2^31, clamped below 1
+// (bits/random.h:1869, bits/random.tcc:3348).  A hop makes 2M - 2 draws in bin order -- bin b: one for the upward steps (b > 0), one
+// for the downward steps (b < M - 1) -- so draw j of a hop is state * 16807^(j+1): the host keeps every stream's engine state and
+// advances it by 2M - 2 per randomised hop (HopDesc.seed = the state before the hop), the device jumps ahead with a table of powers.
+// Same seed, same draws as the reference compiled with g++ (tests: case_engine_draws, case_random_time_factor_parity).
+constexpr unsigned kLcgModulus = 2147483647u, kLcgMultiplier = 16807u;
+__device__ __forceinline__ unsigned lcgMulMod(unsigned a, unsigned b) { // a*b mod (2^31 - 1), a, b < 2^31 - 1
+	const unsigned long long p = (unsigned long long)a*b;
+	unsigned r = unsigned(p & kLcgModulus) + unsigned(p >> 31); // 2^31 = 1 (mod m)
+	r = (r & kLcgModulus) + (r >> 31);
+	return r >= kLcgModulus ? r - kLcgModulus : r;
+}
+// draw `index` (0-based) of the hop whose engine state was `state`: uniform_real_distribution<float>(lo, hi)
+__device__ __forceinline__ float engineDraw(const DevBatch &d, unsigned state, int index, float lo, float hi) {
+	const unsigned x = lcgMulMod(state, d.lcgPow[index]);
+	float u = float(x - 1u)*4.656612873077392578125e-10f; // / 2^31, exact
+	if (u >= 1.0f) u = 0.999999940395355224609375f;     // nextafter(1, 0)
+	return __fadd_rn(__fmul_rn(u, hi - lo), lo);        // two roundings, as the x86 build of the reference has no fused multiply-add
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -1730,10 +1745,10 @@ __device__ __forceinline__ void computeRecord(const DevBatch &d, const HopDesc &
 	}
 	const float2 mpL = src.mapAt(min(b + L, M - 1));
 	float tfUp = hd.timeFactor, tfDn = hd.timeFactor;
-	if (randomTf) { // uniform(4 - tf, tf): one draw per bin and direction (:640,:749,:769)
-		const float lo = 4.0f - hd.timeFactor, span = hd.timeFactor - lo;
-		tfUp = lo + span*hashUniform(hd.seed, b, 0);
-		tfDn = lo + span*hashUniform(hd.seed, b, 1);
+	if (randomTf) { // uniform(4 - tf, tf): the upward steps of bin b take draw 2b - 1 of the hop, the downward steps draw 2b (:640,:749,:769)
+		const float lo = 4.0f - hd.timeFactor;
+		if (b > 0) tfUp = engineDraw(d, hd.seed, 2*b - 1, lo, hd.timeFactor);
+		if (b < M - 1) tfDn = engineDraw(d, hd.seed, 2*b, lo, hd.timeFactor);
 	}
 	auto twists = [&](int cm, float2 Pcm, float2 &A, float2 &B, float2 &Cc, float2 &Dc) {
 		const float2 *in = src.inRow(cm);

@@ -147,12 +147,12 @@ def case_api_surface(lib, ref, cfg=SMALL, scale=1):
 
 
 def case_random_call_sequences(lib, ref, seeds=range(6), cfg=SMALL, calls=14):
-    """API fuzz: a seeded random walk over the public members -- process() with ragged chunks at changing ratios (0.75 ... 1.6) and
-    input-only calls, setTransposeSemitones / setTransposeFactor / setFormantFactor / setFormantBase between calls, seek(), flush() of
-    up to one interval, reset() -- replayed on the product, the checker and the perturbed checkers (check_scenario).  Short walks (a
-    few dozen hops), so the sample-domain comparison stays informative; 1-3 channels.  Left out on purpose: whatever draws from the
-    reference's implementation-defined RandomEngine (output without input and any other stretch beyond 2x, flushes longer than an
-    interval): case_random_time_factor* cover those by level and determinism."""
+    """API fuzz: a seeded random walk over the public members -- process() with ragged chunks at changing ratios (0.75 ... 2.6), input-only
+    and output-only calls, setTransposeSemitones / setTransposeFactor / setFormantFactor / setFormantBase between calls, seek(), flush()
+    of up to 2.3 intervals, reset() -- replayed on the product, the checker and the perturbed checkers (check_scenario).  Short walks (a
+    few dozen hops), so the sample-domain comparison stays informative; 1-3 channels.  Stretches beyond 2x (output without input, long
+    flushes, the first hop after a start or reset) draw random time factors: product and checker are constructed with the same seed
+    and the product replicates the checker's std::default_random_engine (smst_kernels.hip: engineDraw), so they stay comparable."""
     sr = 48000
     seeds = list(seeds)
     uninformative = []
@@ -188,19 +188,22 @@ def case_random_call_sequences(lib, ref, seeds=range(6), cfg=SMALL, calls=14):
                         o.setFormantFactor(float(rng.choice([0.9, 1.0, 1.15])), bool(rng.integers(0, 2)))
                     else:
                         o.setFormantBase(float(rng.choice([0.0, 150.0/sr])))
-                    ratio = float(rng.choice([0.75, 1.0, 1.3, 1.6]))
-                elif kind == "flush":  # at most one interval: a longer flush draws from the implementation-defined RandomEngine (DESIGN section 2 ii)
-                    outs.append(o.flush(int(rng.integers(1, o.intervalSamples() + 1))))
+                    ratio = float(rng.choice([0.75, 1.0, 1.3, 1.6, 2.6]))
+                elif kind == "flush":  # up to 2.3 intervals: beyond one interval the flush runs hops at a huge time factor (random engine, below)
+                    outs.append(o.flush(int(rng.integers(1, 300))))
                 elif kind == "seek":
                     n = int(rng.integers(50, 700))
                     o.seek(xx[:, pos:pos + n], float(rng.choice([0.8, 1.0, 1.2])))
                     pos += n
                 elif kind == "reset":
                     o.reset()
-                elif kind == "empty":  # input without output (output without input is a stretch beyond 2x: random time factors, no parity)
-                    n = int(rng.integers(1, 200))
-                    outs.append(o.process(xx[:, pos:pos + n], 0))
-                    pos += n
+                elif kind == "empty":  # output without new input (a stretch beyond 2x: random time factors) / input without output
+                    if rng.integers(0, 2):
+                        outs.append(o.process(xx[:, pos:pos], int(rng.integers(1, 200))))
+                    else:
+                        n = int(rng.integers(1, 200))
+                        outs.append(o.process(xx[:, pos:pos + n], 0))
+                        pos += n
                 else:
                     n = int(rng.integers(1, 900))
                     outs.append(o.process(xx[:, pos:pos + n], max(1, int(n*ratio))))
@@ -495,13 +498,44 @@ def case_random_time_factor_seeds(lib, ref, cfg=None, streams=8, stretch=2.5, se
     worst = 0.0
     skip = 2*int(0.12*sr)
     for s in range(streams):
-        r = make("ref", lib, ref, C, cfg)
+        r = make("ref", lib, ref, C, cfg, seed=7 + s)  # stream s of a batch = the reference instance seeded with seed + s
         o = r.process(xs[s], nout)
         ra, rb = np.sqrt(np.mean(outs["a"][s][:, skip:]**2)), np.sqrt(np.mean(o[:, skip:]**2))
         worst = max(worst, abs(ra/rb - 1))
         assert abs(ra/rb - 1) < level_tol, ("level at %.1fx" % stretch, s, ra, rb)
         assert np.isfinite(outs["a"][s]).all()
     return dict(level=worst)
+
+
+def case_random_time_factor_parity(lib, ref, geometries=(SMALL,), seeds=(0, 12345, -7)):
+    """Beyond 2x the reference draws a time factor per bin and direction from std::default_random_engine (:639-640, :749, :769) --
+    implementation-defined in general, but defined for the checker (g++ / libstdc++: minstd_rand0 through
+    uniform_real_distribution<float>), and the product replicates exactly that engine (smst_kernels.hip: engineDraw; the host advances
+    every stream's engine state by 2M - 2 draws per randomised hop).  So with the same seed the SAMPLES are comparable: teacher-forced
+    single hops at 2.5x, free-running 2.5x and 4x over short horizons, output without input, and a flush of several intervals."""
+    worst = {}
+    for cfg in geometries:
+        name = cfg.get("preset", "configure")
+        worst["forced/" + name] = case_teacher_forced(lib, ref, cfg, 2, 2.5, "forced 2.5x " + name)
+        scale = 1 if cfg.get("preset") == "configure" else 11
+        C, sr = 2, int(cfg.get("sample_rate", 48000))
+        for seed in seeds:
+            x = synth_input(1, C, 4000*scale, sr) + 0.3*synth_input(5, C, 4000*scale, sr)
+
+            def run(play, label, seed=seed):
+                g, r = make("product", lib, ref, C, cfg, seed=seed), make("ref", lib, ref, C, cfg, seed=seed)
+                y, o = play(g, x), play(r, x)
+                o2 = [play(make("ref", lib, ref, C, cfg, seed=seed), perturbed(x, k)) for k in SELF_SEEDS]
+                assert_parity(y, o, o2, r.intervalSamples(), "%s (%s, seed %d)" % (label, name, seed))
+                return rel_rms(y, o)
+            worst["2.5x/%s/%d" % (name, seed)] = run(lambda ob, xx: ob.process(xx[:, :1200*scale], 3000*scale), "free-running 2.5x")
+            worst["4x/%s/%d" % (name, seed)] = run(lambda ob, xx: ob.process(xx[:, :600*scale], 2400*scale), "free-running 4x")
+            worst["output-only/%s/%d" % (name, seed)] = run(
+                lambda ob, xx: np.concatenate([ob.process(xx[:, :1500*scale], 1500*scale), ob.process(xx[:, :0], 300*scale), ob.process(xx[:, 1500*scale:2500*scale], 1000*scale)], axis=1),
+                "output without input")
+            worst["flush/%s/%d" % (name, seed)] = run(
+                lambda ob, xx: np.concatenate([ob.process(xx[:, :2000*scale], 2400*scale), ob.flush(700*scale)], axis=1), "flush of 5 intervals")
+    return worst
 
 
 def case_sub_batches(lib, ref, monkeypatch):
@@ -652,8 +686,9 @@ def case_teacher_forced(lib, ref, cfg, channels, stretch, label, setup=None, war
     kw = dict(preset=cfg["preset"], sample_rate=cfg.get("sample_rate", 48000.0)) if cfg.get("preset") in ("default", "cheaper") else \
         dict(block=cfg["block"], interval=cfg["interval"], split=cfg.get("split", False))
     b = pkg.StretchBatch(S, channels, lib=lib, **kw)
-    refs = [make("ref", lib, ref, channels, cfg, setup) for _ in streams]
-    twins = [make("ref", lib, ref, channels, cfg, setup) for _ in streams]  # the perturbed-input checkers
+    # stream i of a batch is the reference instance constructed with seed + i (include/smst.h): same random engine, same draws beyond 2x
+    refs = [make("ref", lib, ref, channels, cfg, setup, seed=i) for i, _ in enumerate(streams)]
+    twins = [make("ref", lib, ref, channels, cfg, setup, seed=i) for i, _ in enumerate(streams)]  # the perturbed-input checkers
     if setup:
         setup(b)
     I = b.intervalSamples()

@@ -158,3 +158,7 @@ def test_across_equals_single_hop_emu(emu, monkeypatch):
 
 def test_random_call_sequences_emu(emu, ref):
     pc.case_random_call_sequences(emu, ref, seeds=range(6))
+
+
+def test_random_time_factor_parity_emu(emu, ref):
+    print(pc.case_random_time_factor_parity(emu, ref))

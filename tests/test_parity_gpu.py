@@ -572,3 +572,10 @@ def test_random_call_sequences(hip, ref):
     """API fuzz against the checker: seeded random walks over process / parameter setters / seek / flush / reset."""
     pc.case_random_call_sequences(hip, ref, seeds=range(12))
     pc.case_random_call_sequences(hip, ref, seeds=range(100, 104), cfg=pc.SMALL_SPLIT)
+
+
+def test_random_time_factor_parity(hip, ref):
+    """Stretch beyond 2x, output without input, long flushes: the product replicates the checker's std::default_random_engine, so
+    samples are compared, not just levels."""
+    r = pc.case_random_time_factor_parity(hip, ref, geometries=(pc.SMALL, dict(preset="default", sample_rate=48000.0)), seeds=(0, 12345))
+    _report("random_time_factor_parity", {k.replace("/", "_"): (v if isinstance(v, float) else v.get("spectrum")) for k, v in r.items()})
