@@ -2093,7 +2093,9 @@ __device__ __forceinline__ void vocoderProduceStaged(const DevBatch &d, int s, i
 		if (interior(n)) {
 #pragma unroll
 			for (int i = 0; i < G::LOADS; ++i) {
-				const int sb = BS*n + pbin[i];
+				// lanes without a piece (beyond TOTAL, rows beyond the tile's hops) load from the start of the rotation table: their
+				// piece description may point a few bins past a row's end (found by the address sanitiser on the CPU stand-in)
+				const int sb = pok[i] ? BS*n + pbin[i] : 0;
 				v[i] = *reinterpret_cast<const float4 *>(psrc[i] + sb); // 8-byte aligned; dword alignment suffices on gfx9
 				if (i == G::LOADS - 1 && pen[i]) ve = loadEnergyPair(d, penergy + sb);
 			}

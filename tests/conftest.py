@@ -66,6 +66,8 @@ def ref():
 def emu():
     """Product sources compiled against the CPU stand-in for the HIP runtime (tests/emu) -- host-logic checks only."""
     pkg = package()
+    if os.environ.get("SMST_EMU_LIBRARY"):  # e.g. a -fsanitize=address,undefined build of the same sources (tests/emu/build_emu.sh asan)
+        return pkg.bind(ctypes.CDLL(os.environ["SMST_EMU_LIBRARY"]))
     so = os.path.join(ROOT, "tests", "emu", "libsmst_emu.so")
     srcs = [os.path.join(pkg.CSRC_DIR, f) for f in os.listdir(pkg.CSRC_DIR)] + [
         os.path.join(ROOT, "tests", "emu", "hip_emu.cpp"), os.path.join(ROOT, "tests", "emu", "hip", "hip_runtime.h"),
