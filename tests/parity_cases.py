@@ -405,7 +405,7 @@ def case_half_state(lib, ref, cfg, channels, stretch, label, setup=None, hops=30
         dict(block=cfg["block"], interval=cfg["interval"], split=cfg.get("split", False))
     b = pkg.StretchBatch(S, channels, lib=lib, half_state=True, **kw)
     assert b.lib.smst_batch_half_state(b.h) == 1
-    refs = [make("ref", lib, ref, channels, cfg, setup) for _ in streams]
+    refs = [make("ref", lib, ref, channels, cfg, setup, seed=i) for i, _ in enumerate(streams)]  # stream i of a batch = the instance seeded seed + i
     if setup:
         setup(b)
     I = b.intervalSamples()
@@ -452,9 +452,9 @@ def case_batch_ragged(lib, ref, cfg=SMALL, S=5, n=6000):
     y = b.process(xs, nout, in_samples=nin)
     for s in range(S):
         setup = lambda o, s=s: o.setTransposeSemitones(float(semis[s]), 0.0)  # noqa: E731
-        r = make("ref", lib, ref, C, cfg, setup)
+        r = make("ref", lib, ref, C, cfg, setup, seed=s)  # stream s of a batch = the instance seeded seed + s
         o = r.process(xs[s][:, :nin[s]], nout[s])
-        o2 = [make("ref", lib, ref, C, cfg, setup).process(perturbed(xs[s][:, :nin[s]], seed), nout[s]) for seed in SELF_SEEDS]
+        o2 = [make("ref", lib, ref, C, cfg, setup, seed=s).process(perturbed(xs[s][:, :nin[s]], seed), nout[s]) for seed in SELF_SEEDS]
         assert_parity(y[s][:, :nout[s]], o, o2, cfg["interval"], "batch stream %d" % s, require_informative=False)
         ra, rb = np.sqrt(np.mean(y[s][:, :nout[s]]**2)), np.sqrt(np.mean(o**2))  # phase-free: output level within 1 %
         assert abs(ra/rb - 1) < 0.01, (s, ra, rb)
@@ -775,8 +775,8 @@ def case_hop_magnitudes(lib, ref, cfg, channels, stretch, label, setup=None, hop
     kw = dict(preset=cfg["preset"], sample_rate=cfg.get("sample_rate", 48000.0)) if cfg.get("preset") in ("default", "cheaper") else \
         dict(block=cfg["block"], interval=cfg["interval"], split=cfg.get("split", False))
     b = pkg.StretchBatch(S, channels, lib=lib, **kw)
-    refs = [make("ref", lib, ref, channels, cfg, setup) for _ in streams]
-    twins = [make("ref", lib, ref, channels, cfg, setup) for _ in streams] if setup else None
+    refs = [make("ref", lib, ref, channels, cfg, setup, seed=i) for i, _ in enumerate(streams)]  # stream i of a batch = the instance seeded seed + i
+    twins = [make("ref", lib, ref, channels, cfg, setup, seed=i) for i, _ in enumerate(streams)] if setup else None
     if setup:
         setup(b)
     I = b.intervalSamples()

@@ -78,9 +78,9 @@ def _batch_vs_ref(hip, ref, S, C, sr, n, nout, cfg, preset, label, setup=None, p
                 setup(o)
             if per_stream_setup:
                 per_stream_setup(o, s, None)
-        r = pc.make("ref", hip, ref, C, cfg, one)
+        r = pc.make("ref", hip, ref, C, cfg, one, seed=s)  # stream s of a batch = the instance seeded seed + s
         o = r.process(xs[s], nouts[s])
-        o2 = [pc.make("ref", hip, ref, C, cfg, one).process(pc.perturbed(xs[s], seed), nouts[s]) for seed in pc.SELF_SEEDS]
+        o2 = [pc.make("ref", hip, ref, C, cfg, one, seed=s).process(pc.perturbed(xs[s], seed), nouts[s]) for seed in pc.SELF_SEEDS]
         pc.assert_parity(y[s][:, :nouts[s]], o, o2, r.intervalSamples(), "%s stream %d" % (label, s), cap=cap, require_informative=False)
         # phase-free check that survives decorrelation (SURVEY App. D.2 iv): output energy within 1 %
         ra, rb = np.sqrt(np.mean(y[s][:, :nouts[s]]**2)), np.sqrt(np.mean(o**2))
