@@ -5,7 +5,8 @@
 // the instruction: op_sel / op_sel_hi pick, per result lane, which half of each 64-bit source is read, neg_lo / neg_hi negate
 // a source for one lane.  So a complex multiply is TWO instructions, a complex multiply-add is two as well.  The bin
 // recurrence (signalsmith-stretch.h:744-800) is five complex multiplies per step on ONE wave per stream, and that wave is
-// the critical path of the whole pipeline: these helpers take ~20 of its ~105 instructions per step.
+// a serial chain of M + 5*63 steps per 64-hop tile (it WAS the critical path of the kernel when these helpers were written; since
+// then the producers' window loads are -- DESIGN.md section 5): these helpers take ~20 of its ~50 instructions per step.
 //
 // Rounding (every kernel uses the same helpers, so staged / gathering / single-hop / un-fused paths stay bit-identical):
 //   cmul(a, b)     re = fma(a.y, -b.y, rnd(a.x*b.x))        im = fma(a.y, b.x, rnd(a.x*b.y))

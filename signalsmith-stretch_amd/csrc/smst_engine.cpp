@@ -368,7 +368,8 @@ void Batch::releaseAll() {
 	if (stChain) hipStreamSynchronize(stChain);
 	if (stSynth) hipStreamSynchronize(stSynth);
 	if (stGate) hipStreamSynchronize(stGate);
-	for (auto &e : liveEvents) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
+	for (auto &e : livePool) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
+	livePool.clear();
 	liveEvents.clear();
 	for (void *p : allocations) hipFree(p);
 	allocations.clear();
@@ -599,6 +600,24 @@ template <typename F> void Batch::timed(double &acc, F &&f) {
 	hipEventDestroy(a);
 	hipEventDestroy(b);
 }
+void Batch::growLivePool(size_t pairs) {
+	// timing events WITHOUT the default system-scope fences: those drain and flush at every record and slowed the
+	// recurrence from 1.2 to 1.7 ms per launch (and the step by 7 %)
+	while (livePool.size() < pairs) {
+		hipEvent_t a = nullptr, b = nullptr;
+		SMST_HIP(hipEventCreateWithFlags(&a, hipEventDisableSystemFence));
+		SMST_HIP(hipEventCreateWithFlags(&b, hipEventDisableSystemFence));
+		livePool.emplace_back(a, b);
+	}
+}
+void Batch::enableProfiling(int mode) {
+	profiling = mode == 1;
+	liveTiming = mode == 2;
+	if (liveTiming) {
+		SMST_HIP(hipSetDevice(dev));
+		growLivePool(1024); // 128 steps of the headline workload between two takeTimings(): no event is created inside process()
+	}
+}
 BatchTimings Batch::takeTimings() {
 	if (!liveEvents.empty()) {
 		SMST_HIP(hipSetDevice(dev));
@@ -608,10 +627,8 @@ BatchTimings Batch::takeTimings() {
 			SMST_HIP(hipEventElapsedTime(&ms, e.first, e.second));
 			timings.chainLiveMs += ms;
 			++timings.chainLiveLaunches;
-			hipEventDestroy(e.first);
-			hipEventDestroy(e.second);
 		}
-		liveEvents.clear();
+		liveEvents.clear(); // the pairs go back to the pool
 	}
 	BatchTimings t = timings;
 	timings = BatchTimings();
@@ -916,10 +933,9 @@ void Batch::process(const float *in, long long inSS, long long inCS, const int *
 			if (th[0]) {
 				hipEvent_t liveA = nullptr, liveB = nullptr;
 				if (liveTiming && !serial) {
-					// timing events WITHOUT the default system-scope fences: those drain and flush at every record and slowed the
-					// recurrence from 1.2 to 1.7 ms per launch (and the step by 7 %)
-					SMST_HIP(hipEventCreateWithFlags(&liveA, hipEventDisableSystemFence));
-					SMST_HIP(hipEventCreateWithFlags(&liveB, hipEventDisableSystemFence));
+					if (liveEvents.size() == livePool.size()) growLivePool(livePool.size() + 64); // only if a run outgrows what enableProfiling() made
+					liveA = livePool[liveEvents.size()].first;
+					liveB = livePool[liveEvents.size()].second;
 					SMST_HIP(hipEventRecord(liveA, sC));
 				}
 				timed(timings.chainMs, [&] {

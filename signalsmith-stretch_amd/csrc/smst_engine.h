@@ -71,7 +71,8 @@ public:
 
 	hipStream_t stream() const { return st; }
 	int device() const { return dev; }
-	void enableProfiling(int mode) { profiling = mode == 1; liveTiming = mode == 2; } // 1: every kernel class, serialised; 2: recurrence kernel in place
+	void growLivePool(size_t pairs);
+	void enableProfiling(int mode); // 1: every kernel class, serialised; 2: recurrence kernel in place (timing events come from a pool created here, not inside process())
 	BatchTimings takeTimings();
 	size_t workspaceBytes() const { return wsBytes; }
 	long allocationEvents() const { return allocEvents; } // test hook: must not move across steady-state process() calls
@@ -130,7 +131,8 @@ private:
 	std::vector<StreamParams> params;
 	bool paramsDirty = true;
 	bool profiling = false, liveTiming = false;
-	std::vector<std::pair<hipEvent_t, hipEvent_t>> liveEvents;
+	std::vector<std::pair<hipEvent_t, hipEvent_t>> liveEvents; // pairs recorded since the last takeTimings()
+	std::vector<std::pair<hipEvent_t, hipEvent_t>> livePool;   // every pair ever created; [0, liveEvents.size()) are in use
 	BatchTimings timings;
 
 	std::vector<void *> allocations;

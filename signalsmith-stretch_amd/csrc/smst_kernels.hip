@@ -344,7 +344,7 @@ __device__ __forceinline__ void dftLast(float2 (&v)[R3]) {
 // prep(idx) -> any value: called for ALL outputs of a thread before the first store(idx, value, prepared), so whatever it
 // loads is in flight together (a load placed inside `store` is not moved above the preceding stores by the compiler).
 // LEAN: fewer table bytes per frame (the tables are L2-resident, but 73 KB of them per frame crossed the CU's 64-B/clk vector
-// memory path beside 48 KB of data -- ablation in DESIGN.md: tables held constant took 0.9 ms per step off the analysis and 0.4 off
+// memory path beside 48 KB of data -- ablation in EXPERIMENTS.md: tables held constant took 0.9 ms per step off the analysis and 0.4 off
 // the synthesis).  The 15 stage-A twiddles w^n come from six loaded ones (w^1..w^4, w^8, w^12: three 16-byte loads instead of
 // eight) and nine products of two of them: one extra rounding each.
 template <int SIGN, int R3, bool LEAN, typename Load, typename Prep, typename Store>

@@ -1,6 +1,6 @@
 """Reads the per-block timestamps an instrumented build of kVocoder leaves in its trace buffer (one workgroup, first 400
 blocks: producer 0, the recurrence wave, the writer) and prints where each of them spends a block.  Only meaningful with a
-library built from the instrumented sources ("timeline of one block"); a product build has no
+library built from the instrumented sources (see EXPERIMENTS.md, "what bounds kVocoder" and "Timeline of one block"); a product build has no
 selector 7 and this script fails."""
 import ctypes as C
 import os
