@@ -241,7 +241,7 @@ def main():
     S = args.streams
     n_in = int(args.seconds*sr_cfg)
     n_out = int(round(n_in*args.stretch))
-    batch = pkg.StretchBatch(S, C, preset=preset, sample_rate=sr_cfg, device=dev_index, seed=stream_rank, half_state=args.half_state)
+    batch = pkg.StretchBatch(S, C, preset=preset, sample_rate=sr_cfg, device=dev_index, seed=stream_rank*S, half_state=args.half_state)  # global stream g carries the engine of seed g
     if setup:
         setup(batch)
     if per_stream:  # config 5: per-stream random stretch 0.75-1.5x and +-12 st
