@@ -22,6 +22,8 @@ struct DevBatch {
 	int halfState;                // carried Band.output / Prediction.energy / overlap-add sums stored in fp16 (BASELINE config 5 "fp16 internal")
 	int fftLean;                  // SMST_FFT_TABLES=lean: register-blocked FFT kernels with the smaller tables (opt-in experiment, see smst_engine.cpp)
 	int noFastFft;                // SMST_NO_FAST_FFT: the generic radix-4/2/3/5 ladder even where a register-blocked FFT exists (cross-check)
+	int fftTeams;                 // analysis / synthesis by persistent workgroups of three free-running teams, tables in LDS (default; SMST_FFT_TEAMS=0: one frame per workgroup)
+	int teamsGrid;                // their grid: one workgroup per CU, a multiple of 8
 	int noStage;                  // SMST_NO_STAGE: producers of the fused kernel gather from HBM even where staging applies
 	FftPlan plan;
 	// constant tables
@@ -75,7 +77,7 @@ struct IoArgs {
 };
 
 void launchEnergy(const DevBatch &d, const IoArgs &io, int sBase, int nStreams, float *energyOut, hipStream_t st);
-void launchAnalyse(const DevBatch &d, const IoArgs &io, int sBase, int nStreams, int hopBase, int tileHops, hipStream_t st);
+void launchAnalyse(const DevBatch &d, const IoArgs &io, int sBase, int nStreams, int hopBase, int tileHops, bool anyInCall, bool anyLate, hipStream_t st);
 bool launchFeed(const DevBatch &d, int sBase, int nStreams, int hopBase, int tileHops, bool anyFormants, hipStream_t st); // true: pass A done too
 void launchPredict(const DevBatch &d, int sBase, int nStreams, int hopBase, int tileHops, bool plain, bool passADone, hipStream_t st);
 void launchChain(const DevBatch &d, int sBase, int nStreams, int hopBase, hipStream_t st);

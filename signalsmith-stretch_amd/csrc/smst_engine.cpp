@@ -180,6 +180,13 @@ void Batch::construct(const FftPlan &plan, long seed) {
 	d.fftLean = 0;
 	if (const char *env = std::getenv("SMST_FFT_TABLES")) d.fftLean = std::string(env) == "lean";
 	d.feedSerial = std::getenv("SMST_FEED_SERIAL") != nullptr;
+	d.fftTeams = 1;
+	if (const char *env = std::getenv("SMST_FFT_TEAMS")) d.fftTeams = atoi(env);
+	{
+		int cus = 0;
+		SMST_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+		d.teamsGrid = std::max(8, cus/8*8);
+	}
 
 	// constant tables
 	std::vector<float2> tw(M), half(M), rot(M);
@@ -846,7 +853,12 @@ void Batch::process(const float *in, long long inSS, long long inCS, const int *
 			unsigned char *th = tileHasV.data() + (size_t)(sub*nTiles + t)*8;
 			for (int h = h0; h < h1; ++h) {
 				const unsigned f = list[h].flags;
-				if (f & HOP_NEW_SPECTRUM) { lastNewLocal = h - h0; th[3] = 1; }
+				if (f & HOP_NEW_SPECTRUM) {
+					lastNewLocal = h - h0; th[3] = 1;
+					// analysis frames whose window lies in this call's input ([5], taken by kAnalyseTeams) / reaches into the history ([6])
+					const bool aligned = d.M - d.B/2 == d.M/16 && d.B - d.B/2 == 15*(d.M/16);
+					for (int which = 0; which < ((f & HOP_REANALYSE_PREV) ? 2 : 1); ++which) th[(aligned && list[h].inputOffset - (which ? d.I : 0) - d.B >= 0) ? 5 : 6] = 1;
+				}
 				th[0] = 1;
 				if (f & HOP_MAPPED) th[1] = 1;
 				if (f & HOP_FORMANTS) th[2] = 1;
@@ -913,7 +925,7 @@ void Batch::process(const float *in, long long inSS, long long inCS, const int *
 			}
 			if (!serial && fused && !plain && q >= 1) SMST_HIP(hipStreamWaitEvent(sF, evChain[slot ^ 1], 0)); // pass A reads the carried state
 			if (th[0]) {
-				if (th[3]) timed(timings.analyseMs, [&] { launchAnalyse(dd, io, sBase, ns, hopBase, tileHops, sF); if (profiling) ++timings.analyseLaunches; });
+				if (th[3]) timed(timings.analyseMs, [&] { launchAnalyse(dd, io, sBase, ns, hopBase, tileHops, th[5] != 0, th[6] != 0, sF); if (profiling) ++timings.analyseLaunches; });
 				bool passADone = false;
 				if (th[1] || th[2]) timed(timings.feedMs, [&] { passADone = launchFeed(dd, sBase, ns, hopBase, tileHops, th[2] != 0, sF); });
 				timed(timings.predictMs, [&] {

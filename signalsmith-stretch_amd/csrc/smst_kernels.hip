@@ -90,9 +90,9 @@ __device__ __forceinline__ size_t stateRow(const DevBatch &d, int sGlobal, int c
 // optimisation only), so streams are dealt to XCDs in groups of 8 -- all blocks of a stream land on one XCD and its L2
 // serves the overlap, instead of 8 L2s each fetching the same samples.
 struct BlockCoord { int x, y, s; };
-__device__ __forceinline__ BlockCoord xcdAwareBlock() {
-	const int gx = gridDim.x, gy = gridDim.y, S = gridDim.z, n = gx*gy;
-	const int lin = blockIdx.x + gx*(blockIdx.y + gy*blockIdx.z);
+// lin: position in the order in which the hardware deals workgroups (or a persistent team its jobs) to the XCDs
+__device__ __forceinline__ BlockCoord xcdAwareCoord(int lin, int gx, int gy, int S) {
+	const int n = gx*gy;
 	const int g = lin/(8*n), rest = lin - g*8*n;
 	BlockCoord r;
 	int idx;
@@ -101,6 +101,9 @@ __device__ __forceinline__ BlockCoord xcdAwareBlock() {
 	r.x = idx%gx;
 	r.y = idx/gx;
 	return r;
+}
+__device__ __forceinline__ BlockCoord xcdAwareBlock() {
+	return xcdAwareCoord(blockIdx.x + gridDim.x*(blockIdx.y + gridDim.y*blockIdx.z), gridDim.x, gridDim.y, gridDim.z);
 }
 
 // The reference draws its random time factors (stretch beyond 2x: :639-640, :749, :769) from std::default_random_engine through
@@ -347,10 +350,13 @@ __device__ __forceinline__ void dftLast(float2 (&v)[R3]) {
 // memory path beside 48 KB of data -- ablation in EXPERIMENTS.md: tables held constant took 0.9 ms per step off the analysis and 0.4 off
 // the synthesis).  The 15 stage-A twiddles w^n come from six loaded ones (w^1..w^4, w^8, w^12: three 16-byte loads instead of
 // eight) and nine products of two of them: one extra rounding each.
-template <int SIGN, int R3, bool LEAN, typename Load, typename Prep, typename Store>
-__device__ __forceinline__ void fftFast(float2 *lds, const float4 *__restrict__ twA, const float4 *__restrict__ twB, Load load, Prep prep, Store store) {
+struct BlockSync { __device__ __forceinline__ void operator()() const { __syncthreads(); } };
+// t / sync: a workgroup may hold several TEAMS of 256 threads, each transforming its own frame in its own `lds` at its own pace;
+// t is then the index within the team and sync() the team's barrier
+template <int SIGN, int R3, bool LEAN, typename Load, typename Prep, typename Store, typename Sync = BlockSync>
+__device__ __forceinline__ void fftFast(float2 *lds, const float4 *__restrict__ twA, const float4 *__restrict__ twB, Load load, Prep prep, Store store,
+                                        const int t = threadIdx.x, Sync sync = Sync()) {
 	constexpr int MA = 16*R3;
-	const int t = threadIdx.x;
 	float2 v[16];
 	// stage A: radix 16, stride 1
 	if (t < MA) {
@@ -387,14 +393,14 @@ __device__ __forceinline__ void fftFast(float2 *lds, const float4 *__restrict__ 
 			lds[17*t + n] = val; // padded index of 16 t + n
 		}
 	}
-	__syncthreads();
+	sync();
 	// stage B: radix 16, stride 16
 	const int p = t >> 4, q0 = t & 15;
 	if (t < MA) {
 #pragma unroll
 		for (int k = 0; k < 16; ++k) v[k] = lds[q0 + 17*(p + R3*k)];
 	}
-	__syncthreads();
+	sync();
 	if (t < MA) {
 		float4 wB[8];
 #pragma unroll
@@ -413,7 +419,7 @@ __device__ __forceinline__ void fftFast(float2 *lds, const float4 *__restrict__ 
 			lds[q0 + 256*p + 16*n] = val;
 		}
 	}
-	__syncthreads();
+	sync();
 	// stage C: radix R3, stride 256, no twiddles
 	if (t < 256) {
 		constexpr int G = LastStage<R3>::G, RA = LastStage<R3>::RA;
@@ -446,8 +452,15 @@ __device__ __forceinline__ void fftFast(float2 *lds, const float4 *__restrict__ 
 	}
 }
 
+// The whole analysis window of the hop lies in this call's input, and the halves of the packed input change validity at element-slot
+// boundaries (both presets): the frames that kAnalyseTeams takes.  The host evaluates the same condition (smst_engine.cpp).
+__device__ __forceinline__ bool analysisWindowInCall(const DevBatch &d, const HopDesc &hd, int which) {
+	const int halfB = d.B/2, MA = d.M/16;
+	return d.M - halfB == MA && d.B - halfB == 15*MA && hd.inputOffset - (which ? d.I : 0) - d.B >= 0;
+}
+
 template <int R3, bool LEAN>
-__global__ __launch_bounds__(16*R3 > 256 ? 16*R3 : 256) __attribute__((amdgpu_waves_per_eu(4, 4))) void kAnalyseFast(DevBatch d, IoArgs io, int sBase, int hopBase) {
+__global__ __launch_bounds__(16*R3 > 256 ? 16*R3 : 256) __attribute__((amdgpu_waves_per_eu(4, 4))) void kAnalyseFast(DevBatch d, IoArgs io, int sBase, int hopBase, int lateOnly) {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smemRaw[];
 	float2 *lds = reinterpret_cast<float2 *>(smemRaw);
 	const BlockCoord bc = xcdAwareBlock();
@@ -458,6 +471,7 @@ __global__ __launch_bounds__(16*R3 > 256 ? 16*R3 : 256) __attribute__((amdgpu_wa
 	const HopDesc hd = d.hops[(size_t)(sBase + s)*d.hopStride + hopBase + k];
 	if (!(hd.flags & HOP_ACTIVE) || !(hd.flags & HOP_NEW_SPECTRUM)) return;
 	if (which == 1 && !(hd.flags & HOP_REANALYSE_PREV)) return;
+	if (lateOnly && analysisWindowInCall(d, hd, which)) return; // kAnalyseTeams has taken this frame
 	const int B = d.B, H = d.M, halfB = B/2, N = d.N;
 	const int base = hd.inputOffset - (which ? d.I : 0) - B;
 	const float *x = io.in + (size_t)(sBase + s)*io.inStreamStride + (size_t)c*io.inChannelStride;
@@ -527,6 +541,74 @@ __global__ __launch_bounds__(16*R3 > 256 ? 16*R3 : 256) __attribute__((amdgpu_wa
 		}, prep, store);
 }
 
+// ------------------------------------------------------------------------------------------------------
+// K1 by persistent TEAMS (the default for the 2560- and 3072-bin geometries; SMST_FFT_TEAMS=0: one frame per workgroup): one workgroup per CU, three teams of 256 threads, each team transforming
+// frame after frame AT ITS OWN PACE -- the barriers of a transform are the team's (an LDS counter its four waves spin on), not the
+// workgroup's.  The folded window and the stage twiddles (76 KB) are copied to LDS once per workgroup and shared by the teams, so
+// per frame only the samples come in and the spectrum goes out (kAnalyseFast pulls 74 KB of tables through L1 per frame).
+// Same table values, same operations in the same order: bit-identical to kAnalyseFast.
+// ------------------------------------------------------------------------------------------------------
+struct TeamSync { // LDS operations of a wave complete in order: a wave's counter increment is seen after its data writes / reads
+	volatile int *word;
+	int *generation;
+	__device__ __forceinline__ void operator()() const {
+		asm volatile("" ::: "memory");
+		__builtin_amdgcn_wave_barrier(); // (the CPU stand-in runs a wave lane by lane: every lane reaches the barrier before lane 0 signals)
+		if ((threadIdx.x & 63) == 0) (void)__hip_atomic_fetch_add(const_cast<int *>(word), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+		*generation += 4;
+		while (__hip_atomic_load(const_cast<int *>(word), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < *generation) __builtin_amdgcn_s_sleep(1);
+		__builtin_amdgcn_wave_barrier();
+		asm volatile("" ::: "memory");
+	}
+};
+
+template <int R3, int TEAMS>
+__global__ __launch_bounds__(256*TEAMS) void kAnalyseTeams(DevBatch d, IoArgs io, const HopDesc *__restrict__ hopTable, int sBase, int hopBase, int tileHops, int nStreams) {
+	static_assert(16*R3 <= 256, "a team is 256 threads");
+	extern __shared__ __attribute__((aligned(16))) unsigned char smemRaw[];
+	constexpr int MA = 16*R3, H = 256*R3, N = 2*H, B = 480*R3, halfB = B/2; // the geometry this kernel is launched for (analysisWindowInCall)
+	const int team = __builtin_amdgcn_readfirstlane(threadIdx.x >> 8), t = threadIdx.x & 255, tA = t < MA ? t : 0;
+	const int total = tileHops*2*d.C*nStreams;
+	float4 *winLds = reinterpret_cast<float4 *>(smemRaw); // (winA, winB) of all elements
+	float4 *twALds = winLds + H;                           // first-stage twiddles, [8][MA]
+	float4 *twBLds = twALds + 8*MA;                        // second-stage twiddles, [8][R3]
+	float2 *lds = reinterpret_cast<float2 *>(twBLds + 8*R3) + (size_t)team*(H + H/16);
+	volatile int *words = reinterpret_cast<volatile int *>(reinterpret_cast<float2 *>(twBLds + 8*R3) + (size_t)TEAMS*(H + H/16));
+	for (int i = threadIdx.x; i < H; i += blockDim.x) winLds[i] = d.win4[i];
+	for (int i = threadIdx.x; i < 8*MA; i += blockDim.x) twALds[i] = d.twA4[i];
+	for (int i = threadIdx.x; i < 8*R3; i += blockDim.x) twBLds[i] = d.twB4[i];
+	if (threadIdx.x < 16) words[threadIdx.x] = 0;
+	__syncthreads();
+	int generation = 0;
+	const TeamSync sync{words + team, &generation};
+	const int stride = gridDim.x*TEAMS;
+	for (int lin = blockIdx.x + gridDim.x*team; lin < total; lin += stride) { // the same residue mod 8 for all of a workgroup's teams
+		const BlockCoord bc = xcdAwareCoord(lin, tileHops, 2*d.C, nStreams);
+		const HopDesc hd = hopTable[(size_t)(sBase + bc.s)*d.hopStride + hopBase + bc.x];
+		const int c = bc.y >> 1, which = bc.y & 1;
+		if (!(hd.flags & HOP_ACTIVE) || !(hd.flags & HOP_NEW_SPECTRUM) || (which && !(hd.flags & HOP_REANALYSE_PREV)) || !analysisWindowInCall(d, hd, which)) continue;
+		const int base = hd.inputOffset - (which ? d.I : 0) - B;
+		const float *x = io.in + (size_t)(sBase + bc.s)*io.inStreamStride + (size_t)c*io.inChannelStride;
+		const float *x0 = x + base + halfB, *x1 = x + base - H + halfB; // slot 0 has no imaginary part, slot 15 no real part
+		float2 *dst = (which ? d.Xprev : d.Xcur) + rowOf(d, bc.s, bc.x, c);
+		fftFast<-1, R3, false>(lds, twALds, twBLds,
+			[&](int m, int slot) { // kAnalyseFast's roundings: round(xi*b + round(xr*a)), the absent half an exact zero
+				const float4 w = winLds[tA + MA*slot];
+				float2 r = make_float2(0.f, 0.f);
+				if (slot < 15) { const float xr = x0[m]; r = make_float2(xr*w.x, xr*w.y); }
+				if (slot > 0) { const float xi = x1[m]; r = make_float2(fmaf(xi, w.z, r.x), fmaf(xi, w.w, r.y)); }
+				return r;
+			},
+			[](int, int) { return 0; },
+			[&](int j, float2 u, int, int) {
+				const int kk = 2*j;
+				if (kk < H) dst[kk] = u;
+				else dst[N - 1 - kk] = cconj(u);
+			}, t, sync);
+		sync(); // the last stage's LDS reads, before the next frame's first-stage writes
+	}
+}
+
 template <int R3, bool LEAN>
 __global__ __launch_bounds__(16*R3 > 256 ? 16*R3 : 256) void kSynthFast(DevBatch d, int sBase, int hopBase) {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smemRaw[];
@@ -582,6 +664,53 @@ __global__ __launch_bounds__(16*R3 > 256 ? 16*R3 : 256) void kSynthFast(DevBatch
 			if (m < B - halfB) frame[m + halfB] = (2*v.x)*r.z;
 			if (m >= H - halfB) frame[m - H + halfB] = (2*v.y)*r.w;
 		});
+}
+
+// K4a by persistent teams (see kAnalyseTeams): kSynthFast's transform with kAnalyseTeams' organisation -- the (twiddle, window) table of
+// the outputs and the stage twiddles sit in LDS, a team synthesises frame after frame at its own pace.  Bit-identical to kSynthFast.
+template <int R3, int TEAMS>
+__global__ __launch_bounds__(256*TEAMS) void kSynthTeams(DevBatch d, const HopDesc *__restrict__ hopTable, int sBase, int hopBase, int tileHops, int nStreams) {
+	static_assert(16*R3 <= 256, "a team is 256 threads");
+	extern __shared__ __attribute__((aligned(16))) unsigned char smemRaw[];
+	constexpr int MA = 16*R3, H = 256*R3, N = 2*H;
+	const int team = __builtin_amdgcn_readfirstlane(threadIdx.x >> 8), t = threadIdx.x & 255;
+	const int B = d.B, halfB = B/2;
+	const int total = tileHops*d.C*nStreams;
+	float4 *synLds = reinterpret_cast<float4 *>(smemRaw); // (e^{+i pi m/N}, the two window samples of output m)
+	float4 *twALds = synLds + H;
+	float4 *twBLds = twALds + 8*MA;
+	float2 *lds = reinterpret_cast<float2 *>(twBLds + 8*R3) + (size_t)team*(H + H/16);
+	volatile int *words = reinterpret_cast<volatile int *>(reinterpret_cast<float2 *>(twBLds + 8*R3) + (size_t)TEAMS*(H + H/16));
+	for (int i = threadIdx.x; i < H; i += blockDim.x) synLds[i] = d.synTab[i];
+	for (int i = threadIdx.x; i < 8*MA; i += blockDim.x) twALds[i] = d.twA4[i];
+	for (int i = threadIdx.x; i < 8*R3; i += blockDim.x) twBLds[i] = d.twB4[i];
+	if (threadIdx.x < 16) words[threadIdx.x] = 0;
+	__syncthreads();
+	int generation = 0;
+	const TeamSync sync{words + team, &generation};
+	const int stride = gridDim.x*TEAMS;
+	for (int lin = blockIdx.x + gridDim.x*team; lin < total; lin += stride) {
+		const BlockCoord bc = xcdAwareCoord(lin, tileHops, d.C, nStreams); // x: hop, y: channel
+		const HopDesc hd = hopTable[(size_t)(sBase + bc.s)*d.hopStride + hopBase + bc.x];
+		if (!(hd.flags & HOP_ACTIVE)) continue;
+		const float2 *X = d.OUT + rowOf(d, bc.s, bc.x, bc.y);
+		float *__restrict__ frame = d.frames + ((size_t)((size_t)bc.s*d.T + bc.x)*d.C + bc.y)*(size_t)B;
+		fftFast<+1, R3, false>(lds, twALds, twBLds,
+			[&](int j, int) { // one load at a selected address, conjugated afterwards (see kSynthFast)
+				const int kk = 2*j;
+				const bool upper = kk >= H;
+				float2 v = X[upper ? N - 1 - kk : kk];
+				if (upper) v.y = -v.y;
+				return v;
+			},
+			[&](int m, int) { return synLds[m]; },
+			[&](int m, float2 u, float4 r, int) {
+				const float2 v = cmulcPlain(u, make_float2(r.x, r.y)); // * e^{+i pi m / N}
+				if (m < B - halfB) frame[m + halfB] = (2*v.x)*r.z;
+				if (m >= H - halfB) frame[m - H + halfB] = (2*v.y)*r.w;
+			}, t, sync);
+		sync(); // the last stage's LDS reads, before the next frame's first-stage writes
+	}
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -3153,14 +3282,25 @@ static inline int divUp(int a, int b) { return (a + b - 1)/b; }
 void launchEnergy(const DevBatch &d, const IoArgs &io, int sBase, int nStreams, float *energyOut, hipStream_t st) {
 	hipLaunchKernelGGL(kEnergy, dim3(nStreams, kEnergyParts), dim3(256), 256*sizeof(float), st, d, io, sBase, energyOut);
 }
-void launchAnalyse(const DevBatch &d, const IoArgs &io, int sBase, int nStreams, int hopBase, int tileHops, hipStream_t st) {
+void launchAnalyse(const DevBatch &d, const IoArgs &io, int sBase, int nStreams, int hopBase, int tileHops, bool anyInCall, bool anyLate, hipStream_t st) {
 	const dim3 grid(tileHops, d.C*2, nStreams);
 	const size_t fastLds = ((size_t)d.M + d.M/16)*sizeof(float2);
+	// persistent teams pay a 76-KB table copy per workgroup: only where every team gets a few frames
+	const bool teams = !d.noFastFft && d.fftTeams && !d.fftLean && anyInCall && (d.M == 256*10 || d.M == 256*12) && tileHops*d.C*2*nStreams >= 6*d.teamsGrid;
+	if (teams) {
+		const int jobs = tileHops*d.C*2*nStreams;
+		const int wgs = std::max(8, std::min((jobs + 2)/3/8*8, d.teamsGrid)); // one workgroup per CU, a multiple of 8 (one residue class of the job order per XCD)
+		const size_t lds = ((size_t)d.M + d.M/2 + d.M/32)*sizeof(float4) + 3*fastLds + 64; // window, first- and second-stage twiddles, a buffer per team, barrier words
+		if (d.M == 256*10) hipLaunchKernelGGL((kAnalyseTeams<10, 3>), dim3(wgs), dim3(768), lds, st, d, io, d.hops, sBase, hopBase, tileHops, nStreams);
+		else hipLaunchKernelGGL((kAnalyseTeams<12, 3>), dim3(wgs), dim3(768), lds, st, d, io, d.hops, sBase, hopBase, tileHops, nStreams);
+		if (!anyLate) return;
+	}
+	const int lateOnly = teams ? 1 : 0; // the frames whose windows reach into the carried history
 	if (!d.noFastFft) { // every preset: presetCheaper at 44.1 / 48 kHz, presetDefault at 44.1 / 48 kHz, presetCheaper at 88.2 / 96 kHz, presetDefault at 88.2 / 96 kHz
-		if (d.M == 256*10) { if (d.fftLean) hipLaunchKernelGGL((kAnalyseFast<10, true>), grid, dim3(256), fastLds, st, d, io, sBase, hopBase); else hipLaunchKernelGGL((kAnalyseFast<10, false>), grid, dim3(256), fastLds, st, d, io, sBase, hopBase); return; }
-		if (d.M == 256*12) { if (d.fftLean) hipLaunchKernelGGL((kAnalyseFast<12, true>), grid, dim3(256), fastLds, st, d, io, sBase, hopBase); else hipLaunchKernelGGL((kAnalyseFast<12, false>), grid, dim3(256), fastLds, st, d, io, sBase, hopBase); return; }
-		if (d.M == 256*20) { if (d.fftLean) hipLaunchKernelGGL((kAnalyseFast<20, true>), grid, dim3(320), fastLds, st, d, io, sBase, hopBase); else hipLaunchKernelGGL((kAnalyseFast<20, false>), grid, dim3(320), fastLds, st, d, io, sBase, hopBase); return; }
-		if (d.M == 256*24) { if (d.fftLean) hipLaunchKernelGGL((kAnalyseFast<24, true>), grid, dim3(384), fastLds, st, d, io, sBase, hopBase); else hipLaunchKernelGGL((kAnalyseFast<24, false>), grid, dim3(384), fastLds, st, d, io, sBase, hopBase); return; }
+		if (d.M == 256*10) { if (d.fftLean) hipLaunchKernelGGL((kAnalyseFast<10, true>), grid, dim3(256), fastLds, st, d, io, sBase, hopBase, lateOnly); else hipLaunchKernelGGL((kAnalyseFast<10, false>), grid, dim3(256), fastLds, st, d, io, sBase, hopBase, lateOnly); return; }
+		if (d.M == 256*12) { if (d.fftLean) hipLaunchKernelGGL((kAnalyseFast<12, true>), grid, dim3(256), fastLds, st, d, io, sBase, hopBase, lateOnly); else hipLaunchKernelGGL((kAnalyseFast<12, false>), grid, dim3(256), fastLds, st, d, io, sBase, hopBase, lateOnly); return; }
+		if (d.M == 256*20) { if (d.fftLean) hipLaunchKernelGGL((kAnalyseFast<20, true>), grid, dim3(320), fastLds, st, d, io, sBase, hopBase, lateOnly); else hipLaunchKernelGGL((kAnalyseFast<20, false>), grid, dim3(320), fastLds, st, d, io, sBase, hopBase, lateOnly); return; }
+		if (d.M == 256*24) { if (d.fftLean) hipLaunchKernelGGL((kAnalyseFast<24, true>), grid, dim3(384), fastLds, st, d, io, sBase, hopBase, lateOnly); else hipLaunchKernelGGL((kAnalyseFast<24, false>), grid, dim3(384), fastLds, st, d, io, sBase, hopBase, lateOnly); return; }
 	}
 	size_t lds = 2*(size_t)d.M*sizeof(float2);
 	hipLaunchKernelGGL(kAnalyse, grid, dim3(256), lds, st, d, io, sBase, hopBase);
@@ -3367,6 +3507,14 @@ void launchChain(const DevBatch &d, int sBase, int nStreams, int hopBase, hipStr
 void launchSynth(const DevBatch &d, int sBase, int nStreams, int hopBase, int tileHops, hipStream_t st) {
 	const dim3 grid(tileHops, d.C, nStreams);
 	const size_t fastLds = ((size_t)d.M + d.M/16)*sizeof(float2);
+	if (!d.noFastFft && d.fftTeams && !d.fftLean && (d.M == 256*10 || d.M == 256*12) && tileHops*d.C*nStreams >= 6*d.teamsGrid) {
+		const int jobs = tileHops*d.C*nStreams;
+		const int wgs = std::max(8, std::min((jobs + 2)/3/8*8, d.teamsGrid));
+		const size_t lds = ((size_t)d.M + d.M/2 + d.M/32)*sizeof(float4) + 3*fastLds + 64;
+		if (d.M == 256*10) hipLaunchKernelGGL((kSynthTeams<10, 3>), dim3(wgs), dim3(768), lds, st, d, d.hops, sBase, hopBase, tileHops, nStreams);
+		else hipLaunchKernelGGL((kSynthTeams<12, 3>), dim3(wgs), dim3(768), lds, st, d, d.hops, sBase, hopBase, tileHops, nStreams);
+		return;
+	}
 	if (!d.noFastFft) {
 		if (d.M == 256*10) { if (d.fftLean) hipLaunchKernelGGL((kSynthFast<10, true>), grid, dim3(256), fastLds, st, d, sBase, hopBase); else hipLaunchKernelGGL((kSynthFast<10, false>), grid, dim3(256), fastLds, st, d, sBase, hopBase); return; }
 		if (d.M == 256*12) { if (d.fftLean) hipLaunchKernelGGL((kSynthFast<12, true>), grid, dim3(256), fastLds, st, d, sBase, hopBase); else hipLaunchKernelGGL((kSynthFast<12, false>), grid, dim3(256), fastLds, st, d, sBase, hopBase); return; }

@@ -99,11 +99,14 @@ static inline const char *hipGetErrorString(hipError_t) { return "emu"; }
 static inline hipError_t hipGetLastError() { return 0; }
 static inline hipError_t hipSetDevice(int) { return 0; }
 static inline hipError_t hipGetDeviceCount(int *n) { *n = 1; return 0; }
+enum hipDeviceAttribute_t { hipDeviceAttributeMultiprocessorCount };
+static inline hipError_t hipDeviceGetAttribute(int *v, hipDeviceAttribute_t, int) { *v = 8; return 0; } // a small machine: persistent kernels loop over their jobs
 static inline hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) { *s = (hipStream_t)1; return 0; }
 static inline hipError_t hipStreamSynchronize(hipStream_t) { return 0; }
 static inline hipError_t hipDeviceGetStreamPriorityRange(int *lo, int *hi) { *lo = 0; *hi = 0; return 0; }
 static inline hipError_t hipStreamCreateWithPriority(hipStream_t *s, unsigned, int) { *s = (hipStream_t)1; return 0; }
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
+#define __builtin_amdgcn_readfirstlane(x) (x) /* used on wave-uniform values only */
 #define __builtin_amdgcn_s_sleep(x) emuSyncThreads()
 // wave-level votes/shuffles are only used by single-wave kernels whose lanes all reach them; the emulator runs lanes one at a
 // time, so these are provided by tests/emu/hip_emu.cpp with a gather-then-yield protocol

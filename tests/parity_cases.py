@@ -884,6 +884,34 @@ def case_fast_fft_close_to_generic(lib, monkeypatch, presets=(("cheaper", 48000)
     return worst
 
 
+def case_fft_teams_equals_per_frame(lib, monkeypatch, presets=(("cheaper", 48000), ("default", 48000)), seconds=0.6, streams=3, channels=2):
+    """Persistent analysis / synthesis workgroups (tables loaded once per workgroup, frame after frame) against one frame per
+    workgroup (SMST_FFT_TEAMS=0): the same table values and the same operations in the same order, so bit-identical -- at 1.4x with a
+    pitch shift on one stream, over two calls (the second call's first hops reach into the carried history: frames that the persistent
+    kernel leaves to the per-frame kernel), with ragged lengths."""
+    pkg = package()
+    for preset, sr in presets:
+        n = int(seconds*sr)
+        x = np.stack([synth_input(s, channels, n, sr) for s in range(streams)])
+        outs = []
+        for teams in (True, False):
+            if teams:
+                monkeypatch.delenv("SMST_FFT_TEAMS", raising=False)
+            else:
+                monkeypatch.setenv("SMST_FFT_TEAMS", "0")
+            b = pkg.StretchBatch(streams, channels, preset=preset, sample_rate=sr, lib=lib)
+            b.setTransposeSemitones(4.0, 0.2, stream=1)
+            cut = n*2//3
+            n_in = np.array([cut - 17*s for s in range(streams)], np.int32)
+            y1 = np.array(b.process(np.ascontiguousarray(x[:, :, :cut]), (n_in*1.4).astype(np.int32), in_samples=n_in), copy=True)
+            y2 = np.array(b.process(np.ascontiguousarray(x[:, :, cut:]), int((n - cut)*1.4)), copy=True)
+            b.close()
+            outs.append(np.concatenate([y1, y2], axis=2))
+        monkeypatch.delenv("SMST_FFT_TEAMS", raising=False)
+        assert np.abs(outs[0]).max() > 0.05
+        assert np.array_equal(outs[0], outs[1]), (preset, sr, float(np.abs(outs[0] - outs[1]).max()))
+
+
 def case_clone(lib):
     """smst_clone (the drop-in's copy constructor): the copy continues exactly as the original does, and independently of it."""
     pkg = package()

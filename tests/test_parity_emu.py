@@ -162,3 +162,7 @@ def test_random_call_sequences_emu(emu, ref):
 
 def test_random_time_factor_parity_emu(emu, ref):
     print(pc.case_random_time_factor_parity(emu, ref))
+
+
+def test_fft_teams_equals_per_frame_emu(emu, monkeypatch):
+    pc.case_fft_teams_equals_per_frame(emu, monkeypatch, presets=(("cheaper", 48000),), seconds=0.45, streams=3)

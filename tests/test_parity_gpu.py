@@ -579,3 +579,9 @@ def test_random_time_factor_parity(hip, ref):
     samples are compared, not just levels."""
     r = pc.case_random_time_factor_parity(hip, ref, geometries=(pc.SMALL, dict(preset="default", sample_rate=48000.0)), seeds=(0, 12345))
     _report("random_time_factor_parity", {k.replace("/", "_"): (v if isinstance(v, float) else v.get("spectrum")) for k, v in r.items()})
+
+
+def test_fft_teams_equals_per_frame(hip, monkeypatch):
+    """kAnalyseTeams (SMST_FFT_TEAMS=1) against kAnalyseFast: bit-identical."""
+    pc.case_fft_teams_equals_per_frame(hip, monkeypatch, presets=(("cheaper", 48000), ("default", 48000)), streams=5)
+    pc.case_fft_teams_equals_per_frame(hip, monkeypatch, presets=(("default", 48000),), streams=2, channels=1)
