@@ -333,8 +333,10 @@ def main():
             batch.enableProfiling(0)
             ms.pop("chain_live", None)
             launches.pop("chain_live", None)
-        names = {"analyse": "kAnalyseFast" if M in (3072, 5120, 2560, 6144) else "kAnalyse", "predict": "kPredictA/B",
-                 "chain": "kVocoder" if C <= 2 else "kVocoderN", "synth": "kSynthFast" if M in (3072, 5120, 2560, 6144) else "kSynth", "emit": "kEmit"}
+        teams = M in (2560, 3072) and os.environ.get("SMST_FFT_TEAMS", "1") != "0"  # persistent-team FFT kernels (the 48-kHz presets' geometries)
+        names = {"analyse": "kAnalyseTeams" if teams else ("kAnalyseFast" if M in (5120, 6144, 2560, 3072) else "kAnalyse"), "predict": "kPredictA/B",
+                 "chain": "kVocoder" if C <= 2 else "kVocoderN",
+                 "synth": "kSynthTeams" if teams else ("kSynthFast" if M in (5120, 6144, 2560, 3072) else "kSynth"), "emit": "kEmit"}
         launch_count = {k: launches[k] for k in ("analyse", "predict", "chain", "synth", "emit")}
         dom = max(launch_count, key=lambda k: ms[k])  # the class with the largest stand-alone time per step
         avg_ms_alone = ms[dom]/max(launch_count[dom], 1) or float("nan")
