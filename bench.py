@@ -112,6 +112,76 @@ def cpu_baseline(budget_s=5.0):
                 single_core_Msamples_s=single/1e6, realtime_x=rate/(2*2.5*SR))
 
 
+def cmd_binary_baseline(physical_cpus, seconds=30.0, stretch=1.5):
+    """The reference's OWN cmd/ binary (oracle/_ref/ref_cli = /root/reference/cmd/main.cpp compiled unmodified) on the same
+    kind of input, WAV file in -> WAV file out (so its 16-bit file I/O is inside the time): once alone on an idle core, then one
+    pinned process per physical core at the same time.  Samples counted as the GPU line counts them (in + out, per channel)."""
+    import struct
+    import tempfile
+    import numpy as np
+    exe = os.path.join(ROOT, "oracle", "_ref", "ref_cli")
+    if not os.path.exists(exe):
+        return None
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from conftest import synth_input
+    n = int(seconds*SR)
+    x = 0.8*synth_input(0, 2, n, SR)
+    tmp = tempfile.mkdtemp(prefix="smst_cmd_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    src = os.path.join(tmp, "in.wav")
+    data = np.clip(np.round(x.T*32768.0), -32768, 32767).astype("<i2").tobytes()
+    with open(src, "wb") as f:
+        f.write(b"RIFF" + struct.pack("<I", 36 + len(data)) + b"WAVEfmt " + struct.pack("<IHHIIHH", 16, 1, 2, SR, SR*4, 4, 16))
+        f.write(b"data" + struct.pack("<I", len(data)) + data)
+    samples = 2*(n + int(round(n*stretch)))
+
+    def launch(cpu, i):
+        def pin():
+            try:
+                os.sched_setaffinity(0, {cpu})
+            except OSError:
+                pass
+        return subprocess.Popen([exe, src, os.path.join(tmp, "out%d.wav" % i), "--time=%g" % stretch], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, preexec_fn=pin)
+    try:
+        t0 = time.perf_counter()
+        rc = launch(physical_cpus[0], 0).wait()
+        single = time.perf_counter() - t0
+        if rc != 0:
+            return dict(error="ref_cli exited with %d" % rc)
+        t0 = time.perf_counter()
+        procs = [launch(cpu, i) for i, cpu in enumerate(physical_cpus)]
+        ok = all(p.wait() == 0 for p in procs)
+        wall = time.perf_counter() - t0
+    finally:
+        import shutil
+        shutil.rmtree(tmp, ignore_errors=True)
+    return dict(binary="oracle/_ref/ref_cli (cmd/main.cpp, unmodified; g++ -O3; L1 restated)", what="%.0f s stereo 48 kHz 16-bit WAV -> WAV at %.2fx, presetDefault; "
+                "whole process incl. file I/O in /dev/shm" % (seconds, stretch), single_process_s=single, single_process_Msamples_s=samples/single/1e6,
+                processes=len(physical_cpus), all_processes_wall_s=wall, aggregate_Msamples_s=(samples*len(physical_cpus)/wall/1e6 if ok else None))
+
+
+def self_check(batch_first_output, x0, n_out0, C, sr_cfg, preset, setup, seconds=1.0):
+    """Stream 0 of the benched batch's FIRST call (from the reset state; taken outside the timed region) against oracle/_ref on the same
+    input: relative RMS over the first `seconds` of output (the free-running phase recurrence is chaotic, so only a short horizon says
+    anything sample by sample) and the level ratio over the whole call."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import numpy as np
+    import ref_oracle
+    if not ref_oracle.available():
+        return dict(checked=False, reason="oracle/_ref not built on this box")
+    r = ref_oracle.RefStretch(seed=0)
+    (r.presetCheaper if preset == "cheaper" else r.presetDefault)(C, sr_cfg)
+    if setup:
+        setup(r)
+    ref = r.process(x0, n_out0)
+    got = batch_first_output[:, :n_out0]
+    k = min(n_out0, int(seconds*sr_cfg))
+    err = float(np.sqrt(np.mean((got[:, :k] - ref[:, :k])**2)/max(np.mean(ref[:, :k]**2), 1e-30)))
+    level = float(np.sqrt(np.mean(got**2)/max(np.mean(ref**2), 1e-30)))
+    return dict(checked=True, stream=0, call="first call of the benched batch (reset state), outside the timed region", rel_rms_first_second=err,
+                level_ratio_whole_call=level, ok=bool(err < 2e-2 and abs(level - 1) < 2e-2),
+                bound="rel-RMS < 2e-2 over the first second (formant configs move at 1e-2: chaotic recurrence, tests/parity_cases.py has the measured bounds), level within 2 %")
+
+
 def pin_rank_to_numa_node(local_rank, world):
     """Multi-GPU runs: keep each rank's host scheduler (the block scheduler of process() is single-threaded host code) on
     the CPUs of the NUMA node its GPU hangs off; ranks that share a node split its CPUs.  Best effort, silent when sysfs
@@ -169,6 +239,21 @@ def measured_traffic(sha16):
     return t, "profiles/traffic_latest.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `%s` on library %s)" % (t.get("command", "bench.py"), sha16)
 
 
+def self_launch_command(gpus, oversubscribe, visible_devices, argv, environ):
+    """`python bench.py --gpus N` started plainly (no WORLD_SIZE): the command that starts the N ranks exactly as the driver does (one
+    process per GPU under torch.distributed.run, rendezvous on 127.0.0.1) -- or a loud refusal when the box has fewer devices than
+    asked for, instead of a line that says n_gpus: 1."""
+    if not oversubscribe and visible_devices < gpus:
+        raise SystemExit("bench: --gpus %d asked for, but only %d GPU(s) are visible on this box -- refusing to print a line for fewer "
+                         "devices than requested (use --oversubscribe --dist-backend gloo to exercise the N-rank launch path on one device)" % (gpus, visible_devices))
+    port = environ.get("MASTER_PORT", str(29500 + (os.getpid() % 400)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus), "--master-addr", "127.0.0.1",
+           "--master-port", port, os.path.abspath(__file__)] + list(argv)
+    env = dict(environ, MASTER_ADDR="127.0.0.1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return cmd, env
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -178,6 +263,7 @@ def main():
     ap.add_argument("--seconds", type=float, default=10.0, help="seconds of input per stream per step")
     ap.add_argument("--stretch", type=float, default=1.5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-self-check", action="store_true", help="skip the comparison of stream 0's first call with oracle/_ref")
     ap.add_argument("--no-serial-pass", action="store_true", help="skip the extra, serialised per-kernel-class profiling call (used under rocprofv3, so that every launch it sees is an in-place one)")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed even with one rank: exercises the barrier / max-over-ranks path of the N>1 runs on a 1-GPU box")
     ap.add_argument("--oversubscribe", action="store_true", help="N ranks on ONE GPU (every LOCAL_RANK maps to device 0): exercises the N>1 launch path -- rendezvous, barrier, "
@@ -209,12 +295,19 @@ def main():
 
     import torch
     import torch.distributed as dist
+    if args.gpus < 1:
+        raise SystemExit("bench: --gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        cmd, env = self_launch_command(args.gpus, args.oversubscribe, torch.cuda.device_count(), sys.argv[1:], os.environ)
+        raise SystemExit(subprocess.call(cmd, env=env))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     stream_rank = args.as_rank if (args.as_rank is not None and world == 1) else rank
-    if world != args.gpus and world > 1:
-        raise SystemExit("WORLD_SIZE (%d) != --gpus (%d)" % (world, args.gpus))
+    if world != args.gpus:
+        raise SystemExit("bench: WORLD_SIZE (%d) != --gpus (%d): launch with --nproc-per-node equal to --gpus" % (world, args.gpus))
+    if not args.oversubscribe and torch.cuda.device_count() <= local_rank:
+        raise SystemExit("bench: rank %d has no GPU of its own (LOCAL_RANK %d, %d visible)" % (rank, local_rank, torch.cuda.device_count()))
     dev_index = 0 if args.oversubscribe else local_rank
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
@@ -227,6 +320,9 @@ def main():
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
     red_device = device if args.dist_backend == "nccl" else torch.device("cpu")
+    dist_world = dist.get_world_size() if use_dist else None
+    if use_dist and dist_world != args.gpus:
+        raise SystemExit("bench: the process group has %d ranks, --gpus says %d" % (dist_world, args.gpus))
 
     affinity = pin_rank_to_numa_node(dev_index if args.oversubscribe else local_rank, world) if world > 1 else None
     if args.oversubscribe and affinity and world > 1:  # ranks share the device's NUMA node: split its CPUs by RANK, not by device index
@@ -261,8 +357,12 @@ def main():
         if use_dist:
             dist.barrier()
 
-    for _ in range(args.warmup):
+    first_call = None
+    for w in range(args.warmup):
         batch.process(x, n_out, out=y, ordered=False)
+        if w == 0 and rank == 0 and not args.no_self_check:  # stream 0 of the batch's first call, for the self-check below (untimed)
+            batch.synchronize()
+            first_call = (y[0].cpu().numpy().copy(), x[0].cpu().numpy().copy(), (n_out[0] if per_stream else n_out))
     batch.synchronize()
     barrier()
     torch.cuda.synchronize()
@@ -383,15 +483,34 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
             cpu = cpu_baseline()
+            if cpu is not None:
+                cpu["cmd_binary"] = cmd_binary_baseline(host_topology()[1])
         except Exception as e:  # the baseline is reported, never required
             cpu = dict(error=str(e))
+    check = None
+    if rank == 0:
+        if first_call is None:
+            check = dict(checked=False, reason="--no-self-check" if args.no_self_check else "no warm-up call to take the first output from")
+        else:
+            try:
+                ref_setup = None
+                if setup or per_stream:
+                    def ref_setup(r):
+                        if setup:
+                            setup(r)
+                        if per_stream:
+                            r.setTransposeSemitones(float(semis[0]), 0.0)
+                check = self_check(first_call[0], first_call[1], first_call[2], C, sr_cfg, preset, ref_setup)
+            except Exception as e:
+                check = dict(checked=False, reason="self-check failed to run: %s" % e)
     if rank == 0:
         sharding = "streams/%d, no collective" % world
         if args.oversubscribe:
             sharding = "OVERSUBSCRIBED: %d ranks on ONE device (cuda:0), %d streams each, no collective on the data path; %s for barrier + all_reduce" % (world, S, args.dist_backend)
         line = {
             "metric": "Msamples/sec (in+out) at 48kHz stereo presetDefault",
-            "value": value, "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": value, "unit": "Msamples/s", "n_gpus": world, "dist_world_size": dist_world, "dist_backend": (args.dist_backend if use_dist else None),
+            "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed/args.steps*1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic", "state_storage": "f16" if args.half_state else "f32",
             "config": {"workload": ("BASELINE configs[1]: %d stereo streams per GPU, 48 kHz, presetDefault, %.2fx stretch, fp32, "
@@ -403,7 +522,7 @@ def main():
                        "rank0_cpu_affinity": ("%d CPUs from %d" % (len(affinity), affinity[0])) if affinity else None},
             "realtime_x": world*S*args.seconds*args.steps/elapsed,
             "channels": C,
-            "output_finite_nonzero": ok,
+            "output_finite_nonzero": ok, "self_check": check,
             "roofline": roofline, "cpu_baseline": cpu,
         }
         print(json.dumps(line))
@@ -411,6 +530,8 @@ def main():
         dist.destroy_process_group()
     if rank == 0 and not ok:
         raise SystemExit("bench: output not finite / silent -- the line above is not a valid measurement")
+    if rank == 0 and check and check.get("checked") and not check.get("ok"):
+        raise SystemExit("bench: stream 0 of the first call disagrees with the checker (%s) -- the line above is not a valid measurement" % check)
 
 
 if __name__ == "__main__":

@@ -201,6 +201,11 @@ int smst_batch_debug_get_map(smst_batch *b, int stream, float *dst);
 /* the kernels' packed complex helpers (csrc/smst_complex.h, gfx950 inline assembly) evaluated on the device: in = n x
  * (a.re, a.im, b.re, b.im, c.re, c.im, fraction), out = n x (a*b, a*conj(b), a*b + c, a + (b - a)*fraction) as 8 floats. */
 int smst_debug_complex_selftest(int device, const float *in, float *out, int n);
+/* launches, since the library was loaded, of one kernel variant: "vocoder_aligned", "vocoder_staged", "vocoder_gather",
+ * "vocoder_n", "vocoder_one", "vocoder_across", "chain_unfused", "analyse_teams", "analyse_fast", "analyse_generic",
+ * "synth_teams", "synth_fast", "synth_generic" (-1: unknown name).  The "this form is bit-identical to that form" tests
+ * assert through it that both forms really ran. */
+long long smst_debug_launch_count(const char *name);
 
 #ifdef __cplusplus
 }

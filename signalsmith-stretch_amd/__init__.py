@@ -101,6 +101,7 @@ _SIGNATURES = {
     "smst_batch_wait_for_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "smst_batch_signal_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "smst_debug_complex_selftest": (C.c_int, [C.c_int, _fp, _fp, C.c_int]),
+    "smst_debug_launch_count": (_ll, [C.c_char_p]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 
@@ -177,6 +178,12 @@ def complex_selftest(values, device=0, lib=None):
     out = np.zeros((v.shape[0], 8), np.float32)
     _check(lib, lib.smst_debug_complex_selftest(device, v.ctypes.data_as(_fp), out.ctypes.data_as(_fp), v.shape[0]))
     return out
+
+
+def launch_count(name, lib=None):
+    """Launches of one kernel variant since the library was loaded (test hook, smst_debug_launch_count)."""
+    lib = lib if lib is not None else load_library()
+    return int(lib.smst_debug_launch_count(name.encode()))
 
 
 class StretchBatch:

@@ -162,6 +162,7 @@ int smst_debug_complex_selftest(int device, const float *in, float *out, int n) 
 	return 0;
 	SMST_CATCH
 }
+long long smst_debug_launch_count(const char *name) { return smst::launchCount(name); }
 int smst_batch_debug_get_map(smst_batch *b, int stream, float *dst) {
 	if (!b || !b->engine) return fail("null batch");
 	SMST_TRY

@@ -22,9 +22,10 @@ struct DevBatch {
 	int halfState;                // carried Band.output / Prediction.energy / overlap-add sums stored in fp16 (BASELINE config 5 "fp16 internal")
 	int fftLean;                  // SMST_FFT_TABLES=lean: register-blocked FFT kernels with the smaller tables (opt-in experiment, see smst_engine.cpp)
 	int noFastFft;                // SMST_NO_FAST_FFT: the generic radix-4/2/3/5 ladder even where a register-blocked FFT exists (cross-check)
-	int fftTeams;                 // analysis / synthesis by persistent workgroups of three free-running teams, tables in LDS (default; SMST_FFT_TEAMS=0: one frame per workgroup)
+	int fftTeams;                 // analysis / synthesis by persistent workgroups of three free-running teams, tables in LDS (default; SMST_FFT_TEAMS=0: one frame per workgroup; =2: teams even for tiles with few frames per team -- tests)
 	int teamsGrid;                // their grid: one workgroup per CU, a multiple of 8
 	int noStage;                  // SMST_NO_STAGE: producers of the fused kernel gather from HBM even where staging applies
+	int noAlign;                  // SMST_NO_ALIGN: staged producers with per-row windows and lag L+1 (round 3) instead of the line-aligned form
 	FftPlan plan;
 	// constant tables
 	const float2 *twH;     // e^{-2 pi i j / H}
@@ -75,6 +76,14 @@ struct IoArgs {
 	const int *inSamples;  // [S] device
 	const int *outSamples; // [S] device
 };
+
+// Which kernel variant a launcher chose, counted per process (test hook: smst_debug_launch_count).  "Bit-identical to the other
+// form" tests assert through these that BOTH forms really ran.
+enum LaunchKind {
+	LK_VOC_ALIGNED, LK_VOC_STAGED, LK_VOC_GATHER, LK_VOC_N, LK_VOC_ONE, LK_VOC_ACROSS, LK_CHAIN_UNFUSED,
+	LK_ANALYSE_TEAMS, LK_ANALYSE_FAST, LK_ANALYSE_GENERIC, LK_SYNTH_TEAMS, LK_SYNTH_FAST, LK_SYNTH_GENERIC, LK_COUNT
+};
+long long launchCount(const char *name); // -1: unknown name
 
 void launchEnergy(const DevBatch &d, const IoArgs &io, int sBase, int nStreams, float *energyOut, hipStream_t st);
 void launchAnalyse(const DevBatch &d, const IoArgs &io, int sBase, int nStreams, int hopBase, int tileHops, bool anyInCall, bool anyLate, hipStream_t st);

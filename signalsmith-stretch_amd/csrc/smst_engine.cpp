@@ -173,6 +173,7 @@ void Batch::construct(const FftPlan &plan, long seed) {
 	d.noFeedFusion = 0;
 	if (const char *env = std::getenv("SMST_NO_FEED_FUSION")) d.noFeedFusion = atoi(env);
 	d.noStage = std::getenv("SMST_NO_STAGE") != nullptr;
+	d.noAlign = std::getenv("SMST_NO_ALIGN") != nullptr;
 	d.noFastFft = std::getenv("SMST_NO_FAST_FFT") != nullptr;
 	// lean FFT tables (8-byte window entries + generated modulation, six stage twiddles instead of fifteen) are OPT-IN: they take 0.2 ms
 	// off a 16.3-ms step, and their one extra rounding per element (spectra 1.2e-7 away from the full tables') flipped a peak decision

@@ -11,6 +11,8 @@
 //   * synthesis FFTs and the overlap-add (a gather over the covering frames, no atomics) are again parallel
 //     over (stream, hop, channel).
 #include <hip/hip_runtime.h>
+#include <atomic>
+#include <cstring>
 #include "smst_device.h"
 #include <smst_complex.h> // angle brackets: tests/emu shadows this header for the CPU stand-in
 
@@ -2366,7 +2368,220 @@ __device__ __forceinline__ void vocoderProduceStaged(const DevBatch &d, int s, i
 	}
 }
 
+// Line-aligned staged producers (PLAIN tiles without random time factors, L <= 4, M a multiple of 16), wavefront lag 8.
+// What bounded the staged kernel above was the CU's L1-miss line rate: with lag = L+1 every row's
+// windows sit at their own odd alignment, a 160-byte IN window touches 2-3 lines of which it needs 64 new bytes, and each
+// line comes through L1 again in three or four consecutive blocks -- ~600 lines per 8-step block.  With a lag of EIGHT bins
+// row r covers bins 8(n-r) .. 8(n-r)+7 in block n: every row advances by exactly half a 128-byte line per block, in step.
+// So each (row, array) keeps a 32-bin ring in LDS -- bin x at position x & 31, i.e. the two lines around the row's current
+// bins -- and a line is fetched from memory exactly ONCE, whole and aligned, in the block before its first use:
+//   IN  needs bins b0-2L .. b0+7+L  (within [b0-8, b0+11]):  lines j-1, j at b0 = 16j; lines j, j+1 at b0 = 16j+8
+//   PV  needs bins b0+1  .. b0+7+L                         :  line  j      at b0 = 16j; lines j, j+1 at b0 = 16j+8
+// i.e. a row receives line (m+1)/2 of every array in the blocks with m = n - row odd (m = -1 brings line 0), into the half
+// of the ring whose line was last read the block before.  A producer wave owns 8 rows; per block 4 of them take a new line
+// of 2*CH arrays: 8*CH lines = CH 16-byte loads per lane, each instruction 8 whole lines (the lag-(L+1) form: 6 loads per
+// lane and block, ~75 lines per wave).  The rotation factors of a lane's two previous-hop bins travel in registers (the
+// table's active region is 4 KB and stays in L1); the row above a wave's first row (Prediction.energy of the previous hop,
+// owned by the neighbouring wave) is staged as the 16 bins its block needs.  The 8-bin lag costs 63*3 more steps per tile
+// (+5.6 %) and puts rows r and r+1 on complementary halves of the LDS banks with NO row padding (ring pitch 32 bins).
+// Same operands, same operations in the same order as vocoderProduceStaged / computeRecord: bit-identical records.
+template <int CH, int L>
+struct AlignGeom {
+	static constexpr int RING = 32;                   // bins per (row, array) ring
+	static constexpr int ROWLEN = 2*CH*RING;          // float2 per row: CH input rings, then CH previous-input rings
+	static constexpr int XLEN = CH*16;                // the row above the wave's first row: 16 bins per channel
+	static constexpr int PER_PRODUCER = 8*ROWLEN + XLEN;
+	static constexpr int LOADS = CH;                  // (4 rows x 2*CH arrays x 8 pieces) / 64 lanes
+};
+
+template <int CH, int L, int NB>
+__device__ __forceinline__ void vocoderProduceAligned(const DevBatch &d, int s, int sg, int nh, int it, int k, int totalBlocks,
+                                                      float4 *recs, volatile int *sync, const HopDesc *hopsLds, float2 *sbuf, const CarriedOutput &stOut) {
+	using G = AlignGeom<CH, L>;
+	constexpr int NF = 9 + 3*CH, NCH = (NF + 3)/4, BS = 8, LAG = 8;
+	static_assert(2*L <= 8 && 7 + L <= 11, "the windows must fit the two lines around the row's bins");
+	const int M = d.M, lines = M >> 4;
+	float2 *xbuf = sbuf + 8*G::ROWLEN;
+	for (int i = k; i < G::PER_PRODUCER/2; i += 64) reinterpret_cast<float4 *>(sbuf)[i] = make_float4(0.f, 0.f, 0.f, 0.f); // bins below 0 read as zero
+	__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+	__builtin_amdgcn_wave_barrier();
+	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+	// ---- block-invariant description of this lane's line pieces: [parity of the block][load]
+	const float2 *lsrc[2][G::LOADS];
+	int llds[2][G::LOADS], lrow[2][G::LOADS];
+#pragma unroll
+	for (int par = 0; par < 2; ++par) {
+#pragma unroll
+		for (int i = 0; i < G::LOADS; ++i) {
+			const int q = k + 64*i, li = q >> 3, piece = q & 7;
+			const int rr = li/(2*CH), a = li%(2*CH);
+			const int r = 2*rr + par, row = 8*it + r;
+			const bool ok = row < nh;
+			const HopDesc hd = hopsLds[ok ? row : 0];
+			const float2 *src = (a < CH) ? inputRow(d, hd, s, sg, a) : prevRow(d, hd, s, row, sg, a - CH);
+			lsrc[par][i] = (ok ? src : d.rot) + 2*piece;
+			llds[par][i] = r*G::ROWLEN + a*G::RING + 2*piece;
+			lrow[par][i] = ok ? r : (1 << 20); // a row beyond the tile's hops never reaches m >= -1
+		}
+	}
+	// the row above this wave's first row: hop 8*it - 1 of the tile, or (it == 0) the carried Prediction.energy
+	const int xc = (k >> 3) < CH ? (k >> 3) : 0, xpiece = k & 7;
+	const bool xlane = k < 8*CH;
+	const float2 *xsrc = d.rot;
+	if (it > 0) xsrc = inputRow(d, hopsLds[8*it - 1], s, sg, xc);
+	const size_t xenergy = stateRow(d, sg, xc);
+	float4 v[G::LOADS];
+	float4 xv = make_float4(0.f, 0.f, 0.f, 0.f);
+	const int st = k & 7, r = k >> 3, row = 8*it + r;
+	float2 rot1 = make_float2(1.f, 0.f), rotL = rot1, rotNext1 = rot1, rotNextL = rot1;
+	auto lineOf = [&](int n, int i) { const int m = n - 8*it - lrow[(n + 1) & 1][i]; return m >= -1 ? (m + 1) >> 1 : -1; }; // m is odd
+	auto issue = [&](int n) {
+		const int par = (n + 1) & 1;
+#pragma unroll
+		for (int i = 0; i < G::LOADS; ++i) {
+			const int j = lineOf(n, i);
+			const int jc = min(max(j, 0), lines - 1);
+			v[i] = *reinterpret_cast<const float4 *>(lsrc[par][i] + 16*jc);
+		}
+		const int x0 = BS*(n - 8*it) + 2*xpiece, xcl = min(max(x0, 0), M - 2);
+		if (it > 0) xv = *reinterpret_cast<const float4 *>(xsrc + xcl);
+		else { const float2 e = loadEnergyPair(d, xenergy + xcl); xv = make_float4(e.x, 0.f, e.y, 0.f); }
+		const int b = BS*(n - row) + st;
+		rotNext1 = d.rot[min(max(b + 1, 0), M - 1)];
+		rotNextL = d.rot[min(max(b + L, 0), M - 1)];
+	};
+	auto park = [&](int n) {
+		const int par = (n + 1) & 1;
+#pragma unroll
+		for (int i = 0; i < G::LOADS; ++i) {
+			const int j = lineOf(n, i);
+			if (j >= 0) *reinterpret_cast<float4 *>(sbuf + llds[par][i] + 16*(j & 1)) = (j < lines) ? v[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+		}
+		const int x0 = BS*(n - 8*it) + 2*xpiece;
+		if (xlane) *reinterpret_cast<float4 *>(xbuf + xc*16 + (x0 & 15)) = (x0 >= 0 && x0 + 1 < M) ? xv : make_float4(0.f, 0.f, 0.f, 0.f);
+		rot1 = rotNext1;
+		rotL = rotNextL;
+	};
+	const HopDesc hd = hopsLds[row < nh ? row : 0];
+	const bool rotate = hd.flags & HOP_NEW_SPECTRUM;
+	const float tf = hd.timeFactor;
+	const float2 *mine = sbuf + r*G::ROWLEN, *above = sbuf + (r > 0 ? r - 1 : 0)*G::ROWLEN;
+	// Hop 0's previous-hop taps are the carried Band.output (FOLD0, see computeRecord): the wave that owns row 0 fetches them with
+	// its lines, one block ahead (lanes 0..7 = row 0, steps 0..7; the other lanes load in-range values they never use)
+	float2 car1[CH], carL[CH], carNext1[CH], carNextL[CH];
+#pragma unroll
+	for (int c = 0; c < CH; ++c) car1[c] = carL[c] = carNext1[c] = carNextL[c] = make_float2(0.f, 0.f);
+	auto issueCarried = [&](int nn) {
+		const int b = BS*nn + st; // row 0: no skew
+#pragma unroll
+		for (int c = 0; c < CH; ++c) {
+			carNext1[c] = stOut[(size_t)c*M + min(b + 1, M - 1)];
+			carNextL[c] = stOut[(size_t)c*M + min(b + L, M - 1)];
+		}
+	};
+	// The wave's first lines are due in block n0 = 8*it - 1 (m = -1 of its first row: line 0); for it == 0 that is a block BEFORE the
+	// tile's first one, which only parks.  Blocks before n0 (the wavefront has not reached this wave's rows): all-zero records.
+	const int n0 = 8*it - 1;
+	for (int skip = 0; skip < min(n0, totalBlocks); ++skip) {
+		const int slot = skip%NB;
+		while (skip - ldsPeek(&sync[NB]) >= NB) __builtin_amdgcn_s_sleep(2);
+		asm volatile("" ::: "memory");
+#pragma unroll
+		for (int j = 0; j < NCH; ++j) recs[((slot*BS + st)*NCH + j)*64 + ((row + st) & 63)] = make_float4(0.f, 0.f, 0.f, 0.f);
+		asm volatile("" ::: "memory");
+		if (k == 0) ldsCount(&sync[slot]);
+	}
+	int n = n0;
+	if (n < totalBlocks) issue(n);
+	for (; n < totalBlocks; ++n) {
+		park(n);
+		if (it == 0) {
+#pragma unroll
+			for (int c = 0; c < CH; ++c) { car1[c] = carNext1[c]; carL[c] = carNextL[c]; }
+		}
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+		if (n + 1 < totalBlocks) { issue(n + 1); if (it == 0) issueCarried(n + 1); }
+		if (n < 0) { // the parking-only block of the wave that owns row 0
+			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+			__builtin_amdgcn_wave_barrier();
+			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+			continue;
+		}
+		const int slot = n%NB;
+		while (n - ldsPeek(&sync[NB]) >= NB) __builtin_amdgcn_s_sleep(2); // slot still being read
+		asm volatile("" ::: "memory");
+		const int b0 = BS*(n - row), b = b0 + st;
+		float f[NCH*4];
+#pragma unroll
+		for (int j = 0; j < NCH*4; ++j) f[j] = 0.0f;
+		if (row < nh && b >= 0 && b < M) {
+			// same arithmetic as computeRecord<CH, true, false, false>, operands from the rings
+			auto IN = [&](int c, int x) { return mine[c*G::RING + (x & 31)]; };
+			auto lerpIN = [&](int c, LerpIndex li) {
+				const float2 low = IN(c, li.lo), high = IN(c, li.lo + 1);
+				return clerp(low, high, li.fr);
+			};
+			float2 p[CH];
+			float e[CH];
+#pragma unroll
+			for (int c = 0; c < CH; ++c) { p[c] = IN(c, b); e[c] = cnorm(p[c]); }
+			int mc = 0;
+			float eMax = e[0];
+#pragma unroll
+			for (int c = 1; c < CH; ++c) if (e[c] > eMax) { mc = c; eMax = e[c]; }
+			float2 Pm = p[0];
+#pragma unroll
+			for (int c = 1; c < CH; ++c) if (c == mc) Pm = p[c];
+			const float fb = float(b);
+			float2 A = cmulc(Pm, lerpIN(mc, lerpIndex(fb - tf)));
+			float2 B = cmulc(Pm, lerpIN(mc, lerpIndex(fb - L*tf)));
+			auto twist = [&](int bx, float2 rotV, float stepMul) {
+				const int bc = min(bx, M - 1);
+				const float2 rotB = rotate ? rotV : make_float2(1.f, 0.f);
+				const float2 Q = cmul(mine[(CH + mc)*G::RING + (bx & 31)], rotB);
+				const float2 Px = IN(mc, bx);
+				const float2 TW = cmul(rotB, cmulc(Px, Q));
+				const float eNow = cnorm(Px);
+				// Prediction.energy of the previous hop: hop row-1's input (its ring runs 8 bins ahead of this row's), or the carried state
+				const float2 up = (r > 0) ? above[mc*G::RING + (bx & 31)] : xbuf[mc*16 + (bx & 15)];
+				const float ePrev = (row > 0) ? cnorm(up) : up.x;
+				const float den = fmaxf(ePrev, eNow) + 1e-15f;
+				const float2 down = cmulc(Px, lerpIN(mc, lerpIndex(float(bc) - stepMul*tf)));
+				const float2 rr = cmulc(TW, down);
+				const float inv = __builtin_amdgcn_rcpf(den); // 1-ulp hardware reciprocal (an IEEE division costs ten instructions per record)
+				return make_float2(rr.x*inv, rr.y*inv);
+			};
+			float2 Cc = twist(b + 1, rot1, 1.0f), Dc = twist(b + L, rotL, float(L));
+			const float2 zero = make_float2(0.f, 0.f);
+			if (!(b > 0)) A = zero;
+			if (!(b >= L)) B = zero;
+			if (!(b < M - 1)) Cc = zero;
+			if (!(b < M - L)) Dc = zero;
+			if (it == 0) { // FOLD0: row 0's record carries the previous-hop part ready-made (wave-uniform branch, lane select inside)
+				float2 c1 = car1[0], cL = carL[0];
+#pragma unroll
+				for (int c = 1; c < CH; ++c) if (c == mc) { c1 = car1[c]; cL = carL[c]; }
+				const float2 K = prevHopTerms(c1, Cc, cL, Dc);
+				if (r == 0) { Cc = K; Dc = zero; }
+			}
+			f[0] = A.x; f[1] = A.y; f[2] = B.x; f[3] = B.y; f[4] = Cc.x; f[5] = Cc.y; f[6] = Dc.x; f[7] = Dc.y;
+			f[8] = __int_as_float(mc);
+			recordChannelFields<CH>(f, p, e, mc);
+		}
+#pragma unroll
+		for (int j = 0; j < NCH; ++j) recs[((slot*BS + st)*NCH + j)*64 + ((row + st) & 63)] = make_float4(f[4*j], f[4*j + 1], f[4*j + 2], f[4*j + 3]);
+		asm volatile("" ::: "memory");
+		if (k == 0) ldsCount(&sync[slot]);
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier(); // every lane has read its operands before the next block's lines are parked
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+	}
+}
+
 constexpr int kVocBlockSteps = 8, kVocBlocks = 3, kVocBlocksStaged = 2, kVocWaves = 16, kVocStagedProducers = 8, kVocOutBlocks = 4;
+constexpr int kVocOutBlocksAligned = 3; // lag 8: a row's 16-bin line lies in exactly two result blocks
 // results ring: [block][step][channel][kVocOutPitch] -- 66, not 64: the writer reads a row's values of steps 2 apart in adjacent
 // lane groups, and 2*CH*64 float2 is a multiple of the 32 banks (an 8-way conflict on every writer read with the first layout)
 constexpr int kVocOutPitch = 66;
@@ -2384,21 +2599,24 @@ __device__ __forceinline__ float2 fromLaneBelow(float2 v, float2 lane0) { // lan
 // output: no skew (lag 0), no DPP, M steps per launch.  kVocoderOne runs one chain per WAVE (64 lanes computing the same
 // values); at 4096 streams that is four chain waves per SIMD and 1.57 ms per hop quantum.  Same records, same arithmetic:
 // bit-identical to the other recurrence kernels.
-template <int CH, bool PLAIN, int L, bool STAGED, bool ROTL = false, bool ACROSS = false>
+// ALIGNED (with STAGED): the line-aligned producers and a wavefront lag of 8 bins (vocoderProduceAligned).
+template <int CH, bool PLAIN, int L, bool STAGED, bool ROTL = false, bool ACROSS = false, bool ALIGNED = false>
 __global__ __launch_bounds__(64*kVocWaves) __attribute__((amdgpu_waves_per_eu(4, 4))) void kVocoder(DevBatch d, int sBase, int hopBase, int acrossRows, int acrossStreams) {
 	static_assert(!STAGED || (PLAIN && L <= 5), "staged producers: identity map, bounded windows");
+	static_assert(!ALIGNED || (STAGED && L <= 4), "line-aligned producers: windows within the two lines around a row's bins");
 	static_assert(!ACROSS || !STAGED, "rows that are streams gather their operands");
 	static_assert(!ROTL || (!PLAIN && !STAGED), "the LDS copy of the rotation table serves the gathering producers of mapped tiles");
 	constexpr int NF = 9 + 3*CH, NCH = (NF + 3)/4, BS = kVocBlockSteps, NB = STAGED ? kVocBlocksStaged : kVocBlocks;
 	constexpr int NP = STAGED ? kVocStagedProducers : kVocWaves - 2;
-	constexpr int lag = ACROSS ? 0 : L + 1;
-	static_assert(BS == 8 && L >= 1 && L <= 7, "history registers are indexed by step & 7");
+	constexpr int lag = ACROSS ? 0 : (ALIGNED ? 8 : L + 1);
+	constexpr int OB = ALIGNED ? kVocOutBlocksAligned : kVocOutBlocks; // result ring blocks
+	static_assert(BS == 8 && L >= 1 && L <= 7 && lag <= 8, "history registers are indexed by step & 7");
 	extern __shared__ __attribute__((aligned(16))) unsigned char smemRaw[];
 	float4 *recs = reinterpret_cast<float4 *>(smemRaw);                 // [(slot*BS + st)*NCH + j][64 lanes]
 	volatile int *sync = reinterpret_cast<volatile int *>(recs + NB*BS*NCH*64); // [0..NB) units produced, [NB] blocks consumed
 	int *rowClass = const_cast<int *>(sync) + 16;                                  // [2][64]: the writer's two classes of rows
 	HopDesc *hopsLds = reinterpret_cast<HopDesc *>(rowClass + 128);                // the tile's 64 hop descriptors
-	float2 *outRing = reinterpret_cast<float2 *>(hopsLds + 64);                    // [kVocOutBlocks][BS][CH][64]: results on their way to HBM
+	float2 *outRing = reinterpret_cast<float2 *>(hopsLds + 64);                    // [OB][BS][CH][kVocOutPitch]: results on their way to HBM
 	// sync words: [0..NB) units produced per slot, [NB] blocks consumed, [NB+1] result blocks ready, [NB+2] result blocks written
 
 	// rows of the workgroup: hops 0 .. nh-1 of stream s, or (ACROSS) hop 0 of streams s .. s+nh-1
@@ -2426,7 +2644,7 @@ __global__ __launch_bounds__(64*kVocWaves) __attribute__((amdgpu_waves_per_eu(4,
 			hopsLds[threadIdx.x] = d.hops[(size_t)sg*d.hopStride + hopBase + threadIdx.x];
 		}
 	}
-	float2 *rotLds = outRing + (size_t)kVocOutBlocks*BS*CH*kVocOutPitch; // [M] hop rotation table (ROTL; the staged kernel keeps its windows here)
+	float2 *rotLds = outRing + (size_t)OB*BS*CH*kVocOutPitch; // [M] hop rotation table (ROTL; the staged kernels keep their windows here)
 	if constexpr (ROTL) {
 		for (int i = threadIdx.x; i < M; i += blockDim.x) rotLds[i] = d.rot[i];
 	}
@@ -2468,7 +2686,7 @@ __global__ __launch_bounds__(64*kVocWaves) __attribute__((amdgpu_waves_per_eu(4,
 					const int b = 16*G + 2*part;
 					const bool ok = idx < count[q] && row < nh && G >= 0 && 16*G < M && (!ACROSS || (hopsLds[row].flags & HOP_ACTIVE));
 					const int t0 = b + lag*row, t1 = t0 + 1; // the steps at which the two bins were produced
-					const int r0 = t0 >= 0 ? (t0 >> 3)%kVocOutBlocks : 0, r1 = t1 >= 0 ? (t1 >> 3)%kVocOutBlocks : 0;
+					const int r0 = t0 >= 0 ? (t0 >> 3)%OB : 0, r1 = t1 >= 0 ? (t1 >> 3)%OB : 0;
 #pragma unroll
 					for (int c = 0; c < CH; ++c) {
 						float2 v0 = outRing[((r0*BS + (t0 & 7))*CH + c)*kVocOutPitch + row], v1 = outRing[((r1*BS + (t1 & 7))*CH + c)*kVocOutPitch + row];
@@ -2494,9 +2712,14 @@ __global__ __launch_bounds__(64*kVocWaves) __attribute__((amdgpu_waves_per_eu(4,
 		int pIndex = wave - 1 - (wave > 4);
 		if (STAGED) pIndex = (wave & 3) ? ((wave < 8) ? pIndex : ((wave == 9) ? 6 : ((wave == 10) ? 7 : NP))) : NP;
 		if (pIndex >= NP) return;
-		if constexpr (STAGED) {
+		if constexpr (ALIGNED) {
+			using G = AlignGeom<CH, L>;
+			float2 *sbuf = outRing + (size_t)OB*BS*CH*kVocOutPitch + (size_t)pIndex*G::PER_PRODUCER;
+			vocoderProduceAligned<CH, L, NB>(d, s, sg, nh, pIndex, k, totalBlocks, recs, sync, hopsLds, sbuf, stOut);
+			return;
+		} else if constexpr (STAGED) {
 			using G = StageGeom<CH, L>;
-			float2 *sbuf = outRing + (size_t)kVocOutBlocks*BS*CH*kVocOutPitch + (size_t)pIndex*G::ROWS*G::ROWLEN;
+			float2 *sbuf = outRing + (size_t)OB*BS*CH*kVocOutPitch + (size_t)pIndex*G::ROWS*G::ROWLEN;
 			vocoderProduceStaged<CH, L, NB, NP>(d, s, sg, nh, pIndex, k, totalBlocks, recs, sync, hopsLds, sbuf, stOut);
 			return;
 		}
@@ -2555,7 +2778,7 @@ __global__ __launch_bounds__(64*kVocWaves) __attribute__((amdgpu_waves_per_eu(4,
 		const float4 *blockRecs = recs + (size_t)slot*BS*NCH*64;
 		while (n - seenWritten >= 2) { __builtin_amdgcn_s_sleep(1); seenWritten = ldsPeek(&sync[NB + 2]); } // the writer still owns this result slot
 		asm volatile("" ::: "memory");
-		float2 *blockOut = outRing + (size_t)(n%kVocOutBlocks)*BS*CH*kVocOutPitch + k;
+		float2 *blockOut = outRing + (size_t)(n%OB)*BS*CH*kVocOutPitch + k;
 		float4 q[2][NCH]; // two register sets alternate, so the next step's record loads never overwrite live values
 #pragma unroll
 		for (int j = 0; j < NCH; ++j) q[0][j] = blockRecs[j*64 + k];
@@ -2578,8 +2801,9 @@ __global__ __launch_bounds__(64*kVocWaves) __attribute__((amdgpu_waves_per_eu(4,
 #pragma unroll
 			for (int c = 0; c < CH; ++c) {
 				if constexpr (!ACROSS) {
-					tap1[c] = fromLaneBelow(h[(i + 8 - L) & 7][c], tap1[c]);
-					tapL[c] = fromLaneBelow(h[(i + 7) & 7][c], tapL[c]);
+					// lane k-1 finished its bin b+x (x = 1, L) lag - x steps ago
+					tap1[c] = fromLaneBelow(h[(i + 17 - lag) & 7][c], tap1[c]);
+					tapL[c] = fromLaneBelow(h[(i + 16 + L - lag) & 7][c], tapL[c]);
 				}
 			}
 			// the maximum channel's taps: explicit per-component selects (v_cndmask) -- written as an `if` the compiler makes a branch of
@@ -3279,6 +3503,16 @@ void launchComplexSelfTest(const float *in, float *out, int n, hipStream_t st) {
 // ------------------------------------------------------------------------------------------------------
 static inline int divUp(int a, int b) { return (a + b - 1)/b; }
 
+static std::atomic<long long> gLaunchCounts[LK_COUNT];
+static const char *const kLaunchNames[LK_COUNT] = {
+	"vocoder_aligned", "vocoder_staged", "vocoder_gather", "vocoder_n", "vocoder_one", "vocoder_across", "chain_unfused",
+	"analyse_teams", "analyse_fast", "analyse_generic", "synth_teams", "synth_fast", "synth_generic"};
+static inline void countLaunch(LaunchKind k) { gLaunchCounts[k].fetch_add(1, std::memory_order_relaxed); }
+long long launchCount(const char *name) {
+	for (int i = 0; i < LK_COUNT; ++i) if (name && std::strcmp(name, kLaunchNames[i]) == 0) return gLaunchCounts[i].load(std::memory_order_relaxed);
+	return -1;
+}
+
 void launchEnergy(const DevBatch &d, const IoArgs &io, int sBase, int nStreams, float *energyOut, hipStream_t st) {
 	hipLaunchKernelGGL(kEnergy, dim3(nStreams, kEnergyParts), dim3(256), 256*sizeof(float), st, d, io, sBase, energyOut);
 }
@@ -3286,16 +3520,18 @@ void launchAnalyse(const DevBatch &d, const IoArgs &io, int sBase, int nStreams,
 	const dim3 grid(tileHops, d.C*2, nStreams);
 	const size_t fastLds = ((size_t)d.M + d.M/16)*sizeof(float2);
 	// persistent teams pay a 76-KB table copy per workgroup: only where every team gets a few frames
-	const bool teams = !d.noFastFft && d.fftTeams && !d.fftLean && anyInCall && (d.M == 256*10 || d.M == 256*12) && tileHops*d.C*2*nStreams >= 6*d.teamsGrid;
+	const bool teams = !d.noFastFft && d.fftTeams && !d.fftLean && anyInCall && (d.M == 256*10 || d.M == 256*12) && (d.fftTeams == 2 || tileHops*d.C*2*nStreams >= 6*d.teamsGrid);
 	if (teams) {
 		const int jobs = tileHops*d.C*2*nStreams;
 		const int wgs = std::max(8, std::min((jobs + 2)/3/8*8, d.teamsGrid)); // one workgroup per CU, a multiple of 8 (one residue class of the job order per XCD)
 		const size_t lds = ((size_t)d.M + d.M/2 + d.M/32)*sizeof(float4) + 3*fastLds + 64; // window, first- and second-stage twiddles, a buffer per team, barrier words
 		if (d.M == 256*10) hipLaunchKernelGGL((kAnalyseTeams<10, 3>), dim3(wgs), dim3(768), lds, st, d, io, d.hops, sBase, hopBase, tileHops, nStreams);
 		else hipLaunchKernelGGL((kAnalyseTeams<12, 3>), dim3(wgs), dim3(768), lds, st, d, io, d.hops, sBase, hopBase, tileHops, nStreams);
+		countLaunch(LK_ANALYSE_TEAMS);
 		if (!anyLate) return;
 	}
 	const int lateOnly = teams ? 1 : 0; // the frames whose windows reach into the carried history
+	if (!d.noFastFft && d.M%256 == 0 && (d.M/256 == 10 || d.M/256 == 12 || d.M/256 == 20 || d.M/256 == 24)) countLaunch(LK_ANALYSE_FAST); else countLaunch(LK_ANALYSE_GENERIC);
 	if (!d.noFastFft) { // every preset: presetCheaper at 44.1 / 48 kHz, presetDefault at 44.1 / 48 kHz, presetCheaper at 88.2 / 96 kHz, presetDefault at 88.2 / 96 kHz
 		if (d.M == 256*10) { if (d.fftLean) hipLaunchKernelGGL((kAnalyseFast<10, true>), grid, dim3(256), fastLds, st, d, io, sBase, hopBase, lateOnly); else hipLaunchKernelGGL((kAnalyseFast<10, false>), grid, dim3(256), fastLds, st, d, io, sBase, hopBase, lateOnly); return; }
 		if (d.M == 256*12) { if (d.fftLean) hipLaunchKernelGGL((kAnalyseFast<12, true>), grid, dim3(256), fastLds, st, d, io, sBase, hopBase, lateOnly); else hipLaunchKernelGGL((kAnalyseFast<12, false>), grid, dim3(256), fastLds, st, d, io, sBase, hopBase, lateOnly); return; }
@@ -3359,14 +3595,26 @@ static void launchVocoderTL(const DevBatch &d, int sBase, int nStreams, int hopB
 	constexpr int NCH = (9 + 3*CH + 3)/4;
 	const size_t fixed = 64 + 128*sizeof(int) + 64*sizeof(HopDesc) + (size_t)kVocOutBlocks*kVocBlockSteps*CH*kVocOutPitch*sizeof(float2);
 	const size_t lds = (size_t)kVocBlocks*kVocBlockSteps*NCH*64*sizeof(float4) + fixed;
+	if constexpr (L <= 4) {
+		if (plain && bounded && !d.noStage && !d.noAlign && d.M%16 == 0) {
+			using G = AlignGeom<CH, L>;
+			const size_t fixedA = 64 + 128*sizeof(int) + 64*sizeof(HopDesc) + (size_t)kVocOutBlocksAligned*kVocBlockSteps*CH*kVocOutPitch*sizeof(float2);
+			const size_t ldsAligned = (size_t)kVocBlocksStaged*kVocBlockSteps*NCH*64*sizeof(float4) + fixedA + (size_t)kVocStagedProducers*G::PER_PRODUCER*sizeof(float2);
+			hipLaunchKernelGGL((kVocoder<CH, true, L, true, false, false, true>), dim3(nStreams), dim3(64*kVocWaves), ldsAligned, st, d, sBase, hopBase, 0, 0);
+			countLaunch(LK_VOC_ALIGNED);
+			return;
+		}
+	}
 	if constexpr (L <= 5) {
 		if (plain && bounded && !d.noStage) {
 			using G = StageGeom<CH, L>;
 			const size_t ldsStaged = (size_t)kVocBlocksStaged*kVocBlockSteps*NCH*64*sizeof(float4) + fixed + (size_t)kVocStagedProducers*G::ROWS*G::ROWLEN*sizeof(float2);
 			hipLaunchKernelGGL((kVocoder<CH, true, L, true>), dim3(nStreams), dim3(64*kVocWaves), ldsStaged, st, d, sBase, hopBase, 0, 0);
+			countLaunch(LK_VOC_STAGED);
 			return;
 		}
 	}
+	countLaunch(LK_VOC_GATHER);
 	if (plain) { hipLaunchKernelGGL((kVocoder<CH, true, L, false>), dim3(nStreams), dim3(64*kVocWaves), lds, st, d, sBase, hopBase, 0, 0); return; }
 	// mapped tiles: the hop rotation table beside the rings when the CU's 160 KB hold it (presetDefault: 3073 bins, 24 KB)
 	const size_t ldsRot = lds + (size_t)d.M*sizeof(float2);
@@ -3399,6 +3647,7 @@ static void launchVocoderAcrossT(const DevBatch &d, int sBase, int nStreams, int
 }
 bool acrossSupported(const DevBatch &d) { return d.C <= 2 && d.lag == d.L + 1 && d.L >= 2 && d.L <= 5; }
 void launchVocoderAcross(const DevBatch &d, int sBase, int nStreams, int hopBase, bool plain, hipStream_t st) {
+	countLaunch(LK_VOC_ACROSS);
 	if (d.C == 1) launchVocoderAcrossT<1>(d, sBase, nStreams, hopBase, plain, st);
 	else launchVocoderAcrossT<2>(d, sBase, nStreams, hopBase, plain, st);
 }
@@ -3449,6 +3698,7 @@ static void launchVocoderOneT(const DevBatch &d, int sBase, int nStreams, int ho
 // single-hop tiles (every stream fires at most one hop): see kVocoderOne.  Same geometries as the fused 3-8 channel kernel.
 bool singleHopSupported(const DevBatch &d) { return d.lag == d.L + 1 && d.L >= 2 && d.L <= 5; }
 void launchVocoderOne(const DevBatch &d, int sBase, int nStreams, int hopBase, bool plain, hipStream_t st) {
+	countLaunch(LK_VOC_ONE);
 	switch (d.C) {
 	case 1: launchVocoderOneT<1>(d, sBase, nStreams, hopBase, plain, st); return;
 	case 2: launchVocoderOneT<2>(d, sBase, nStreams, hopBase, plain, st); return;
@@ -3464,6 +3714,7 @@ bool fusedSupported(const DevBatch &d) {
 	return d.lag == d.L + 1 && d.L >= 2 && d.L <= (d.C <= 2 ? 7 : 5); // other geometries: kPredictB + kChain (records through HBM)
 }
 void launchVocoder(const DevBatch &d, int sBase, int nStreams, int hopBase, bool plain, bool bounded, hipStream_t st) {
+	if (d.C > 2) countLaunch(LK_VOC_N);
 	switch (d.C) {
 	case 1: launchVocoderT<1>(d, sBase, nStreams, hopBase, plain, bounded, st); return;
 	case 2: launchVocoderT<2>(d, sBase, nStreams, hopBase, plain, bounded, st); return;
@@ -3493,6 +3744,7 @@ static void launchChainT(const DevBatch &d, int sBase, int nStreams, int hopBase
 	hipLaunchKernelGGL(kChain<CH>, dim3(nStreams), dim3(64), lds, st, d, sBase, hopBase);
 }
 void launchChain(const DevBatch &d, int sBase, int nStreams, int hopBase, hipStream_t st) {
+	countLaunch(LK_CHAIN_UNFUSED);
 	switch (d.C) {
 	case 1: launchChainT<1>(d, sBase, nStreams, hopBase, st); break;
 	case 2: launchChainT<2>(d, sBase, nStreams, hopBase, st); break;
@@ -3507,14 +3759,16 @@ void launchChain(const DevBatch &d, int sBase, int nStreams, int hopBase, hipStr
 void launchSynth(const DevBatch &d, int sBase, int nStreams, int hopBase, int tileHops, hipStream_t st) {
 	const dim3 grid(tileHops, d.C, nStreams);
 	const size_t fastLds = ((size_t)d.M + d.M/16)*sizeof(float2);
-	if (!d.noFastFft && d.fftTeams && !d.fftLean && (d.M == 256*10 || d.M == 256*12) && tileHops*d.C*nStreams >= 6*d.teamsGrid) {
+	if (!d.noFastFft && d.fftTeams && !d.fftLean && (d.M == 256*10 || d.M == 256*12) && (d.fftTeams == 2 || tileHops*d.C*nStreams >= 6*d.teamsGrid)) {
 		const int jobs = tileHops*d.C*nStreams;
 		const int wgs = std::max(8, std::min((jobs + 2)/3/8*8, d.teamsGrid));
 		const size_t lds = ((size_t)d.M + d.M/2 + d.M/32)*sizeof(float4) + 3*fastLds + 64;
 		if (d.M == 256*10) hipLaunchKernelGGL((kSynthTeams<10, 3>), dim3(wgs), dim3(768), lds, st, d, d.hops, sBase, hopBase, tileHops, nStreams);
 		else hipLaunchKernelGGL((kSynthTeams<12, 3>), dim3(wgs), dim3(768), lds, st, d, d.hops, sBase, hopBase, tileHops, nStreams);
+		countLaunch(LK_SYNTH_TEAMS);
 		return;
 	}
+	if (!d.noFastFft && d.M%256 == 0 && (d.M/256 == 10 || d.M/256 == 12 || d.M/256 == 20 || d.M/256 == 24)) countLaunch(LK_SYNTH_FAST); else countLaunch(LK_SYNTH_GENERIC);
 	if (!d.noFastFft) {
 		if (d.M == 256*10) { if (d.fftLean) hipLaunchKernelGGL((kSynthFast<10, true>), grid, dim3(256), fastLds, st, d, sBase, hopBase); else hipLaunchKernelGGL((kSynthFast<10, false>), grid, dim3(256), fastLds, st, d, sBase, hopBase); return; }
 		if (d.M == 256*12) { if (d.fftLean) hipLaunchKernelGGL((kSynthFast<12, true>), grid, dim3(256), fastLds, st, d, sBase, hopBase); else hipLaunchKernelGGL((kSynthFast<12, false>), grid, dim3(256), fastLds, st, d, sBase, hopBase); return; }

@@ -895,10 +895,10 @@ def case_fft_teams_equals_per_frame(lib, monkeypatch, presets=(("cheaper", 48000
         x = np.stack([synth_input(s, channels, n, sr) for s in range(streams)])
         outs = []
         for teams in (True, False):
-            if teams:
-                monkeypatch.delenv("SMST_FFT_TEAMS", raising=False)
-            else:
-                monkeypatch.setenv("SMST_FFT_TEAMS", "0")
+            # "2": the team kernels even where a tile has only a few frames per team (on a 256-CU part this case is far below the
+            # launcher's threshold of six frames per team, and BOTH runs would take the per-frame kernels)
+            monkeypatch.setenv("SMST_FFT_TEAMS", "2" if teams else "0")
+            counts = [pkg.launch_count(k, lib) for k in ("analyse_teams", "synth_teams", "analyse_fast")]
             b = pkg.StretchBatch(streams, channels, preset=preset, sample_rate=sr, lib=lib)
             b.setTransposeSemitones(4.0, 0.2, stream=1)
             cut = n*2//3
@@ -907,6 +907,9 @@ def case_fft_teams_equals_per_frame(lib, monkeypatch, presets=(("cheaper", 48000
             y2 = np.array(b.process(np.ascontiguousarray(x[:, :, cut:]), int((n - cut)*1.4)), copy=True)
             b.close()
             outs.append(np.concatenate([y1, y2], axis=2))
+            grew = [pkg.launch_count(k, lib) - c for k, c in zip(("analyse_teams", "synth_teams", "analyse_fast"), counts)]
+            # teams: both team kernels ran, and the per-frame kernel took the frames that reach into the history (mixed tile)
+            assert (grew[0] > 0 and grew[1] > 0 and grew[2] > 0) if teams else (grew[0] == 0 and grew[1] == 0 and grew[2] > 0), (teams, grew)
         monkeypatch.delenv("SMST_FFT_TEAMS", raising=False)
         assert np.abs(outs[0]).max() > 0.05
         assert np.array_equal(outs[0], outs[1]), (preset, sr, float(np.abs(outs[0] - outs[1]).max()))

@@ -39,3 +39,44 @@ def test_world_size_2_gloo_matches_single_process(emu, tmp_path):
     whole = b.process(xs, nout)
     assert sharded.shape == whole.shape
     assert np.array_equal(sharded, whole)
+
+
+def _bench_module():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("smst_bench", os.path.join(ROOT, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_bench_self_launch_command():
+    """`python bench.py --gpus N` without a launcher starts its own N ranks the way the driver does -- or refuses loudly."""
+    import pytest
+    bench = _bench_module()
+    cmd, env = bench.self_launch_command(4, False, 8, ["--gpus", "4", "--steps", "3"], {"MASTER_PORT": "29999"})
+    assert cmd[1:4] == ["-m", "torch.distributed.run", "--nnodes=1"]
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "4" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
+    assert cmd[cmd.index("--master-port") + 1] == "29999" and cmd[-4:] == ["--gpus", "4", "--steps", "3"]
+    assert os.path.basename(cmd[-5]) == "bench.py" and env["MASTER_ADDR"] == "127.0.0.1" and env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    with pytest.raises(SystemExit) as e:
+        bench.self_launch_command(2, False, 1, ["--gpus", "2"], {})
+    assert "only 1 GPU(s) are visible" in str(e.value)
+    cmd, _ = bench.self_launch_command(2, True, 1, ["--gpus", "2", "--oversubscribe"], {})  # N ranks on one device: allowed, says so in the line
+    assert cmd[cmd.index("--nproc-per-node") + 1] == "2"
+
+
+def test_bench_refuses_more_gpus_than_visible():
+    """End to end on whatever box this runs on: asking for more GPUs than are visible is an error, not an n_gpus: 1 line."""
+    import torch
+    ask = torch.cuda.device_count() + 1 if torch.cuda.device_count() > 0 else 2
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(ask), "--steps", "1", "--warmup", "0"],
+                         capture_output=True, text=True, timeout=300, env={k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")})
+    assert res.returncode != 0
+    assert "GPU(s) are visible" in res.stderr and '"n_gpus"' not in res.stdout
+
+
+def test_bench_refuses_world_size_mismatch():
+    """Under a launcher with the wrong rank count the bench refuses as well (it used to print n_gpus: 1 for --gpus 8 with WORLD_SIZE unset)."""
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], capture_output=True, text=True, timeout=300, env=env)
+    assert res.returncode != 0 and "WORLD_SIZE (1) != --gpus (2)" in res.stderr

@@ -202,23 +202,28 @@ def test_cmd_main_flow_config1(hip, ref):
 
 @pytest.mark.gpu
 def test_staged_producers_equal_gathered(hip, monkeypatch):
-    """The fused recurrence kernel has two record producers: windows staged in LDS (plain tiles) and direct gathers.
-    Same arithmetic, so the outputs must be bit-identical -- over two calls, so that the carried state is exercised."""
+    """The fused recurrence kernel has three record producers: line-aligned rings in LDS with a wavefront lag of 8 bins
+    (plain tiles, the default), per-row windows staged in LDS with lag L+1 (SMST_NO_ALIGN=1; the only staged form for
+    L = 5) and direct gathers (SMST_NO_STAGE=1).  Same arithmetic, so the outputs must be bit-identical -- over two calls,
+    so that the carried state is exercised; the launch counters prove that each form really ran."""
     import torch
     pkg = package()
     S, C, sr = 8, 2, 48000
     x = torch.from_numpy(np.stack([synth_input(s, C, 24000, sr) for s in range(S)])).cuda()
     outs = []
-    for gathered in (False, True):
-        if gathered:
-            monkeypatch.setenv("SMST_NO_STAGE", "1")
+    for env, counter in ((None, "vocoder_aligned"), ("SMST_NO_ALIGN", "vocoder_staged"), ("SMST_NO_STAGE", "vocoder_gather")):
+        if env:
+            monkeypatch.setenv(env, "1")
+        before = pkg.launch_count(counter, hip)
         b = pkg.StretchBatch(S, C, preset="default", sample_rate=sr, lib=hip)
         y1 = b.process(x[:, :, :9000].contiguous(), 11000)
         y2 = b.process(x[:, :, 9000:].contiguous(), 21000)
         b.synchronize()
         outs.append(torch.cat([y1, y2], dim=2).clone())
         b.close()
+        assert pkg.launch_count(counter, hip) > before, counter
     assert torch.equal(outs[0], outs[1]), float((outs[0] - outs[1]).abs().max())
+    assert torch.equal(outs[1], outs[2]), float((outs[1] - outs[2]).abs().max())
 
 
 @pytest.mark.gpu
