@@ -15,8 +15,9 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# SMST_LIBRARY: measurement hook -- another BUILD of the same library (an A/B variant, an instrumented trace build under
-# variants/), never another implementation; unset in every product use
+# SMST_LIBRARY: measurement hook of bench.py / tools/ -- another BUILD of the same library (an A/B variant, an instrumented trace
+# build under variants/), never another implementation; unset in every product use, and announced on stderr when set.  A build that
+# lacks entry points of include/smst.h is refused at load unless SMST_LIBRARY_ALLOW_MISSING=1 (A/B against an older revision).
 LIBRARY_PATH = os.environ.get("SMST_LIBRARY") or os.path.join(_HERE, "libsmst_hip.so")
 CSRC_DIR = os.path.join(_HERE, "csrc")
 
@@ -114,9 +115,13 @@ class StretchError(RuntimeError):
 
 def bind(cdll):
     """Attach the include/smst.h prototypes to a loaded library object."""
+    missing = [name for name in _SIGNATURES if not hasattr(cdll, name)]
+    if missing and not (os.environ.get("SMST_LIBRARY") and os.environ.get("SMST_LIBRARY_ALLOW_MISSING") == "1"):
+        raise StretchError("the library lacks entry points of include/smst.h: %s (a stale build? rebuild with __graft_entry__.build(); "
+                           "an A/B build of an older revision needs SMST_LIBRARY_ALLOW_MISSING=1)" % ", ".join(missing))
     for name, (res, args) in _SIGNATURES.items():
-        if os.environ.get("SMST_LIBRARY") and not hasattr(cdll, name):
-            continue  # an A/B build of an older revision may lack the newest entry points
+        if name in missing:
+            continue
         f = getattr(cdll, name)
         f.restype = res
         f.argtypes = args
@@ -141,6 +146,9 @@ def load_library():
             import torch  # noqa: F401
         except ImportError:
             pass
+        if os.environ.get("SMST_LIBRARY"):
+            import sys
+            print("signalsmith-stretch_amd: SMST_LIBRARY is set -- loading %s instead of the in-tree library (measurement hook)" % LIBRARY_PATH, file=sys.stderr)
         _lib = bind(C.CDLL(LIBRARY_PATH))
     return _lib
 

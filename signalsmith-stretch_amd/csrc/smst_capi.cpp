@@ -329,6 +329,7 @@ int smst_configure(smst_stretch *h, int channels, int block, int interval, int s
 	SMST_TRY
 	std::unique_ptr<smst_batch> b(new smst_batch());
 	b->engine.reset(new Batch(1, channels, block, interval, split != 0, h->device, h->seed));
+	if (h->batch) b->engine->inheritAcrossConfigure(*h->batch->engine); // configure() does not reseed the engine (:38-39, :71-94)
 	h->batch = std::move(b);
 	applyParams(h);
 	return SMST_OK;

@@ -1173,6 +1173,27 @@ void Batch::copyStateFrom(Batch &o) {
 	for (auto &lh : lastHop) lh = LastHop();
 }
 
+void Batch::inheritAcrossConfigure(Batch &o) {
+	if (o.S != S) throw Error("inheritAcrossConfigure: stream counts differ");
+	SMST_HIP(hipSetDevice(o.dev));
+	SMST_HIP(hipStreamSynchronize(o.st));
+	std::vector<float> freq((size_t)S*2);
+	SMST_HIP(hipMemcpy(freq.data(), o.d.stFreq, freq.size()*sizeof(float), hipMemcpyDeviceToHost));
+	SMST_HIP(hipSetDevice(dev));
+	SMST_HIP(hipStreamSynchronize(st));
+	SMST_HIP(hipMemcpy(d.stFreq, freq.data(), freq.size()*sizeof(float), hipMemcpyHostToDevice));
+	for (int s = 0; s < S; ++s) {
+		const StreamSched &from = o.sched[s];
+		StreamSched &to = sched[s];
+		to.seed = from.seed;
+		to.prevInputOffset = from.prevInputOffset;
+		to.didSeek = from.didSeek;
+		to.seekTimeFactor = from.seekTimeFactor;
+		to.silenceCounter = from.silenceCounter;
+		to.silenceFirst = from.silenceFirst;
+	}
+}
+
 // ---- test hooks -------------------------------------------------------------------------------------------
 void Batch::debugGetState(int stream, int which, float *dst) {
 	SMST_HIP(hipSetDevice(dev));

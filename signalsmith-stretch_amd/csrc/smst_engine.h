@@ -83,6 +83,10 @@ public:
 	// the object is copyable in the reference (a plain struct, signalsmith-stretch.h:34-35): same geometry required; every piece of
 	// carried state, the parameters and the scheduler state of `other` replace this batch's
 	void copyStateFrom(Batch &other);
+	// What the reference's configure() (:71-94) leaves ALONE when an instance is configured again: the random engine (seeded in the
+	// constructor only, :38-39), prevInputOffset, didSeek / seekTimeFactor, the silence counter and the pitch-estimate averages
+	// (all reset by reset(), :49-60, not by configure).  `other` is the stream's previous batch (same stream count).
+	void inheritAcrossConfigure(Batch &other);
 
 	// test hooks: copy state rows to the host (which: 0 input, 1 prevInput, 2 output -> 2*C*M floats; 3 energy -> C*M)
 	void debugGetState(int stream, int which, float *dst);

@@ -15,6 +15,7 @@
 #include <cstring>
 #include "smst_device.h"
 #include <smst_complex.h> // angle brackets: tests/emu shadows this header for the CPU stand-in
+#include <smst_async.h>   // likewise
 
 namespace smst {
 
@@ -2372,33 +2373,40 @@ __device__ __forceinline__ void vocoderProduceStaged(const DevBatch &d, int s, i
 // What bounded the staged kernel above was the CU's L1-miss line rate: with lag = L+1 every row's
 // windows sit at their own odd alignment, a 160-byte IN window touches 2-3 lines of which it needs 64 new bytes, and each
 // line comes through L1 again in three or four consecutive blocks -- ~600 lines per 8-step block.  With a lag of EIGHT bins
-// row r covers bins 8(n-r) .. 8(n-r)+7 in block n: every row advances by exactly half a 128-byte line per block, in step.
-// So each (row, array) keeps a 32-bin ring in LDS -- bin x at position x & 31, i.e. the two lines around the row's current
-// bins -- and a line is fetched from memory exactly ONCE, whole and aligned, in the block before its first use:
+// row r covers bins b0 = 8(n-r) .. b0+7 in block n: every row advances by exactly half a 128-byte line per block, in step.
+// So each (row, array) keeps the two lines around the row's current bins in LDS, LINEARLY (32 bins: lines lo, lo+1), and a
+// line is fetched from memory exactly ONCE, whole and aligned, in the block before its first use:
 //   IN  needs bins b0-2L .. b0+7+L  (within [b0-8, b0+11]):  lines j-1, j at b0 = 16j; lines j, j+1 at b0 = 16j+8
 //   PV  needs bins b0+1  .. b0+7+L                         :  line  j      at b0 = 16j; lines j, j+1 at b0 = 16j+8
-// i.e. a row receives line (m+1)/2 of every array in the blocks with m = n - row odd (m = -1 brings line 0), into the half
-// of the ring whose line was last read the block before.  A producer wave owns 8 rows; per block 4 of them take a new line
-// of 2*CH arrays: 8*CH lines = CH 16-byte loads per lane, each instruction 8 whole lines (the lag-(L+1) form: 6 loads per
-// lane and block, ~75 lines per wave).  The rotation factors of a lane's two previous-hop bins travel in registers (the
-// table's active region is 4 KB and stays in L1); the row above a wave's first row (Prediction.energy of the previous hop,
-// owned by the neighbouring wave) is staged as the 16 bins its block needs.  The 8-bin lag costs 63*3 more steps per tile
-// (+5.6 %) and puts rows r and r+1 on complementary halves of the LDS banks with NO row padding (ring pitch 32 bins).
-// Same operands, same operations in the same order as vocoderProduceStaged / computeRecord: bit-identical records.
+// i.e. in the blocks with m = n - row odd (m = -1 brings line 0) a row moves its upper line to the lower half of the buffer
+// and parks line (m+1)/2 of every array in the upper half -- every lane moves and parks its own 16-byte piece, so no lane
+// reads what another one writes.  The bins of a block then sit at  base + (x - b0)  with base = 16 + st in a row's even blocks
+// and 8 + st in its odd ones: ONE select per block, after which every operand of a record is an immediate offset from that
+// base (a ring indexed by x & 31 cost three VALU instructions per LDS read, ~70 per record: the first form of this function
+// was 50 % SLOWER than the staged producers above for all its saved loads -- the CU's VALU issue is the shared limit).
+// A producer wave owns 8 rows; per block 4 of them take a new line of 2*CH arrays: 8*CH lines = CH 16-byte loads per lane,
+// each instruction 8 whole lines (the lag-(L+1) form: 6 loads per lane and block, ~75 lines per wave).  The rotation factors
+// of a lane's two previous-hop bins travel in registers (the table's active region is 4 KB and stays in L1); the row above a
+// wave's first row (Prediction.energy of the previous hop, owned by the neighbouring wave) is staged as the 16 bins its block
+// needs.  The 8-bin lag costs 63*3 more steps per tile (+5.6 %) and puts rows r and r+1 on complementary halves of the LDS
+// banks with no row padding.  Same operands, same operations in the same order as vocoderProduceStaged / computeRecord:
+// bit-identical records.
 template <int CH, int L>
 struct AlignGeom {
-	static constexpr int RING = 32;                   // bins per (row, array) ring
-	static constexpr int ROWLEN = 2*CH*RING;          // float2 per row: CH input rings, then CH previous-input rings
+	static constexpr int RING = 32;                   // bins per (row, array): two lines
+	static constexpr int ROWLEN = 2*CH*RING;          // float2 per row: CH input buffers, then CH previous-input buffers
 	static constexpr int XLEN = CH*16;                // the row above the wave's first row: 16 bins per channel
 	static constexpr int PER_PRODUCER = 8*ROWLEN + XLEN;
 	static constexpr int LOADS = CH;                  // (4 rows x 2*CH arrays x 8 pieces) / 64 lanes
 };
 
-template <int CH, int L, int NB>
+template <int CH, int L, int NB, bool FIRST>
 __device__ __forceinline__ void vocoderProduceAligned(const DevBatch &d, int s, int sg, int nh, int it, int k, int totalBlocks,
                                                       float4 *recs, volatile int *sync, const HopDesc *hopsLds, float2 *sbuf, const CarriedOutput &stOut) {
+	// FIRST: the wave that owns rows 0..7 (it == 0): the hop above its first row is the carried state, its row 0 folds the carried
+	// Band.output into its records (FOLD0), and it has a parking-only block before the tile's first one
 	using G = AlignGeom<CH, L>;
-	constexpr int NF = 9 + 3*CH, NCH = (NF + 3)/4, BS = 8, LAG = 8;
+	constexpr int NF = 9 + 3*CH, NCH = (NF + 3)/4, BS = 8;
 	static_assert(2*L <= 8 && 7 + L <= 11, "the windows must fit the two lines around the row's bins");
 	const int M = d.M, lines = M >> 4;
 	float2 *xbuf = sbuf + 8*G::ROWLEN;
@@ -2420,66 +2428,101 @@ __device__ __forceinline__ void vocoderProduceAligned(const DevBatch &d, int s, 
 			const HopDesc hd = hopsLds[ok ? row : 0];
 			const float2 *src = (a < CH) ? inputRow(d, hd, s, sg, a) : prevRow(d, hd, s, row, sg, a - CH);
 			lsrc[par][i] = (ok ? src : d.rot) + 2*piece;
-			llds[par][i] = r*G::ROWLEN + a*G::RING + 2*piece;
+			llds[par][i] = r*G::ROWLEN + a*G::RING + 2*piece; // this lane's piece of the LOWER line; the upper one is 16 bins on
 			lrow[par][i] = ok ? r : (1 << 20); // a row beyond the tile's hops never reaches m >= -1
 		}
 	}
-	// the row above this wave's first row: hop 8*it - 1 of the tile, or (it == 0) the carried Prediction.energy
+	// the row above this wave's first row: hop 8*it - 1 of the tile, or (FIRST) the carried Prediction.energy (fp32: the launcher keeps
+	// batches with fp16 state on the staged producers above)
 	const int xc = (k >> 3) < CH ? (k >> 3) : 0, xpiece = k & 7;
 	const bool xlane = k < 8*CH;
 	const float2 *xsrc = d.rot;
-	if (it > 0) xsrc = inputRow(d, hopsLds[8*it - 1], s, sg, xc);
-	const size_t xenergy = stateRow(d, sg, xc);
-	float4 v[G::LOADS];
-	float4 xv = make_float4(0.f, 0.f, 0.f, 0.f);
+	if (!FIRST) xsrc = inputRow(d, hopsLds[8*it - 1], s, sg, xc);
+	const float *xenergy = d.stEnergy + stateRow(d, sg, xc);
+	const float2 *carried = static_cast<const float2 *>(stOut.base); // [CH][M]
+	// Loads are requested through smst_async.h and waited for by COUNT (loads return in order): the lines of block n+2, the small
+	// loads of block n+1 (row above, rotation factors, FIRST: carried taps) are requested during block n, in the order
+	//   ... lines(n) | small(n) lines(n+1) | small(n+1) lines(n+2) ...
+	// so at the top of block n everything but the LOADS youngest requests -- lines(n+1) -- has to have landed.  A line comes from HBM
+	// and a block lasts ~2 us: with one block of lead the producers waited for their loads a third of every block (cycle trace,
+	// tools/probes/voc_trace_patch_aligned.py), and left to the compiler the waits degenerate to vmcnt(0) behind the branches of
+	// this loop.  Two register sets, one per block parity: the set parked in block n is free for block n+2's lines.
+	Async16 vE[G::LOADS], vO[G::LOADS], xv;
+	Async8 xe, rotNext1, rotNextL, carNext1[CH], carNextL[CH];
 	const int st = k & 7, r = k >> 3, row = 8*it + r;
-	float2 rot1 = make_float2(1.f, 0.f), rotL = rot1, rotNext1 = rot1, rotNextL = rot1;
-	auto lineOf = [&](int n, int i) { const int m = n - 8*it - lrow[(n + 1) & 1][i]; return m >= -1 ? (m + 1) >> 1 : -1; }; // m is odd
-	auto issue = [&](int n) {
-		const int par = (n + 1) & 1;
+	float2 rot1 = make_float2(1.f, 0.f), rotL = rot1;
+	// PAR = (n + 1) & 1: the rows with that parity take a new line in block n; m = n - row is odd
+	auto lineOf = [&](int n, int par, int i) { const int m = n - 8*it - lrow[par][i]; return m >= -1 ? (m + 1) >> 1 : -1; };
+	auto issueLines = [&](int n, int par, Async16 (&v)[G::LOADS]) {
 #pragma unroll
 		for (int i = 0; i < G::LOADS; ++i) {
-			const int j = lineOf(n, i);
-			const int jc = min(max(j, 0), lines - 1);
-			v[i] = *reinterpret_cast<const float4 *>(lsrc[par][i] + 16*jc);
+			const int jc = min(max(lineOf(n, par, i), 0), lines - 1);
+			asyncLoad16(v[i], lsrc[par][i] + 16*jc);
 		}
-		const int x0 = BS*(n - 8*it) + 2*xpiece, xcl = min(max(x0, 0), M - 2);
-		if (it > 0) xv = *reinterpret_cast<const float4 *>(xsrc + xcl);
-		else { const float2 e = loadEnergyPair(d, xenergy + xcl); xv = make_float4(e.x, 0.f, e.y, 0.f); }
-		const int b = BS*(n - row) + st;
-		rotNext1 = d.rot[min(max(b + 1, 0), M - 1)];
-		rotNextL = d.rot[min(max(b + L, 0), M - 1)];
 	};
-	auto park = [&](int n) {
-		const int par = (n + 1) & 1;
+	auto issueSmall = [&](int n) { // 3 requests (FIRST: 3 + 2*CH), every address clamped into its row: n may run past the tile's last block
+		const int x0 = BS*(n - 8*it) + 2*xpiece, xcl = min(max(x0, 0), M - 2);
+		if (FIRST) asyncLoad8(xe, xenergy + xcl);
+		else asyncLoad16(xv, xsrc + xcl);
+		const int b = BS*(n - row) + st;
+		asyncLoad8(rotNext1, d.rot + min(max(b + 1, 0), M - 1));
+		asyncLoad8(rotNextL, d.rot + min(max(b + L, 0), M - 1));
+		if (FIRST) { // hop 0's previous-hop taps are the carried Band.output (FOLD0): lanes 0..7 = row 0 (no skew), steps 0..7
+			const int b0 = min(max(BS*n + st, 0), M - 1);
+#pragma unroll
+			for (int c = 0; c < CH; ++c) {
+				asyncLoad8(carNext1[c], carried + (size_t)c*M + min(b0 + 1, M - 1));
+				asyncLoad8(carNextL[c], carried + (size_t)c*M + min(b0 + L, M - 1));
+			}
+		}
+	};
+	float2 car1[CH], carL[CH];
+#pragma unroll
+	for (int c = 0; c < CH; ++c) car1[c] = carL[c] = make_float2(0.f, 0.f);
+	// Everything block n needs has landed: called at the very END of block n-1 (and once in front of the loop), not at the top of
+	// block n -- the compiler resolves loop-carried values with register copies at the top of the loop body, and a copy of a register
+	// whose load is still in flight reads garbage (seen in the generated code of the first version; tools/check_async_isa.py scans the
+	// ISA of every build for such reads)
+	auto landed = [&](Async16 (&v)[G::LOADS]) {
+		asyncWait<G::LOADS>();
+#pragma unroll
+		for (int i = 0; i < G::LOADS; ++i) asyncArrived(v[i]);
+		if (FIRST) asyncArrived(xe); else asyncArrived(xv);
+		asyncArrived(rotNext1);
+		asyncArrived(rotNextL);
+		if (FIRST) {
+#pragma unroll
+			for (int c = 0; c < CH; ++c) { asyncArrived(carNext1[c]); asyncArrived(carNextL[c]); }
+		}
+	};
+	auto park = [&](int n, int par, Async16 (&v)[G::LOADS]) {
+		if (FIRST) {
+#pragma unroll
+			for (int c = 0; c < CH; ++c) { car1[c] = asyncValue(carNext1[c]); carL[c] = asyncValue(carNextL[c]); }
+		}
 #pragma unroll
 		for (int i = 0; i < G::LOADS; ++i) {
-			const int j = lineOf(n, i);
-			if (j >= 0) *reinterpret_cast<float4 *>(sbuf + llds[par][i] + 16*(j & 1)) = (j < lines) ? v[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+			const int j = lineOf(n, par, i);
+			if (j >= 0) { // upper line -> lower half, the new line -> upper half (this lane's piece of both)
+				float4 *lower = reinterpret_cast<float4 *>(sbuf + llds[par][i]), *upper = reinterpret_cast<float4 *>(sbuf + llds[par][i] + 16);
+				*lower = *upper;
+				*upper = (j < lines) ? asyncValue(v[i]) : make_float4(0.f, 0.f, 0.f, 0.f);
+			}
 		}
 		const int x0 = BS*(n - 8*it) + 2*xpiece;
-		if (xlane) *reinterpret_cast<float4 *>(xbuf + xc*16 + (x0 & 15)) = (x0 >= 0 && x0 + 1 < M) ? xv : make_float4(0.f, 0.f, 0.f, 0.f);
-		rot1 = rotNext1;
-		rotL = rotNextL;
+		if (xlane) {
+			float4 piece;
+			if (FIRST) { const float2 e = asyncValue(xe); piece = make_float4(e.x, 0.f, e.y, 0.f); }
+			else piece = asyncValue(xv);
+			*reinterpret_cast<float4 *>(xbuf + xc*16 + 2*xpiece) = (x0 >= 0 && x0 + 1 < M) ? piece : make_float4(0.f, 0.f, 0.f, 0.f);
+		}
+		rot1 = asyncValue(rotNext1);
+		rotL = asyncValue(rotNextL);
 	};
 	const HopDesc hd = hopsLds[row < nh ? row : 0];
 	const bool rotate = hd.flags & HOP_NEW_SPECTRUM;
 	const float tf = hd.timeFactor;
-	const float2 *mine = sbuf + r*G::ROWLEN, *above = sbuf + (r > 0 ? r - 1 : 0)*G::ROWLEN;
-	// Hop 0's previous-hop taps are the carried Band.output (FOLD0, see computeRecord): the wave that owns row 0 fetches them with
-	// its lines, one block ahead (lanes 0..7 = row 0, steps 0..7; the other lanes load in-range values they never use)
-	float2 car1[CH], carL[CH], carNext1[CH], carNextL[CH];
-#pragma unroll
-	for (int c = 0; c < CH; ++c) car1[c] = carL[c] = carNext1[c] = carNextL[c] = make_float2(0.f, 0.f);
-	auto issueCarried = [&](int nn) {
-		const int b = BS*nn + st; // row 0: no skew
-#pragma unroll
-		for (int c = 0; c < CH; ++c) {
-			carNext1[c] = stOut[(size_t)c*M + min(b + 1, M - 1)];
-			carNextL[c] = stOut[(size_t)c*M + min(b + L, M - 1)];
-		}
-	};
-	// The wave's first lines are due in block n0 = 8*it - 1 (m = -1 of its first row: line 0); for it == 0 that is a block BEFORE the
+	// The wave's first lines are due in block n0 = 8*it - 1 (m = -1 of its first row: line 0); for FIRST that is a block BEFORE the
 	// tile's first one, which only parks.  Blocks before n0 (the wavefront has not reached this wave's rows): all-zero records.
 	const int n0 = 8*it - 1;
 	for (int skip = 0; skip < min(n0, totalBlocks); ++skip) {
@@ -2491,24 +2534,40 @@ __device__ __forceinline__ void vocoderProduceAligned(const DevBatch &d, int s, 
 		asm volatile("" ::: "memory");
 		if (k == 0) ldsCount(&sync[slot]);
 	}
-	int n = n0;
-	if (n < totalBlocks) issue(n);
-	for (; n < totalBlocks; ++n) {
-		park(n);
-		if (it == 0) {
-#pragma unroll
-			for (int c = 0; c < CH; ++c) { car1[c] = carNext1[c]; carL[c] = carNextL[c]; }
-		}
+	if (n0 >= totalBlocks) return; // (a tile so short that the wavefront never reaches this wave's rows)
+	// n0 is odd (or -1): block n0 takes the register set of parity 0 ("E": blocks n with (n + 1) & 1 == 0), block n0 + 1 the other one
+	issueLines(n0, 0, vE);
+	issueSmall(n0);
+	issueLines(n0 + 1, 1, vO);
+	landed(vE);
+	// Block n0 itself: every row of the wave is still in front of bin 0 (m = -1 for the first row) -- park, request, all-zero records
+	// (FIRST: n0 = -1 lies before the tile, no records).  The blocks after it come in pairs, one per register set, with no
+	// condition inside the loop: n0 + 1 and the number of blocks are both even.
+	{
+		park(n0, 0, vE);
 		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 		__builtin_amdgcn_wave_barrier();
 		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-		if (n + 1 < totalBlocks) { issue(n + 1); if (it == 0) issueCarried(n + 1); }
-		if (n < 0) { // the parking-only block of the wave that owns row 0
-			__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-			__builtin_amdgcn_wave_barrier();
-			__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-			continue;
+		issueSmall(n0 + 1);
+		issueLines(n0 + 2, 0, vE);
+		if (!FIRST) {
+			const int slot = n0%NB;
+			while (n0 - ldsPeek(&sync[NB]) >= NB) __builtin_amdgcn_s_sleep(2);
+			asm volatile("" ::: "memory");
+#pragma unroll
+			for (int j = 0; j < NCH; ++j) recs[((slot*BS + st)*NCH + j)*64 + ((row + st) & 63)] = make_float4(0.f, 0.f, 0.f, 0.f);
+			asm volatile("" ::: "memory");
+			if (k == 0) ldsCount(&sync[slot]);
 		}
+		landed(vO);
+	}
+	auto step = [&](int n, int par, Async16 (&v)[G::LOADS], Async16 (&vNextBlock)[G::LOADS]) {
+		park(n, par, v);
+		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+		__builtin_amdgcn_wave_barrier();
+		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+		issueSmall(n + 1);
+		issueLines(n + 2, par, v);
 		const int slot = n%NB;
 		while (n - ldsPeek(&sync[NB]) >= NB) __builtin_amdgcn_s_sleep(2); // slot still being read
 		asm volatile("" ::: "memory");
@@ -2517,16 +2576,22 @@ __device__ __forceinline__ void vocoderProduceAligned(const DevBatch &d, int s, 
 #pragma unroll
 		for (int j = 0; j < NCH*4; ++j) f[j] = 0.0f;
 		if (row < nh && b >= 0 && b < M) {
-			// same arithmetic as computeRecord<CH, true, false, false>, operands from the rings
-			auto IN = [&](int c, int x) { return mine[c*G::RING + (x & 31)]; };
-			auto lerpIN = [&](int c, LerpIndex li) {
-				const float2 low = IN(c, li.lo), high = IN(c, li.lo + 1);
+			// same arithmetic as computeRecord<CH, true, false, false>, operands from the line buffers.  This row's buffer holds the
+			// lines (j-1, j) in its even blocks (b0 = 16j) and (j, j+1) in its odd ones, so bin b sits at 16 + st resp. 8 + st; the row
+			// above runs 8 bins ahead (opposite parity): its buffer holds (j, j+1) either way, bin b at st resp. 8 + st.
+			const bool odd = (n - row) & 1;
+			const float2 *mine = sbuf + r*G::ROWLEN + (odd ? 8 : 16) + st;                               // bin b of channel 0's input
+			const float2 *above = (r > 0) ? sbuf + (r - 1)*G::ROWLEN + (odd ? 8 : 0) + st : xbuf + st; // bin b of the hop above (r == 0: the staged 16 bins start at b0)
+			const int abovePitch = (r > 0) ? G::RING : 16; // channel pitch of `above`
+			auto IN = [&](int c, int off) { return mine[c*G::RING + off]; }; // bin b + off
+			auto lerpIN = [&](int c, LerpIndex li) { // li.lo is an absolute bin
+				const float2 low = mine[c*G::RING + (li.lo - b)], high = mine[c*G::RING + (li.lo - b) + 1];
 				return clerp(low, high, li.fr);
 			};
 			float2 p[CH];
 			float e[CH];
 #pragma unroll
-			for (int c = 0; c < CH; ++c) { p[c] = IN(c, b); e[c] = cnorm(p[c]); }
+			for (int c = 0; c < CH; ++c) { p[c] = IN(c, 0); e[c] = cnorm(p[c]); }
 			int mc = 0;
 			float eMax = e[0];
 #pragma unroll
@@ -2537,15 +2602,15 @@ __device__ __forceinline__ void vocoderProduceAligned(const DevBatch &d, int s, 
 			const float fb = float(b);
 			float2 A = cmulc(Pm, lerpIN(mc, lerpIndex(fb - tf)));
 			float2 B = cmulc(Pm, lerpIN(mc, lerpIndex(fb - L*tf)));
-			auto twist = [&](int bx, float2 rotV, float stepMul) {
-				const int bc = min(bx, M - 1);
+			auto twist = [&](int off, float2 rotV, float stepMul) { // bx = b + off
+				const int bc = min(b + off, M - 1);
 				const float2 rotB = rotate ? rotV : make_float2(1.f, 0.f);
-				const float2 Q = cmul(mine[(CH + mc)*G::RING + (bx & 31)], rotB);
-				const float2 Px = IN(mc, bx);
+				const float2 Q = cmul(mine[(CH + mc)*G::RING + off], rotB);
+				const float2 Px = IN(mc, off);
 				const float2 TW = cmul(rotB, cmulc(Px, Q));
 				const float eNow = cnorm(Px);
-				// Prediction.energy of the previous hop: hop row-1's input (its ring runs 8 bins ahead of this row's), or the carried state
-				const float2 up = (r > 0) ? above[mc*G::RING + (bx & 31)] : xbuf[mc*16 + (bx & 15)];
+				// Prediction.energy of the previous hop: hop row-1's input, or the carried state
+				const float2 up = above[mc*abovePitch + off];
 				const float ePrev = (row > 0) ? cnorm(up) : up.x;
 				const float den = fmaxf(ePrev, eNow) + 1e-15f;
 				const float2 down = cmulc(Px, lerpIN(mc, lerpIndex(float(bc) - stepMul*tf)));
@@ -2553,13 +2618,13 @@ __device__ __forceinline__ void vocoderProduceAligned(const DevBatch &d, int s, 
 				const float inv = __builtin_amdgcn_rcpf(den); // 1-ulp hardware reciprocal (an IEEE division costs ten instructions per record)
 				return make_float2(rr.x*inv, rr.y*inv);
 			};
-			float2 Cc = twist(b + 1, rot1, 1.0f), Dc = twist(b + L, rotL, float(L));
+			float2 Cc = twist(1, rot1, 1.0f), Dc = twist(L, rotL, float(L));
 			const float2 zero = make_float2(0.f, 0.f);
 			if (!(b > 0)) A = zero;
 			if (!(b >= L)) B = zero;
 			if (!(b < M - 1)) Cc = zero;
 			if (!(b < M - L)) Dc = zero;
-			if (it == 0) { // FOLD0: row 0's record carries the previous-hop part ready-made (wave-uniform branch, lane select inside)
+			if (FIRST) { // FOLD0: row 0's record carries the previous-hop part ready-made (lane select inside)
 				float2 c1 = car1[0], cL = carL[0];
 #pragma unroll
 				for (int c = 1; c < CH; ++c) if (c == mc) { c1 = car1[c]; cL = carL[c]; }
@@ -2577,7 +2642,13 @@ __device__ __forceinline__ void vocoderProduceAligned(const DevBatch &d, int s, 
 		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 		__builtin_amdgcn_wave_barrier(); // every lane has read its operands before the next block's lines are parked
 		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+		landed(vNextBlock);
+	};
+	for (int n = n0 + 1; n < totalBlocks; n += 2) {
+		step(n, 1, vO, vE);
+		step(n + 1, 0, vE, vO);
 	}
+	asyncWait<0>(); // the requests that ran past the tile's last block: nothing of this wave stays in flight behind it
 }
 
 constexpr int kVocBlockSteps = 8, kVocBlocks = 3, kVocBlocksStaged = 2, kVocWaves = 16, kVocStagedProducers = 8, kVocOutBlocks = 4;
@@ -2715,7 +2786,8 @@ __global__ __launch_bounds__(64*kVocWaves) __attribute__((amdgpu_waves_per_eu(4,
 		if constexpr (ALIGNED) {
 			using G = AlignGeom<CH, L>;
 			float2 *sbuf = outRing + (size_t)OB*BS*CH*kVocOutPitch + (size_t)pIndex*G::PER_PRODUCER;
-			vocoderProduceAligned<CH, L, NB>(d, s, sg, nh, pIndex, k, totalBlocks, recs, sync, hopsLds, sbuf, stOut);
+			if (pIndex == 0) vocoderProduceAligned<CH, L, NB, true>(d, s, sg, nh, pIndex, k, totalBlocks, recs, sync, hopsLds, sbuf, stOut);
+			else vocoderProduceAligned<CH, L, NB, false>(d, s, sg, nh, pIndex, k, totalBlocks, recs, sync, hopsLds, sbuf, stOut);
 			return;
 		} else if constexpr (STAGED) {
 			using G = StageGeom<CH, L>;
@@ -3596,7 +3668,7 @@ static void launchVocoderTL(const DevBatch &d, int sBase, int nStreams, int hopB
 	const size_t fixed = 64 + 128*sizeof(int) + 64*sizeof(HopDesc) + (size_t)kVocOutBlocks*kVocBlockSteps*CH*kVocOutPitch*sizeof(float2);
 	const size_t lds = (size_t)kVocBlocks*kVocBlockSteps*NCH*64*sizeof(float4) + fixed;
 	if constexpr (L <= 4) {
-		if (plain && bounded && !d.noStage && !d.noAlign && d.M%16 == 0) {
+		if (plain && bounded && !d.noStage && !d.noAlign && d.M%16 == 0 && !d.halfState) { // (fp16 state: the staged producers below)
 			using G = AlignGeom<CH, L>;
 			const size_t fixedA = 64 + 128*sizeof(int) + 64*sizeof(HopDesc) + (size_t)kVocOutBlocksAligned*kVocBlockSteps*CH*kVocOutPitch*sizeof(float2);
 			const size_t ldsAligned = (size_t)kVocBlocksStaged*kVocBlockSteps*NCH*64*sizeof(float4) + fixedA + (size_t)kVocStagedProducers*G::PER_PRODUCER*sizeof(float2);

@@ -42,8 +42,12 @@ if wall[1] > wall[0]:
     ns = (wall[1] - wall[0])*10.0
     cyc = float(t[5, 300] - t[5, 100])
     print("blocks 100..300: %.1f us wall, %.0f shader-clock ticks -> %.2f GHz, %.2f us per block" % (ns/1e3, cyc, cyc/ns, ns/200e3))
-print("producer 0 : period %.0f | park+barrier %.0f | issue %.0f | slot wait %.0f | compute %.0f | record write %.0f | rest %.0f" % (
-    period(0), d(0, 1), d(1, 12), d(12, 2), d(2, 3), d(3, 4), period(0) - d(0, 4)))
+if t[13, lo:hi].min() > 0:  # the aligned producers' trace: an explicit wait for the loads in front of the parking
+    print("producer 0 : period %.0f | wait loads %.0f | park+barrier %.0f | issue %.0f | slot wait %.0f | compute %.0f | record write %.0f | rest %.0f" % (
+        period(0), d(0, 13), d(13, 1), d(1, 12), d(12, 2), d(2, 3), d(3, 4), period(0) - d(0, 4)))
+else:
+    print("producer 0 : period %.0f | park+barrier %.0f | issue %.0f | slot wait %.0f | compute %.0f | record write %.0f | rest %.0f" % (
+        period(0), d(0, 1), d(1, 12), d(12, 2), d(2, 3), d(3, 4), period(0) - d(0, 4)))
 print("recurrence : period %.0f | wait records %.0f | wait writer %.0f | 8 steps %.0f | rest %.0f" % (
     period(5), d(5, 6), d(6, 7), d(7, 8), period(5) - d(5, 8)))
 print("writer     : period %.0f | wait %.0f | stores %.0f" % (period(9), d(9, 10), d(10, 11)))
