@@ -1,4 +1,4 @@
-"""Turns the rocprofv3 CSVs collected by tests/prof_counters.sh (kernel trace + stats, FETCH_SIZE / WRITE_SIZE / SQ
+"""Turns the rocprofv3 CSVs collected by tools/prof/prof_counters.sh (kernel trace + stats, FETCH_SIZE / WRITE_SIZE / SQ
 passes, each in its own run) into the small summaries committed under profiles/.
 usage: python profiles/summarize.py gpurun_out/<tag> r1 [steps profiled, default 3]
 HBM bytes per launch follow /opt/skills/guides/MI355X_MICROARCH.md (HBM section): FETCH_SIZE and WRITE_SIZE are in KiB;
@@ -55,13 +55,13 @@ def main():
                 best[base] = v.get("calls", 0)
     json.dump(out, open(os.path.join(here, tag + "_pmc_summary.json"), "w"), indent=1, sort_keys=True)
     # what bench.py quotes as `traffic`: only valid for the library build the passes ran on (bench.py compares the hash)
-    steps = int(sys.argv[3]) if len(sys.argv) > 3 else 3  # tests/prof_counters.sh: --steps 2 --warmup 1
+    steps = int(sys.argv[3]) if len(sys.argv) > 3 else 3  # tools/prof/prof_counters.sh: --steps 2 --warmup 1
     per_step = sum(v["hbm_bytes_per_launch"]*v.get("calls", 0) for v in out.values() if "hbm_bytes_per_launch" in v)/steps
     import hashlib
     lib = os.path.join(os.path.dirname(here), "signalsmith-stretch_amd", "libsmst_hip.so")
     sha = hashlib.sha256(open(lib, "rb").read()).hexdigest()[:16]
     latest = {"library_sha16": sha, "bytes_per_step": per_step, "kernels": traffic, "steps_profiled": steps,
-              "command": "bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-serial-pass (tests/prof_counters.sh)", "summary": tag + "_pmc_summary.json"}
+              "command": "bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-serial-pass (tools/prof/prof_counters.sh)", "summary": tag + "_pmc_summary.json"}
     json.dump(latest, open(os.path.join(here, "traffic_latest.json"), "w"), indent=1, sort_keys=True)
     for k in sorted(out, key=lambda k: -out[k].get("avg_us", 0)*out[k].get("calls", 0)):
         v = out[k]

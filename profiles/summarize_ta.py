@@ -1,4 +1,4 @@
-"""Summarises the TA / TCP counter passes of tests/prof_counters2.sh (two counters per rocprofv3 run) into one JSON:
+"""Summarises the TA / TCP counter passes of tools/prof/prof_counters_ta.sh (two counters per rocprofv3 run) into one JSON:
 per kernel, every counter averaged per launch, plus the same divided by TCP_GATE_EN1 (= CU-cycles of the launch summed
 over the CUs), e.g. TA_TA_BUSY/TCP_GATE_EN1 = fraction of the time the texture-address unit was busy.
 usage: python profiles/summarize_ta.py gpurun_out/<tag> profiles/<name>.json ["note"]"""

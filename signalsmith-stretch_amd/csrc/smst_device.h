@@ -16,7 +16,7 @@ struct DevBatch {
 	int hopStride, emitStride;    // row pitch of the per-call hop / emit tables
 	int mapTableLen;
 	int histCur, carryCur;        // which half of the double buffers is current
-	int debugMode;                // SMST_DEBUG_MODE experiments (0 = product behaviour)
+	int debugMode;                // always 0 in the product; builds with -DSMST_EXPERIMENTS read SMST_DEBUG_MODE (timing experiments)
 	int noFeedFusion;             // SMST_NO_FEED_FUSION=1: pass A stays its own kernel (kPredictA) -- cross-check of the folded form
 	int feedSerial;               // SMST_FEED_SERIAL: bin-by-bin feed recurrences (kFeedSerial) instead of the scan form
 	int halfState;                // carried Band.output / Prediction.energy / overlap-add sums stored in fp16 (BASELINE config 5 "fp16 internal")

@@ -17,6 +17,17 @@
 #include <smst_complex.h> // angle brackets: tests/emu shadows this header for the CPU stand-in
 #include <smst_async.h>   // likewise
 
+// Timing experiments that make the output meaningless (SMST_DEBUG_MODE=1: the record producers skip their arithmetic, =2: the recurrence
+// wave only acknowledges its blocks) exist ONLY in builds with -DSMST_EXPERIMENTS (tools/probes/build_variant.sh <name> -- -DSMST_EXPERIMENTS);
+// the product library has no such switch.
+#ifdef SMST_EXPERIMENTS
+#define SMST_SKIP_PRODUCER_MATH(d) ((d).debugMode == 1)
+#define SMST_CONSUMER_ONLY_ACKNOWLEDGES(d) ((d).debugMode == 2)
+#else
+#define SMST_SKIP_PRODUCER_MATH(d) false
+#define SMST_CONSUMER_ONLY_ACKNOWLEDGES(d) false
+#endif
+
 namespace smst {
 
 // ------------------------------------------------------------------------------------------------------
@@ -455,11 +466,17 @@ __device__ __forceinline__ void fftFast(float2 *lds, const float4 *__restrict__ 
 	}
 }
 
-// The whole analysis window of the hop lies in this call's input, and the halves of the packed input change validity at element-slot
-// boundaries (both presets): the frames that kAnalyseTeams takes.  The host evaluates the same condition (smst_engine.cpp).
+// The whole analysis window of the hop lies in this call's input: the frames that kAnalyseTeams takes (the others reach into the carried
+// history and go to the per-frame kernel's bounds-checked path).  The host evaluates the same condition (smst_engine.cpp).
 __device__ __forceinline__ bool analysisWindowInCall(const DevBatch &d, const HopDesc &hd, int which) {
-	const int halfB = d.B/2, MA = d.M/16;
-	return d.M - halfB == MA && d.B - halfB == 15*MA && hd.inputOffset - (which ? d.I : 0) - d.B >= 0;
+	return hd.inputOffset - (which ? d.I : 0) - d.B >= 0;
+}
+// The two halves of the packed input (real part: samples of the window's second half, imaginary part: of its first half) change
+// validity exactly at element-slot boundaries -- slot 0 has no imaginary part, slot 15 no real part: presetDefault / presetCheaper at
+// 48 and 96 kHz (block = 15/16 of the FFT size).  Other block sizes (44.1 kHz: 5292 of 6144) test every element.
+__host__ __device__ __forceinline__ bool slotAlignedWindow(int B, int M) {
+	const int halfB = B/2, MA = M/16;
+	return M - halfB == MA && B - halfB == 15*MA;
 }
 
 template <int R3, bool LEAN>
@@ -565,11 +582,15 @@ struct TeamSync { // LDS operations of a wave complete in order: a wave's counte
 	}
 };
 
-template <int R3, int TEAMS>
+// SLOTS: slotAlignedWindow(B, M) -- the validity of an element's halves is then a compile-time property of its slot; otherwise (44.1 kHz)
+// every element compares its index with the window's two edges.  Either way the arithmetic is kAnalyseFast's, element for element.
+template <int R3, int TEAMS, bool SLOTS>
 __global__ __launch_bounds__(256*TEAMS) void kAnalyseTeams(DevBatch d, IoArgs io, const HopDesc *__restrict__ hopTable, int sBase, int hopBase, int tileHops, int nStreams) {
 	static_assert(16*R3 <= 256, "a team is 256 threads");
 	extern __shared__ __attribute__((aligned(16))) unsigned char smemRaw[];
-	constexpr int MA = 16*R3, H = 256*R3, N = 2*H, B = 480*R3, halfB = B/2; // the geometry this kernel is launched for (analysisWindowInCall)
+	constexpr int MA = 16*R3, H = 256*R3, N = 2*H;
+	const int B = SLOTS ? 480*R3 : d.B, halfB = B/2; // SLOTS: the geometry this kernel is launched for
+	const int realEnd = B - halfB, imagBegin = H - halfB; // element m has a real part for m < realEnd, an imaginary part for m >= imagBegin
 	const int team = __builtin_amdgcn_readfirstlane(threadIdx.x >> 8), t = threadIdx.x & 255, tA = t < MA ? t : 0;
 	const int total = tileHops*2*d.C*nStreams;
 	float4 *winLds = reinterpret_cast<float4 *>(smemRaw); // (winA, winB) of all elements
@@ -592,14 +613,25 @@ __global__ __launch_bounds__(256*TEAMS) void kAnalyseTeams(DevBatch d, IoArgs io
 		if (!(hd.flags & HOP_ACTIVE) || !(hd.flags & HOP_NEW_SPECTRUM) || (which && !(hd.flags & HOP_REANALYSE_PREV)) || !analysisWindowInCall(d, hd, which)) continue;
 		const int base = hd.inputOffset - (which ? d.I : 0) - B;
 		const float *x = io.in + (size_t)(sBase + bc.s)*io.inStreamStride + (size_t)c*io.inChannelStride;
-		const float *x0 = x + base + halfB, *x1 = x + base - H + halfB; // slot 0 has no imaginary part, slot 15 no real part
+		const float *x0 = x + base + halfB, *x1 = x + base - H + halfB;
 		float2 *dst = (which ? d.Xprev : d.Xcur) + rowOf(d, bc.s, bc.x, c);
 		fftFast<-1, R3, false>(lds, twALds, twBLds,
 			[&](int m, int slot) { // kAnalyseFast's roundings: round(xi*b + round(xr*a)), the absent half an exact zero
 				const float4 w = winLds[tA + MA*slot];
 				float2 r = make_float2(0.f, 0.f);
-				if (slot < 15) { const float xr = x0[m]; r = make_float2(xr*w.x, xr*w.y); }
-				if (slot > 0) { const float xi = x1[m]; r = make_float2(fmaf(xi, w.z, r.x), fmaf(xi, w.w, r.y)); }
+				if constexpr (SLOTS) {
+					if (slot < 15) { const float xr = x0[m]; r = make_float2(xr*w.x, xr*w.y); }
+					if (slot > 0) { const float xi = x1[m]; r = make_float2(fmaf(xi, w.z, r.x), fmaf(xi, w.w, r.y)); }
+				} else {
+					// branch-free: both samples are always fetched (index clamped into the window) and the absent half is selected away --
+					// a load inside a lane-dependent branch ends the basic block, and the element's 32 loads then wait for each other in
+					// turn (first version: analysis 4.3 -> 8.4 ms per step at 44.1 kHz)
+					const bool hasRe = m < realEnd, hasIm = m >= imagBegin;
+					const float xr = x0[min(m, realEnd - 1)], xi = x1[max(m, imagBegin)];
+					if (hasRe) r = make_float2(xr*w.x, xr*w.y);
+					const float2 withIm = make_float2(fmaf(xi, w.z, r.x), fmaf(xi, w.w, r.y));
+					if (hasIm) r = withIm;
+				}
 				return r;
 			},
 			[](int, int) { return 0; },
@@ -2305,7 +2337,7 @@ __device__ __forceinline__ void vocoderProduceStaged(const DevBatch &d, int s, i
 		float f[NCH*4];
 #pragma unroll
 		for (int j = 0; j < NCH*4; ++j) f[j] = 0.0f;
-		if (row < nh && b >= 0 && b < M && d.debugMode != 1) {
+		if (row < nh && b >= 0 && b < M && !SMST_SKIP_PRODUCER_MATH(d)) {
 			// same arithmetic as computeRecord<CH, true, false, false>, operands from the staged windows
 			auto IN = [&](int c, int x) { return mine[c*2*G::PIN + (x - b0 + 2*L)]; };
 			auto lerpIN = [&](int c, LerpIndex li) {
@@ -2805,7 +2837,7 @@ __global__ __launch_bounds__(64*kVocWaves) __attribute__((amdgpu_waves_per_eu(4,
 			float f[NCH*4];
 #pragma unroll
 			for (int j = 0; j < NCH*4; ++j) f[j] = 0.0f;
-			if (row < nh && b >= 0 && b < M && d.debugMode != 1) {
+			if (row < nh && b >= 0 && b < M && !SMST_SKIP_PRODUCER_MATH(d)) {
 				if constexpr (ACROSS) {
 					if (hopsLds[row].flags & HOP_ACTIVE) computeRecord<CH, PLAIN, false, false, NCH*4, ROTL, true>(d, hopsLds[row], hopsLds[row], s + row, sg + row, 0, b, f, rotLds);
 				} else {
@@ -2856,7 +2888,7 @@ __global__ __launch_bounds__(64*kVocWaves) __attribute__((amdgpu_waves_per_eu(4,
 		for (int j = 0; j < NCH; ++j) q[0][j] = blockRecs[j*64 + k];
 #pragma unroll
 		for (int i = 0; i < BS; ++i) {
-			if (d.debugMode == 2) break; // experiment: consumer only acknowledges blocks
+			if (SMST_CONSUMER_ONLY_ACKNOWLEDGES(d)) break; // experiment builds only
 			if (i + 1 < BS) {
 #pragma unroll
 				for (int j = 0; j < NCH; ++j) q[(i + 1) & 1][j] = blockRecs[((i + 1)*NCH + j)*64 + ((k + (i + 1)) & 63)];
@@ -3010,7 +3042,7 @@ __global__ __launch_bounds__(64*kVocWaves) __attribute__((amdgpu_waves_per_eu(4,
 			float f[NCH*4];
 #pragma unroll
 			for (int j = 0; j < NCH*4; ++j) f[j] = 0.0f;
-			if (row < nh && b >= 0 && b < M && d.debugMode != 1) computeRecord<CH, PLAIN, false, false>(d, hopsLds[row], hopsLds[row > 0 ? row - 1 : 0], s, sg, row, b, f);
+			if (row < nh && b >= 0 && b < M && !SMST_SKIP_PRODUCER_MATH(d)) computeRecord<CH, PLAIN, false, false>(d, hopsLds[row], hopsLds[row > 0 ? row - 1 : 0], s, sg, row, b, f);
 			// The records depend on feed-forward data only, so a pass is COMPUTED as soon as its wave is free and waits for its
 			// slot just before it is stored.  With the wait in front (first version) one block was in production at a time: a
 			// pass is two dependent rounds of gathers, 7 + 15 thousand cycles on a full tile (cycle trace), the 2-block ring let
@@ -3062,7 +3094,7 @@ __global__ __launch_bounds__(64*kVocWaves) __attribute__((amdgpu_waves_per_eu(4,
 			const float4 *blockRecs = recs + (size_t)slot*BS*NCH*64;
 #pragma unroll
 			for (int i = 0; i < BS; ++i) {
-				if (d.debugMode == 2) break; // experiment: consumer only acknowledges blocks
+				if (SMST_CONSUMER_ONLY_ACKNOWLEDGES(d)) break; // experiment builds only
 				const int t = tb + blk*BS + i;
 				float f[NCH*4];
 #pragma unroll
@@ -3597,8 +3629,14 @@ void launchAnalyse(const DevBatch &d, const IoArgs &io, int sBase, int nStreams,
 		const int jobs = tileHops*d.C*2*nStreams;
 		const int wgs = std::max(8, std::min((jobs + 2)/3/8*8, d.teamsGrid)); // one workgroup per CU, a multiple of 8 (one residue class of the job order per XCD)
 		const size_t lds = ((size_t)d.M + d.M/2 + d.M/32)*sizeof(float4) + 3*fastLds + 64; // window, first- and second-stage twiddles, a buffer per team, barrier words
-		if (d.M == 256*10) hipLaunchKernelGGL((kAnalyseTeams<10, 3>), dim3(wgs), dim3(768), lds, st, d, io, d.hops, sBase, hopBase, tileHops, nStreams);
-		else hipLaunchKernelGGL((kAnalyseTeams<12, 3>), dim3(wgs), dim3(768), lds, st, d, io, d.hops, sBase, hopBase, tileHops, nStreams);
+		const bool slots = slotAlignedWindow(d.B, d.M);
+		if (d.M == 256*10) {
+			if (slots) hipLaunchKernelGGL((kAnalyseTeams<10, 3, true>), dim3(wgs), dim3(768), lds, st, d, io, d.hops, sBase, hopBase, tileHops, nStreams);
+			else hipLaunchKernelGGL((kAnalyseTeams<10, 3, false>), dim3(wgs), dim3(768), lds, st, d, io, d.hops, sBase, hopBase, tileHops, nStreams);
+		} else {
+			if (slots) hipLaunchKernelGGL((kAnalyseTeams<12, 3, true>), dim3(wgs), dim3(768), lds, st, d, io, d.hops, sBase, hopBase, tileHops, nStreams);
+			else hipLaunchKernelGGL((kAnalyseTeams<12, 3, false>), dim3(wgs), dim3(768), lds, st, d, io, d.hops, sBase, hopBase, tileHops, nStreams);
+		}
 		countLaunch(LK_ANALYSE_TEAMS);
 		if (!anyLate) return;
 	}

@@ -649,6 +649,44 @@ def _flip_margin(batch, stream, r):
     return float(np.min(np.abs(en[cand] - sm[cand])/np.maximum(sm[cand], 1e-30)))
 
 
+def _argmax_tie(batch, stream, r):
+    """The other discrete decision of a hop: the maximum-energy channel of a bin (stretch.h:729-737, first maximum wins).  Where the
+    product's arg-max channel differs from the checker's, returns (bin, relative gap between the checker's two largest channel
+    energies, the product's own relative deviation of those two energies) of the CLOSEST such call, else None.  A differing bin
+    whose gap is within reach of the product's measured energy deviation is an explained flip: the phase of that bin follows another
+    channel's twist, and the bins above it inherit the difference through the b-1 / b-L taps (found on the 8-channel noise stream
+    of config 5: bin 2047 decided by 4e-5 between channels 2 and 3, tools/diag/diag_config5_bins.py)."""
+    e_r, e_p = np.asarray(r.bands_real(4), np.float64), np.asarray(batch.debug_state(stream, 3), np.float64)
+    if e_r.shape[0] < 2:
+        return None
+    diff = np.nonzero(np.argmax(e_r, axis=0) != np.argmax(e_p, axis=0))[0]
+    best = None
+    for bn in diff:
+        order = np.argsort(e_r[:, bn])
+        c1, c2 = order[-1], order[-2]
+        top = max(e_r[c1, bn], 1e-300)
+        gap = (e_r[c1, bn] - e_r[c2, bn])/top
+        dev = max(abs(e_p[c1, bn] - e_r[c1, bn]), abs(e_p[c2, bn] - e_r[c2, bn]))/top
+        if best is None or gap < best[1]:
+            best = (int(bn), float(gap), float(dev))
+    return best
+
+
+def _argmax_tie_checker(twin, r):
+    """_argmax_tie between the perturbed-input checker and the checker (the same near-ties flip there too)."""
+    class _AsBatch:
+        def debug_state(self, stream, which):
+            return twin.bands_real(4)
+    return _argmax_tie(_AsBatch(), 0, r)
+
+
+ARGMAX_REACH = 4.0  # an arg-max call decided by less than this multiple of the product's own energy deviation at that bin (floor 1e-6) is a near-tie
+
+
+def _explained_argmax(tie):
+    return tie is not None and tie[1] <= ARGMAX_REACH*max(tie[2], 1e-6)
+
+
 def _hop_io(interval, stretch, k):
     """Input range consumed by hop-aligned call number k (each call emits exactly one interval)."""
     lo = int(round(k*interval/stretch))
@@ -697,7 +735,7 @@ def case_teacher_forced(lib, ref, cfg, channels, stretch, label, setup=None, war
     xs = np.stack([synth_input(s, channels, n_in, sr) for s in streams])
     xp = np.stack([perturbed(x, 1 + i) for i, x in enumerate(xs)])
     worst = dict(spectrum=0.0, spectrum_self=0.0, spectrum_trimmed=0.0, samples=0.0, samples_self=0.0, analysis=0.0, analysis_self=0.0,
-                 ring=0.0, ring_self=0.0)
+                 ring=0.0, ring_self=0.0, spectrum_unflipped=0.0, spectrum_self_unflipped=0.0, ring_unflipped=0.0, ring_self_unflipped=0.0, argmax_ties=0)
     per = [[] for _ in streams]
     rings = [[] for _ in streams]
     for k in range(total_hops):
@@ -725,8 +763,18 @@ def case_teacher_forced(lib, ref, cfg, channels, stretch, label, setup=None, war
                 for key, v in (("samples", e_samp), ("samples_self", s_samp), ("spectrum", e_spec), ("spectrum_self", s_spec),
                                ("spectrum_trimmed", e_trim), ("analysis", e_ana), ("analysis_self", s_ana), ("ring", e_ring), ("ring_self", s_ring)):
                     worst[key] = max(worst[key], v)
-                rings[i].append((e_ring, s_ring))
+                # hops in which the product or the perturbed checker called a bin's maximum channel differently by a near-tie are
+                # flips of a discrete decision (like the peak-run boundaries below): kept out of the smooth bounds, counted
+                tie_p, tie_t = _argmax_tie(b, i, r), _argmax_tie_checker(twins[i], r)
+                tied = _explained_argmax(tie_p) or _explained_argmax(tie_t)
+                worst["argmax_ties"] += int(tied)
+                if not tied:
+                    for key, v in (("spectrum_unflipped", e_spec), ("spectrum_self_unflipped", s_spec), ("ring_unflipped", e_ring), ("ring_self_unflipped", s_ring)):
+                        worst[key] = max(worst[key], v)
+                rings[i].append((e_ring, s_ring, float(tied)))
                 margin = _flip_margin(b, i, r) if (e_samp > max(TOL_FORCED_SAMPLES, SELF_FACTOR*s_samp) or e_spec > max(TOL_FORCED_SPECTRUM, SELF_FACTOR*s_spec)) else None
+                if margin is None and tied:
+                    margin = 0.0  # explained by the arg-max near-tie
                 per[i].append((e_samp, s_samp, e_spec, s_spec, -1.0 if margin is None else margin))
     b.close()
     # per stream, worst forced hop against SELF_FACTOR x the checker's worst one-hop sensitivity (a flipped peak decision is
@@ -746,10 +794,11 @@ def case_teacher_forced(lib, ref, cfg, channels, stretch, label, setup=None, war
         tol_samp, tol_spec = max(TOL_FORCED_SAMPLES, SELF_FACTOR*a[:, 1].max()), max(TOL_FORCED_SPECTRUM, SELF_FACTOR*a[:, 3].max())
         assert a[:, 0].max() <= tol_samp, "%s: stream %d: emitted samples rel-RMS %.3e > %.1e (checker's one-hop sensitivity %.1e)" % (label, streams[i], a[:, 0].max(), tol_samp, a[:, 1].max())
         assert a[:, 2].max() <= tol_spec, "%s: stream %d: Band.output rel-RMS %.3e > %.1e (checker's one-hop sensitivity %.1e)" % (label, streams[i], a[:, 2].max(), tol_spec, a[:, 3].max())
-    assert flips <= max(1, (S*forced_hops)//8), (label, "too many flipped decisions", flips)
+    assert flips <= max(1, (S*forced_hops)//8) + worst["argmax_ties"], (label, "too many flipped decisions", flips)
     worst["flips"] = flips
     for i in range(S):  # the synthesised frame (overlap-add ring after the hop): same rule as the emitted samples
         a = np.array(rings[i])
+        a = a[a[:, 2] == 0] if np.any(a[:, 2] == 0) else a  # hops without an arg-max near-tie
         assert np.median(a[:, 0]) <= max(TOL_FORCED_SAMPLES, SELF_FACTOR*np.median(a[:, 1])), (label, streams[i], "median ring", np.median(a[:, 0]), np.median(a[:, 1]))
         assert a[:, 0].max() <= max(TOL_FORCED_SAMPLES, SELF_FACTOR*a[:, 1].max()) or flips > 0, (label, streams[i], "ring", a[:, 0].max(), a[:, 1].max())
         assert a[:, 0].max() > 0, (label, streams[i], "the ring comparison is empty")
@@ -757,7 +806,7 @@ def case_teacher_forced(lib, ref, cfg, channels, stretch, label, setup=None, war
 
 
 def case_hop_magnitudes(lib, ref, cfg, channels, stretch, label, setup=None, hops=40, streams=(2, 5), tol=TOL_MAGNITUDE,
-                        min_argmax_agreement=0.999, min_map_agreement=0.98):
+                        min_argmax_agreement=0.999, min_map_agreement=0.98, semitones=None):
     """D.2 (iv) + (v), free-running (no state injection): after every hop compare the phase-free quantities, which stay
     comparable after the phases have decorrelated (noise streams): |Band.output| per bin (= sqrt(Prediction.energy) by
     stretch.h:596-603), the arg-max channel per bin derived from Prediction.energy (:729-737), and -- with a frequency
@@ -775,20 +824,44 @@ def case_hop_magnitudes(lib, ref, cfg, channels, stretch, label, setup=None, hop
     kw = dict(preset=cfg["preset"], sample_rate=cfg.get("sample_rate", 48000.0)) if cfg.get("preset") in ("default", "cheaper") else \
         dict(block=cfg["block"], interval=cfg["interval"], split=cfg.get("split", False))
     b = pkg.StretchBatch(S, channels, lib=lib, **kw)
-    refs = [make("ref", lib, ref, channels, cfg, setup, seed=i) for i, _ in enumerate(streams)]  # stream i of a batch = the instance seeded seed + i
-    twins = [make("ref", lib, ref, channels, cfg, setup, seed=i) for i, _ in enumerate(streams)] if setup else None
+    # `stretch` may be one factor or one per stream, `semitones` (optional) one transposition per stream: BASELINE config 5 names
+    # "per-stream random stretch 0.75-1.5x and +-12 st"
+    per_stream = semitones is not None or not np.isscalar(stretch)
+    stretches = [float(stretch)]*S if np.isscalar(stretch) else [float(v) for v in stretch]
+
+    def setup_of(i):
+        def f(o):
+            if setup:
+                setup(o)
+            if semitones is not None:
+                o.setTransposeSemitones(float(semitones[i]), 0.0)
+        return f if (setup or semitones is not None) else None
+    refs = [make("ref", lib, ref, channels, cfg, setup_of(i), seed=i) for i, _ in enumerate(streams)]  # stream i of a batch = the instance seeded seed + i
+    twins = [make("ref", lib, ref, channels, cfg, setup_of(i), seed=i) for i, _ in enumerate(streams)] if (setup or semitones is not None) else None
     if setup:
         setup(b)
+    if semitones is not None:
+        for i in range(S):
+            b.setTransposeSemitones(float(semitones[i]), 0.0, stream=i)
     I = b.intervalSamples()
-    n_in = _hop_io(I, stretch, hops)[1] + 8
+    n_in = max(_hop_io(I, v, hops)[1] for v in stretches) + 8
     xs = np.stack([synth_input(s, channels, n_in, sr) for s in streams])
     xp = np.stack([perturbed(x, 1 + i) for i, x in enumerate(xs)])
     agree, cells, map_ok, map_cells, flips = 0, 0, 0, 0, 0
     errs, owns = np.zeros((S, hops)), np.zeros((S, hops))
     for k in range(hops):
-        lo, hi = _hop_io(I, stretch, k)
-        b.process(xs[:, :, lo:hi] if hi > lo else np.zeros((S, channels, 1), np.float32), I, in_samples=hi - lo)
+        spans = [_hop_io(I, v, k) for v in stretches]
+        if per_stream:  # every stream its own input span of this hop, one batched call (ragged input lengths)
+            width = max(1, max(hi_ - lo_ for lo_, hi_ in spans))
+            chunk = np.zeros((S, channels, width), np.float32)
+            for i, (lo_, hi_) in enumerate(spans):
+                chunk[i, :, :hi_ - lo_] = xs[i][:, lo_:hi_]
+            b.process(chunk, I, in_samples=np.array([hi_ - lo_ for lo_, hi_ in spans], np.int32))
+        else:
+            lo, hi = spans[0]
+            b.process(xs[:, :, lo:hi] if hi > lo else np.zeros((S, channels, 1), np.float32), I, in_samples=hi - lo)
         for i, r in enumerate(refs):
+            lo, hi = spans[i]
             r.process(xs[i][:, lo:hi], I)
             mo, mr = np.abs(b.debug_state(i, 2)), np.abs(r.bands_complex(2))
             if twins:

@@ -166,3 +166,12 @@ def test_random_time_factor_parity_emu(emu, ref):
 
 def test_fft_teams_equals_per_frame_emu(emu, monkeypatch):
     pc.case_fft_teams_equals_per_frame(emu, monkeypatch, presets=(("cheaper", 48000),), seconds=0.45, streams=3)
+    # 44.1 kHz: the window's halves do not end on element-slot boundaries (kAnalyseTeams<..., SLOTS = false>)
+    pc.case_fft_teams_equals_per_frame(emu, monkeypatch, presets=(("default", 44100),), seconds=0.4, streams=2)
+
+
+def test_hop_magnitudes_per_stream_parameters_small(emu, ref):
+    """The per-stream form of the phase-free instrument (every stream its own stretch factor and transposition, ragged input spans in
+    one batched call) at the small geometry, 3 channels, split mode -- the GPU suite runs it on BASELINE config 5 as named."""
+    print(pc.case_hop_magnitudes(emu, ref, pc.SMALL_SPLIT, 3, [0.8, 1.0, 1.37], "magnitudes per stream", hops=30, streams=(0, 1, 2), tol=2e-4,
+                                 semitones=[-7.0, 3.5, 11.0]))

@@ -163,7 +163,7 @@ def test_full_batch_identity_and_determinism(hip):
     chunked = torch.cat(parts, dim=2)
     # bit-identical: the library is built with -ffp-contract=on, so a (hop, bin) cell rounds the same way whichever
     # code path produces it (with the default contraction the first hop after a chunk boundary differed by 1 ulp, which the
-    # recurrence amplified to 2e-4 over these 25 hops -- tests/diag_stage.py)
+    # recurrence amplified to 2e-4 over these 25 hops -- tools/diag/diag_stage.py)
     assert torch.equal(whole, chunked), float((whole - chunked).abs().max())
     b.close()
     # batch == single
@@ -414,6 +414,9 @@ def test_teacher_forced(hip, ref, label, cfg, C, stretch, setup):
     # under formant compensation: 5 x that bounds nothing): Band.output without the 1 % of bins with the largest error, against
     # the caps of SURVEY App. D.2 iii -- 5e-3 stretch / pitch only, 5e-2 with formant processing
     assert w["spectrum_trimmed"] <= (pc.CAP_FORMANT if label == "config4b" else pc.CAP_TONAL), w
+    # ... and on the UNTRIMMED distance of every hop in which no discrete decision flipped (no arg-max channel near-tie, no peak-run
+    # near-tie): the same ceilings, fixed -- not a multiple of the checker's own sensitivity
+    assert w["spectrum_unflipped"] <= (pc.CAP_FORMANT if label == "config4b" else pc.CAP_TONAL) or w["flips"] > w["argmax_ties"], w
     assert w["ring"] > 0 and (w["ring"] <= max(pc.TOL_FORCED_SAMPLES, pc.SELF_FACTOR*w["ring_self"]) or w["flips"] > 0), w
     assert w["equivalent_perturbation"] <= pc.PERTURBATION, w
     assert w["equivalent_perturbation"] >= pc.PERTURBATION/8, w  # ... and PERTURBATION is not much larger than it needs to be
@@ -462,6 +465,17 @@ def test_hop_decisions(hip, ref):
     _report("hop_decisions/config4b", r)
     r = pc.case_hop_magnitudes(hip, ref, CHEAPER96, 8, 1.2, "decisions 8ch", setup=lambda o: o.setTransposeSemitones(-5, 0), hops=40, streams=(0, 2))
     _report("hop_decisions/config5-8ch", r)
+
+
+def test_hop_decisions_config5_as_named(hip, ref):
+    """BASELINE config 5 as it names itself: 8-channel streams at 96 kHz, presetCheaper (split computation), PER-STREAM random stretch
+    0.75-1.5x and +-12 st drawn as bench.py --config 5 draws them (PCG64(5)), six streams (two of every signal type) x 2 s: per-hop
+    |output|, arg-max channel and output map, free running."""
+    g = np.random.Generator(np.random.PCG64(5))
+    stretches, semis = g.uniform(0.75, 1.5, 8192)[:6], g.uniform(-12, 12, 8192)[:6]
+    hops = int(2.0*96000*float(stretches.min())/3840)  # 2 s of input at the smallest stretch factor (interval 3840)
+    r = pc.case_hop_magnitudes(hip, ref, CHEAPER96, 8, stretches, "decisions config5 as named", hops=hops, streams=tuple(range(6)), tol=2e-4, semitones=semis)
+    _report("hop_decisions/config5-as-named-6x2s", r)
 
 
 def test_process_does_not_allocate_in_steady_state_gpu(hip):
@@ -588,5 +602,5 @@ def test_random_time_factor_parity(hip, ref):
 
 def test_fft_teams_equals_per_frame(hip, monkeypatch):
     """kAnalyseTeams (SMST_FFT_TEAMS=1) against kAnalyseFast: bit-identical."""
-    pc.case_fft_teams_equals_per_frame(hip, monkeypatch, presets=(("cheaper", 48000), ("default", 48000)), streams=5)
+    pc.case_fft_teams_equals_per_frame(hip, monkeypatch, presets=(("cheaper", 48000), ("default", 48000), ("default", 44100)), streams=5)
     pc.case_fft_teams_equals_per_frame(hip, monkeypatch, presets=(("default", 48000),), streams=2, channels=1)

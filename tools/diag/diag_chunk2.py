@@ -1,7 +1,7 @@
 """Diagnostic (not a test): which carried state differs between one call and hop-aligned chunked calls, hop by hop."""
 import importlib, os, sys
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from conftest import synth_input
 import torch

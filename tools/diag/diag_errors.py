@@ -1,5 +1,5 @@
 """Diagnostic (not a test): per-hop rel-RMS of the product vs the checker for the chaotic cases, next to the
-checker's own sensitivity to a 1e-7 relative input perturbation.  usage: python tests/diag_errors.py [emu|hip]"""
+checker's own sensitivity to a 1e-7 relative input perturbation.  usage: python tools/diag/diag_errors.py [emu|hip]"""
 import ctypes
 import importlib
 import os
@@ -7,7 +7,7 @@ import sys
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle")); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from conftest import synth_input, rel_rms  # noqa: E402
 import ref_oracle  # noqa: E402

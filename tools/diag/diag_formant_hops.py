@@ -1,12 +1,13 @@
 """Diagnostic (GPU box): per-hop |output| distance product-vs-checker next to the checker's own response to a 1e-6 input
-perturbation, config 4b (pitch map + formants), free-running.  python tests/diag_formant_hops.py [hops]"""
+perturbation, config 4b (pitch map + formants), free-running.  python tools/diag/diag_formant_hops.py [hops]"""
 import json
 import os
 import sys
 
 import numpy as np
 
-sys.path[:0] = [os.path.dirname(os.path.abspath(__file__)), os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle")]
+_ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path[:0] = [os.path.join(_ROOT, "tests"), os.path.join(_ROOT, "oracle")]
 import conftest  # noqa: E402
 import parity_cases as pc  # noqa: E402
 import ref_oracle  # noqa: E402
@@ -81,7 +82,7 @@ def main():
         for r in rs:
             if r["err"] > 5*max(r["own"]) and r["err"] > 1e-4:
                 print("   hop %d err %.2e own %s map diff %.3g (own %.3g) peaks %d" % (r["hop"], r["err"], ["%.1e" % v for v in r["own"]], r["map_maxdiff"], r["map_maxdiff_own"], r["npeaks"]))
-    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "diag_formant_hops.json")
+    out = os.path.join(_ROOT, "gpurun_out", "diag_formant_hops.json")
     os.makedirs(os.path.dirname(out), exist_ok=True)
     json.dump(rows, open(out, "w"))
 

@@ -1,7 +1,7 @@
 """Diagnostic (not a test): staged vs gathered producers of the fused kernel, one call and two calls."""
 import importlib, os, sys, subprocess
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 if len(sys.argv) > 1:
     from conftest import synth_input

@@ -15,7 +15,7 @@ cp gpurun_out/parity_instruments.jsonl $OUT/ 2>/dev/null
 timeout 400 python bench.py > $OUT/bench_line.json 2> $OUT/bench_line.err
 for c in 3 4b 5; do timeout 400 python bench.py --config $c --steps 5 --warmup 2 --no-cpu-baseline > $OUT/bench_config$c.json 2> $OUT/bench_config$c.err; done
 timeout 400 python bench.py --config 5 --half-state --steps 5 --warmup 2 --no-cpu-baseline > $OUT/bench_config5_fp16.json 2> $OUT/bench_config5_fp16.err
-bash tests/prof_counters.sh $TAG/prof > $OUT/prof.log 2>&1
+bash tools/prof/prof_counters.sh $TAG/prof > $OUT/prof.log 2>&1
 cd $ROOT
 timeout 300 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-serial-pass > $OUT/bench_line_as_profiled.json 2> /dev/null
 timeout 400 python tools/bench_sweep.py > $OUT/stream_sweep.json 2> $OUT/stream_sweep.err

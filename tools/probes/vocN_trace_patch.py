@@ -1,5 +1,9 @@
-"""Instrumentation for tools/probes/vocN_trace.py (kVocoderN, 8 channels): apply to a COPY of the sources, build, restore."""
-p='/root/repo/signalsmith-stretch_amd/csrc/smst_kernels.hip'
+"""Instrumentation for tools/probes/vocN_trace.py (kVocoderN, 8 channels).  ONLY through tools/probes/build_variant.sh, which hands it a
+COPY of csrc/ (round 4: run with its old hard-coded default it patched the product sources in place)."""
+import sys
+SRC = sys.argv[1]  # required: a copy of csrc/
+assert "/tmp/" in SRC or "variant" in SRC, "refusing to patch anything but a temporary copy of the sources"
+p = SRC + '/smst_kernels.hip'
 s=open(p).read()
 anchor="// ------------------------------------------------------------------------------------------------------\n// K2b-e: channel-summed energy"
 assert anchor in s
@@ -78,7 +82,7 @@ rep("""	f[0] = A.x; f[1] = A.y; f[2] = B.x; f[3] = B.y; f[4] = Cc.x; f[5] = Cc.y
 	f[8] = __int_as_float(mc);""")
 
 open(p,'w').write(s)
-p='/root/repo/signalsmith-stretch_amd/csrc/smst_engine.cpp'
+p = SRC + '/smst_engine.cpp'
 s=open(p).read()
 o="void Batch::debugGetState(int stream, int which, float *dst) {\n	SMST_HIP(hipSetDevice(dev));\n	SMST_HIP(hipStreamSynchronize(st));"
 assert o in s

@@ -1,6 +1,7 @@
 """Applies the timestamp instrumentation that tools/probes/voc_trace.py reads to a COPY of the kernel / engine sources:\n    cp csrc/smst_kernels.hip csrc/smst_engine.cpp /tmp/keep/ ; python tools/probes/voc_trace_patch.py ; hipcc ... -o variants/trace.so ; restore the sources.\nThe product sources never contain it."""
 import sys
-SRC = sys.argv[1] if len(sys.argv) > 1 else '/root/repo/signalsmith-stretch_amd/csrc'  # a COPY of csrc/ (tools/probes/build_variant.sh makes one)
+SRC = sys.argv[1]  # required: a COPY of csrc/ (tools/probes/build_variant.sh makes one)
+assert '/tmp/' in SRC or 'variant' in SRC, 'refusing to patch anything but a temporary copy of the sources'
 p=SRC + '/smst_kernels.hip'
 s=open(p).read()
 anchor="// Staged producers (PLAIN tiles without random time factors, L <= 5)."
