@@ -25,6 +25,7 @@ struct DevBatch {
 	int fftTeams;                 // analysis / synthesis by persistent workgroups of three free-running teams, tables in LDS (default; SMST_FFT_TEAMS=0: one frame per workgroup; =2: teams even for tiles with few frames per team -- tests)
 	int teamsGrid;                // their grid: one workgroup per CU, a multiple of 8
 	int noStage;                  // SMST_NO_STAGE: producers of the fused kernel gather from HBM even where staging applies
+	int alignAll;                 // SMST_ALIGN_ALL: the line-aligned producers for every geometry they are valid for (default: L = 4 only)
 	int noAlign;                  // SMST_NO_ALIGN: staged producers with per-row windows and lag L+1 (round 3) instead of the line-aligned form
 	FftPlan plan;
 	// constant tables
@@ -76,6 +77,29 @@ struct IoArgs {
 	const int *inSamples;  // [S] device
 	const int *outSamples; // [S] device
 };
+
+// The packed input of a frame: element m = (x[base + halfB + m] w[halfB + m], x[base + halfB - M + m] w[halfB - M + m]), the real part
+// present for m < B - halfB, the imaginary part for m >= M - halfB.  At 48 / 96 kHz (block = 15/16 of the FFT size) those edges are
+// element-slot boundaries: slot 0 has no imaginary part, slot 15 no real part, and kAnalyseTeams fetches exactly the window.  Other
+// block sizes (44.1 kHz: 5292 of 6144) end inside a slot; the team kernel then still fetches WHOLE slots 0..14 / 1..15 -- up to
+// `windowPad` samples on either side of the window, which the table's zero weights cancel -- so a frame is its to take only if
+// that wider span lies in this call's input too.  (First form: one compare + select per element and half: analysis 4.4 -> 6.8 ms per
+// step at 44.1 kHz, slower than the per-frame kernel it was to replace.)
+struct WindowPad { int lo, hi; };
+__host__ __device__ inline WindowPad windowPad(int B, int M) {
+	const int halfB = B/2, MA = M/16;
+	WindowPad p;
+	p.lo = (M - halfB) - MA;          // samples in front of the window that slot 1's imaginary parts reach
+	p.hi = 15*MA - (B - halfB);       // samples behind it that slot 14's real parts reach
+	return p;
+}
+// The frames that kAnalyseTeams takes (the others reach into the carried history, or too close to the end of the input, and go to the
+// per-frame kernel's bounds-checked path).  The host evaluates the same condition (smst_engine.cpp).
+__host__ __device__ inline bool analysisWindowInCall(int B, int M, int I, int inputOffset, int which, int inSamples) {
+	const WindowPad p = windowPad(B, M);
+	const int end = inputOffset - (which ? I : 0);
+	return p.lo >= 0 && p.hi >= 0 && end - B - p.lo >= 0 && end + p.hi <= inSamples;
+}
 
 // Which kernel variant a launcher chose, counted per process (test hook: smst_debug_launch_count).  "Bit-identical to the other
 // form" tests assert through these that BOTH forms really ran.

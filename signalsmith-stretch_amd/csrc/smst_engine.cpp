@@ -138,9 +138,6 @@ void Batch::construct(const FftPlan &plan, long seed) {
 		SMST_HIP(hipStreamCreateWithPriority(&stChain, hipStreamNonBlocking, hi));
 	}
 	SMST_HIP(hipStreamCreateWithFlags(&stSynth, hipStreamNonBlocking));
-	SMST_HIP(hipStreamCreateWithFlags(&stEmit, hipStreamNonBlocking));
-	for (int i = 0; i < 3; ++i) SMST_HIP(hipEventCreateWithFlags(&evEmit[i], hipEventDisableTiming));
-	deferEmit = std::getenv("SMST_EMIT_DEFER") != nullptr;
 	SMST_HIP(hipStreamCreateWithFlags(&stGate, hipStreamNonBlocking));
 	for (int i = 0; i < 2; ++i) {
 		SMST_HIP(hipEventCreateWithFlags(&callSets[i].done, hipEventDisableTiming));
@@ -179,6 +176,7 @@ void Batch::construct(const FftPlan &plan, long seed) {
 	if (const char *env = std::getenv("SMST_NO_FEED_FUSION")) d.noFeedFusion = atoi(env);
 	d.noStage = std::getenv("SMST_NO_STAGE") != nullptr;
 	d.noAlign = std::getenv("SMST_NO_ALIGN") != nullptr;
+	d.alignAll = std::getenv("SMST_ALIGN_ALL") != nullptr;
 	d.noFastFft = std::getenv("SMST_NO_FAST_FFT") != nullptr;
 	// lean FFT tables (8-byte window entries + generated modulation, six stage twiddles instead of fifteen) are OPT-IN: they take 0.2 ms
 	// off a 16.3-ms step, and their one extra rounding per element (spectra 1.2e-7 away from the full tables') flipped a peak decision
@@ -380,7 +378,6 @@ void Batch::releaseAll() {
 	if (st) hipStreamSynchronize(st);
 	if (stChain) hipStreamSynchronize(stChain);
 	if (stSynth) hipStreamSynchronize(stSynth);
-	if (stEmit) hipStreamSynchronize(stEmit);
 	if (stGate) hipStreamSynchronize(stGate);
 	for (auto &e : livePool) { hipEventDestroy(e.first); hipEventDestroy(e.second); }
 	livePool.clear();
@@ -405,9 +402,6 @@ void Batch::releaseAll() {
 	}
 	if (stGate) hipStreamDestroy(stGate);
 	if (stChain) hipStreamDestroy(stChain);
-	for (int i = 0; i < 3; ++i) { if (evEmit[i]) hipEventDestroy(evEmit[i]); evEmit[i] = nullptr; }
-	if (stEmit) hipStreamDestroy(stEmit);
-	stEmit = nullptr;
 	if (stSynth) hipStreamDestroy(stSynth);
 	if (st) hipStreamDestroy(st);
 	st = stChain = stSynth = stGate = nullptr;
@@ -434,7 +428,7 @@ void Batch::allocateWorkspace() {
 	d.recSteps = ((M + d.lag*(d.T - 1) + 63)/64)*64 + 8;
 	d.recPitch = int(recChunks*64 + 16);
 	d.Mp = (M + 32 + 15) & ~15; // rows start on 128-byte lines (the recurrence's writer stores aligned 64-byte groups)
-	const size_t perStream = (size_t)d.T*((size_t)C*((size_t)d.Mp*(3*sizeof(float2) + sizeof(PredEntry)) + (size_t)B*sizeof(float)*3/2) // (frames: three buffers for the two workspaces)
+	const size_t perStream = (size_t)d.T*((size_t)C*((size_t)d.Mp*(3*sizeof(float2) + sizeof(PredEntry)) + (size_t)B*sizeof(float))
 	                                      + (size_t)M*(sizeof(float2) + sizeof(float)) + 3*sizeof(float))
 	                         + (size_t)C*64*sizeof(float2)
 	                         + (needRecords ? (size_t)d.recSteps*d.recPitch*sizeof(float4) : 0)
@@ -469,10 +463,8 @@ void Batch::allocateWorkspace() {
 				}
 				w.est = devAlloc<float>((size_t)subS*d.T*2);
 				w.freqEst = devAlloc<float>((size_t)subS*d.T);
+				w.frames = devAlloc<float>((size_t)subS*d.T*C*B);
 			}
-			for (int i = 0; i < 3; ++i) framesRing[i] = devAlloc<float>((size_t)subS*d.T*C*B);
-			slots[0].frames = framesRing[0];
-			slots[1].frames = framesRing[1];
 			break;
 		} catch (const Error &) {
 			while (allocations.size() > mark) { hipFree(allocations.back()); allocations.pop_back(); }
@@ -868,7 +860,7 @@ void Batch::process(const float *in, long long inSS, long long inCS, const int *
 				if (f & HOP_NEW_SPECTRUM) {
 					lastNewLocal = h - h0; th[3] = 1;
 					// analysis frames whose window lies in this call's input ([5], taken by kAnalyseTeams) / reaches into the history ([6])
-					for (int which = 0; which < ((f & HOP_REANALYSE_PREV) ? 2 : 1); ++which) th[(list[h].inputOffset - (which ? d.I : 0) - d.B >= 0) ? 5 : 6] = 1;
+					for (int which = 0; which < ((f & HOP_REANALYSE_PREV) ? 2 : 1); ++which) th[analysisWindowInCall(d.B, d.M, d.I, list[h].inputOffset, which, nIn[s]) ? 5 : 6] = 1;
 				}
 				th[0] = 1;
 				if (f & HOP_MAPPED) th[1] = 1;
@@ -906,29 +898,12 @@ void Batch::process(const float *in, long long inSS, long long inCS, const int *
 	// kernels of the next tile fill the machine while the recurrence of the current one is in flight.
 	const bool serial = profiling || !overlap;
 	const bool singleHop = singleHopSupported(d) && !noSingleHop;
-	hipStream_t sF = st, sC = serial ? st : stChain, sS = serial ? st : stSynth, sE = serial ? st : stEmit;
+	hipStream_t sF = st, sC = serial ? st : stChain, sS = serial ? st : stSynth;
 	if (!serial) {
 		SMST_HIP(hipEventRecord(evStart, st));
 		SMST_HIP(hipStreamWaitEvent(sC, evStart, 0));
 		SMST_HIP(hipStreamWaitEvent(sS, evStart, 0));
-		SMST_HIP(hipStreamWaitEvent(sE, evStart, 0));
 	}
-	// The emission of tile q (a gather over its synthesised frames: no LDS, pure memory traffic) follows its synthesis on a stream of its
-	// own and so runs beside the recurrence of tile q+1, which it costs 0.14 ms per launch (0.92 ms in place against 0.78 with nothing
-	// beside it; a timing build without kEmit: -0.8 ms per 10-s step).  The alternative was built and measured: SMST_EMIT_DEFER=1 releases
-	// it only when that recurrence has FINISHED, beside the analysis / synthesis teams of the next tile -- the recurrence then runs at
-	// 0.78 ms, and the step gets 1.4 ms LONGER (15.7 against 14.3): the team kernels are on the critical path too and lose more to it
-	// than the recurrence does.  The frames live in a ring of three buffers so that either order is safe (tile q's frames may still be
-	// read while tile q+2's workspace is being filled); the emissions keep their own stream (each reads the carry its predecessor wrote).
-	struct PendingEmit { bool any = false; DevBatch dd; int sBase = 0, ns = 0, t = 0, span = 0, fslot = 0, synthSlot = 0; } pending;
-	auto releaseEmit = [&](bool behindChain, int chainSlot) {
-		if (!pending.any) return;
-		SMST_HIP(hipStreamWaitEvent(sE, evSynth[pending.synthSlot], 0)); // its frames are written
-		if (behindChain) SMST_HIP(hipStreamWaitEvent(sE, evChain[chainSlot], 0)); // ... and the next tile's recurrence is off the machine
-		timed(timings.emitMs, [&] { launchEmit(pending.dd, io, pending.sBase, pending.ns, pending.t, pending.span, sE); if (profiling) ++timings.emitLaunches; });
-		SMST_HIP(hipEventRecord(evEmit[pending.fslot], sE));
-		pending.any = false;
-	};
 	int q = 0;
 	for (int sub = 0; sub < nSub; ++sub) {
 		const int sBase = sub*subS;
@@ -941,10 +916,9 @@ void Batch::process(const float *in, long long inSS, long long inCS, const int *
 			const bool plain = !(th[1] || th[2]);
 			const bool fused = fusedSupported(d) && !noFuse; // mono/stereo: records stay in LDS (kVocoder)
 			const TileBuffers &w = slots[slot];
-			const int fslot = serial ? slot : q%3;
 			DevBatch dd = d;
 			dd.Xcur = w.Xcur; dd.Xprev = w.Xprev; dd.PE = w.PE; dd.OUT = w.OUT; dd.REC = w.REC; dd.dump = w.dump;
-			dd.map = w.map; dd.ratio = w.ratio; dd.energyT = w.energyT; dd.smoothT = w.smoothT; dd.peaksT = w.peaksT; dd.est = w.est; dd.freqEst = w.freqEst; dd.frames = framesRing[fslot];
+			dd.map = w.map; dd.ratio = w.ratio; dd.energyT = w.energyT; dd.smoothT = w.smoothT; dd.peaksT = w.peaksT; dd.est = w.est; dd.freqEst = w.freqEst; dd.frames = w.frames;
 			dd.carryCur = (carryBase + t) & 1;
 			dd.nHops = dTileInfo + ((size_t)(sub*nTiles + t)*2)*subS;
 			dd.lastNewHop = dd.nHops + subS;
@@ -952,11 +926,7 @@ void Batch::process(const float *in, long long inSS, long long inCS, const int *
 				SMST_HIP(hipStreamWaitEvent(sF, evChain[slot], 0));
 				SMST_HIP(hipStreamWaitEvent(sF, evSynth[slot], 0));
 			}
-			// The feed-forward kernels of tile q start when the recurrence of tile q-1 has FINISHED: mapped tiles need it (pass A reads the
-			// carried state), and for plain tiles it keeps the analysis teams (one 154-KB workgroup per CU, half a millisecond each) from
-			// racing the recurrence's workgroups for the CUs at the moment both become eligible -- the recurrence cannot start on a CU a
-			// team has taken (measured when the emission moved to its own stream and stopped delaying them: recurrence 0.97 -> 1.2 ms in place)
-			if (!serial && q >= 1) SMST_HIP(hipStreamWaitEvent(sF, evChain[slot ^ 1], 0));
+			if (!serial && fused && !plain && q >= 1) SMST_HIP(hipStreamWaitEvent(sF, evChain[slot ^ 1], 0)); // pass A reads the carried state
 			if (th[0]) {
 				if (th[3]) timed(timings.analyseMs, [&] { launchAnalyse(dd, io, sBase, ns, hopBase, tileHops, th[5] != 0, th[6] != 0, sF); if (profiling) ++timings.analyseLaunches; });
 				bool passADone = false;
@@ -1003,27 +973,18 @@ void Batch::process(const float *in, long long inSS, long long inCS, const int *
 			if (!serial) {
 				SMST_HIP(hipEventRecord(evChain[slot], sC));
 				SMST_HIP(hipStreamWaitEvent(sS, evChain[slot], 0));
-				releaseEmit(deferEmit, slot); // the previous tile's emission: behind THIS tile's recurrence
-				if (q >= 3) SMST_HIP(hipStreamWaitEvent(sS, evEmit[fslot], 0)); // the frames buffer was last read by the emission of tile q-3
 			}
 			if (th[0]) timed(timings.synthMs, [&] { launchSynth(dd, sBase, ns, hopBase, tileHops, sS); if (profiling) ++timings.synthLaunches; });
-			if (serial) {
-				timed(timings.emitMs, [&] { launchEmit(dd, io, sBase, ns, t, maxSpanV[(size_t)sub*nTiles + t], sS); if (profiling) ++timings.emitLaunches; });
-			} else {
-				SMST_HIP(hipEventRecord(evSynth[slot], sS));
-				pending.any = true; pending.dd = dd; pending.sBase = sBase; pending.ns = ns; pending.t = t;
-				pending.span = maxSpanV[(size_t)sub*nTiles + t]; pending.fslot = fslot; pending.synthSlot = slot;
-			}
+			timed(timings.emitMs, [&] { launchEmit(dd, io, sBase, ns, t, maxSpanV[(size_t)sub*nTiles + t], sS); if (profiling) ++timings.emitLaunches; });
 			checkLaunch("synthesis / emission");
+			if (!serial) SMST_HIP(hipEventRecord(evSynth[slot], sS));
 		}
 	}
 	if (!serial) { // everything the caller can observe is ordered on `st` again
-		releaseEmit(false, 0); // the last tile's emission: nothing left to wait behind
 		for (int i = 0; i < 2 && i < q; ++i) {
 			SMST_HIP(hipStreamWaitEvent(st, evChain[i], 0));
 			SMST_HIP(hipStreamWaitEvent(st, evSynth[i], 0));
 		}
-		for (int i = 0; i < 3 && i < q; ++i) SMST_HIP(hipStreamWaitEvent(st, evEmit[i], 0));
 	}
 	d.carryCur = (carryBase + nTiles) & 1;
 	timed(timings.otherMs, [&] {

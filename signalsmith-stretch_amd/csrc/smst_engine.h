@@ -105,8 +105,7 @@ private:
 	int dev;
 	hipStream_t st = nullptr;       // feed-forward kernels + everything the caller synchronises on
 	hipStream_t stChain = nullptr;  // the bin recurrence (few waves, latency-bound): overlaps with the bulk kernels
-	hipStream_t stSynth = nullptr;  // synthesis of the previous tile
-	hipStream_t stEmit = nullptr;   // emission (overlap-add gather): released behind the NEXT tile's recurrence, beside the FFT kernels
+	hipStream_t stSynth = nullptr;  // synthesis + emission of the previous tile
 	hipStream_t stGate = nullptr;   // silence-gate reduction + table uploads of the NEXT call, while the previous call still runs
 	// Per-call device tables exist twice: a call fills one set on `stGate` while kernels of the previous call read the other
 	// ... and so does their PINNED host staging (h*): nothing pageable is handed to an async copy, so the only host
@@ -120,9 +119,6 @@ private:
 	} callSets[2]{};
 	int callCur = 0;
 	hipEvent_t evStart = nullptr, evFeed[2] = {nullptr, nullptr}, evChain[2] = {nullptr, nullptr}, evSynth[2] = {nullptr, nullptr};
-	hipEvent_t evEmit[3] = {nullptr, nullptr, nullptr}; // emission of the tile that used frames buffer i has finished
-	float *framesRing[3] = {nullptr, nullptr, nullptr}; // synthesised frames [subS][T][C][B]: three buffers, so a tile's emission may run two tiles late
-	bool deferEmit = false; // SMST_EMIT_DEFER=1: emission only behind the NEXT tile's recurrence (measured: slower, see process())
 	struct TileBuffers { float2 *Xcur, *Xprev, *OUT, *dump, *map, *peaksT; float4 *REC; PredEntry *PE; float *ratio, *energyT, *smoothT, *est, *freqEst, *frames; } slots[2]{};
 	bool overlap = true, noFuse = false, noSingleHop = false, noAcross = false;
 	int subS = 0;

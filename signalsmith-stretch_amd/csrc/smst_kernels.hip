@@ -466,19 +466,7 @@ __device__ __forceinline__ void fftFast(float2 *lds, const float4 *__restrict__ 
 	}
 }
 
-// The whole analysis window of the hop lies in this call's input: the frames that kAnalyseTeams takes (the others reach into the carried
-// history and go to the per-frame kernel's bounds-checked path).  The host evaluates the same condition (smst_engine.cpp).
-__device__ __forceinline__ bool analysisWindowInCall(const DevBatch &d, const HopDesc &hd, int which) {
-	return hd.inputOffset - (which ? d.I : 0) - d.B >= 0;
-}
-// The two halves of the packed input (real part: samples of the window's second half, imaginary part: of its first half) change
-// validity exactly at element-slot boundaries -- slot 0 has no imaginary part, slot 15 no real part: presetDefault / presetCheaper at
-// 48 and 96 kHz (block = 15/16 of the FFT size).  Other block sizes (44.1 kHz: 5292 of 6144) test every element.
-__host__ __device__ __forceinline__ bool slotAlignedWindow(int B, int M) {
-	const int halfB = B/2, MA = M/16;
-	return M - halfB == MA && B - halfB == 15*MA;
-}
-
+// (windowPad / analysisWindowInCall: smst_device.h -- the host scheduler evaluates the same condition)
 template <int R3, bool LEAN>
 __global__ __launch_bounds__(16*R3 > 256 ? 16*R3 : 256) __attribute__((amdgpu_waves_per_eu(4, 4))) void kAnalyseFast(DevBatch d, IoArgs io, int sBase, int hopBase, int lateOnly) {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smemRaw[];
@@ -491,7 +479,7 @@ __global__ __launch_bounds__(16*R3 > 256 ? 16*R3 : 256) __attribute__((amdgpu_wa
 	const HopDesc hd = d.hops[(size_t)(sBase + s)*d.hopStride + hopBase + k];
 	if (!(hd.flags & HOP_ACTIVE) || !(hd.flags & HOP_NEW_SPECTRUM)) return;
 	if (which == 1 && !(hd.flags & HOP_REANALYSE_PREV)) return;
-	if (lateOnly && analysisWindowInCall(d, hd, which)) return; // kAnalyseTeams has taken this frame
+	if (lateOnly && analysisWindowInCall(d.B, d.M, d.I, hd.inputOffset, which, io.inSamples[sBase + s])) return; // kAnalyseTeams has taken this frame
 	const int B = d.B, H = d.M, halfB = B/2, N = d.N;
 	const int base = hd.inputOffset - (which ? d.I : 0) - B;
 	const float *x = io.in + (size_t)(sBase + s)*io.inStreamStride + (size_t)c*io.inChannelStride;
@@ -582,15 +570,14 @@ struct TeamSync { // LDS operations of a wave complete in order: a wave's counte
 	}
 };
 
-// SLOTS: slotAlignedWindow(B, M) -- the validity of an element's halves is then a compile-time property of its slot; otherwise (44.1 kHz)
-// every element compares its index with the window's two edges.  Either way the arithmetic is kAnalyseFast's, element for element.
-template <int R3, int TEAMS, bool SLOTS>
+// EXACT: block = 15/16 of the FFT size (windowPad = 0: the geometry is then a compile-time constant); otherwise see windowPad.
+// Either way the arithmetic is kAnalyseFast's, element for element (an absent half contributes a zero: sample x zero weight).
+template <int R3, int TEAMS, bool EXACT>
 __global__ __launch_bounds__(256*TEAMS) void kAnalyseTeams(DevBatch d, IoArgs io, const HopDesc *__restrict__ hopTable, int sBase, int hopBase, int tileHops, int nStreams) {
 	static_assert(16*R3 <= 256, "a team is 256 threads");
 	extern __shared__ __attribute__((aligned(16))) unsigned char smemRaw[];
 	constexpr int MA = 16*R3, H = 256*R3, N = 2*H;
-	const int B = SLOTS ? 480*R3 : d.B, halfB = B/2; // SLOTS: the geometry this kernel is launched for
-	const int realEnd = B - halfB, imagBegin = H - halfB; // element m has a real part for m < realEnd, an imaginary part for m >= imagBegin
+	const int B = EXACT ? 480*R3 : d.B, halfB = B/2; // EXACT: the geometry this kernel is launched for
 	const int team = __builtin_amdgcn_readfirstlane(threadIdx.x >> 8), t = threadIdx.x & 255, tA = t < MA ? t : 0;
 	const int total = tileHops*2*d.C*nStreams;
 	float4 *winLds = reinterpret_cast<float4 *>(smemRaw); // (winA, winB) of all elements
@@ -610,7 +597,7 @@ __global__ __launch_bounds__(256*TEAMS) void kAnalyseTeams(DevBatch d, IoArgs io
 		const BlockCoord bc = xcdAwareCoord(lin, tileHops, 2*d.C, nStreams);
 		const HopDesc hd = hopTable[(size_t)(sBase + bc.s)*d.hopStride + hopBase + bc.x];
 		const int c = bc.y >> 1, which = bc.y & 1;
-		if (!(hd.flags & HOP_ACTIVE) || !(hd.flags & HOP_NEW_SPECTRUM) || (which && !(hd.flags & HOP_REANALYSE_PREV)) || !analysisWindowInCall(d, hd, which)) continue;
+		if (!(hd.flags & HOP_ACTIVE) || !(hd.flags & HOP_NEW_SPECTRUM) || (which && !(hd.flags & HOP_REANALYSE_PREV)) || !analysisWindowInCall(B, H, d.I, hd.inputOffset, which, io.inSamples[sBase + bc.s])) continue;
 		const int base = hd.inputOffset - (which ? d.I : 0) - B;
 		const float *x = io.in + (size_t)(sBase + bc.s)*io.inStreamStride + (size_t)c*io.inChannelStride;
 		const float *x0 = x + base + halfB, *x1 = x + base - H + halfB;
@@ -619,19 +606,8 @@ __global__ __launch_bounds__(256*TEAMS) void kAnalyseTeams(DevBatch d, IoArgs io
 			[&](int m, int slot) { // kAnalyseFast's roundings: round(xi*b + round(xr*a)), the absent half an exact zero
 				const float4 w = winLds[tA + MA*slot];
 				float2 r = make_float2(0.f, 0.f);
-				if constexpr (SLOTS) {
-					if (slot < 15) { const float xr = x0[m]; r = make_float2(xr*w.x, xr*w.y); }
-					if (slot > 0) { const float xi = x1[m]; r = make_float2(fmaf(xi, w.z, r.x), fmaf(xi, w.w, r.y)); }
-				} else {
-					// branch-free: both samples are always fetched (index clamped into the window) and the absent half is selected away --
-					// a load inside a lane-dependent branch ends the basic block, and the element's 32 loads then wait for each other in
-					// turn (first version: analysis 4.3 -> 8.4 ms per step at 44.1 kHz)
-					const bool hasRe = m < realEnd, hasIm = m >= imagBegin;
-					const float xr = x0[min(m, realEnd - 1)], xi = x1[max(m, imagBegin)];
-					if (hasRe) r = make_float2(xr*w.x, xr*w.y);
-					const float2 withIm = make_float2(fmaf(xi, w.z, r.x), fmaf(xi, w.w, r.y));
-					if (hasIm) r = withIm;
-				}
+				if (slot < 15) { const float xr = x0[m]; r = make_float2(xr*w.x, xr*w.y); }
+				if (slot > 0) { const float xi = x1[m]; r = make_float2(fmaf(xi, w.z, r.x), fmaf(xi, w.w, r.y)); }
 				return r;
 			},
 			[](int, int) { return 0; },
@@ -3629,7 +3605,8 @@ void launchAnalyse(const DevBatch &d, const IoArgs &io, int sBase, int nStreams,
 		const int jobs = tileHops*d.C*2*nStreams;
 		const int wgs = std::max(8, std::min((jobs + 2)/3/8*8, d.teamsGrid)); // one workgroup per CU, a multiple of 8 (one residue class of the job order per XCD)
 		const size_t lds = ((size_t)d.M + d.M/2 + d.M/32)*sizeof(float4) + 3*fastLds + 64; // window, first- and second-stage twiddles, a buffer per team, barrier words
-		const bool slots = slotAlignedWindow(d.B, d.M);
+		const WindowPad pad = windowPad(d.B, d.M);
+		const bool slots = pad.lo == 0 && pad.hi == 0;
 		if (d.M == 256*10) {
 			if (slots) hipLaunchKernelGGL((kAnalyseTeams<10, 3, true>), dim3(wgs), dim3(768), lds, st, d, io, d.hops, sBase, hopBase, tileHops, nStreams);
 			else hipLaunchKernelGGL((kAnalyseTeams<10, 3, false>), dim3(wgs), dim3(768), lds, st, d, io, d.hops, sBase, hopBase, tileHops, nStreams);
@@ -3705,8 +3682,11 @@ static void launchVocoderTL(const DevBatch &d, int sBase, int nStreams, int hopB
 	constexpr int NCH = (9 + 3*CH + 3)/4;
 	const size_t fixed = 64 + 128*sizeof(int) + 64*sizeof(HopDesc) + (size_t)kVocOutBlocks*kVocBlockSteps*CH*kVocOutPitch*sizeof(float2);
 	const size_t lds = (size_t)kVocBlocks*kVocBlockSteps*NCH*64*sizeof(float4) + fixed;
+	// line-aligned producers where they were measured to pay: L = 4 (presetDefault at 48 / 96 kHz: step 14.9 -> 14.5 ms).  At L = 3
+	// (presetCheaper) the 8-bin lag costs 9 % more wavefront steps than lag 4 and the two forms tie (10.75 / 10.80 ms per step), so that
+	// geometry stays on the staged producers; SMST_ALIGN_ALL=1 takes the aligned form wherever it is valid (L <= 4), for the A/B.
 	if constexpr (L <= 4) {
-		if (plain && bounded && !d.noStage && !d.noAlign && d.M%16 == 0 && !d.halfState) { // (fp16 state: the staged producers below)
+		if (plain && bounded && !d.noStage && !d.noAlign && d.M%16 == 0 && !d.halfState && (L == 4 || d.alignAll)) { // (fp16 state: the staged producers below)
 			using G = AlignGeom<CH, L>;
 			const size_t fixedA = 64 + 128*sizeof(int) + 64*sizeof(HopDesc) + (size_t)kVocOutBlocksAligned*kVocBlockSteps*CH*kVocOutPitch*sizeof(float2);
 			const size_t ldsAligned = (size_t)kVocBlocksStaged*kVocBlockSteps*NCH*64*sizeof(float4) + fixedA + (size_t)kVocStagedProducers*G::PER_PRODUCER*sizeof(float2);

@@ -201,21 +201,24 @@ def test_cmd_main_flow_config1(hip, ref):
 
 
 @pytest.mark.gpu
-def test_staged_producers_equal_gathered(hip, monkeypatch):
-    """The fused recurrence kernel has three record producers: line-aligned rings in LDS with a wavefront lag of 8 bins
-    (plain tiles, the default), per-row windows staged in LDS with lag L+1 (SMST_NO_ALIGN=1; the only staged form for
-    L = 5) and direct gathers (SMST_NO_STAGE=1).  Same arithmetic, so the outputs must be bit-identical -- over two calls,
-    so that the carried state is exercised; the launch counters prove that each form really ran."""
+@pytest.mark.parametrize("preset,C", [("default", 2), ("default", 1), ("cheaper", 2)])
+def test_staged_producers_equal_gathered(hip, monkeypatch, preset, C):
+    """The fused recurrence kernel has three record producers: whole lines in LDS with a wavefront lag of 8 bins (plain tiles of the
+    L = 4 geometries by default; SMST_ALIGN_ALL=1 wherever valid, as here for presetCheaper's L = 3), per-row windows staged in LDS
+    with lag L+1 (SMST_NO_ALIGN=1; the only staged form for L = 5) and direct gathers (SMST_NO_STAGE=1).  Same arithmetic, so the
+    outputs must be bit-identical -- over two calls, so that the carried state is exercised; the launch counters prove that each
+    form really ran.  (The aligned form waits for its loads by count, smst_async.h: this is its correctness test on hardware.)"""
     import torch
     pkg = package()
-    S, C, sr = 8, 2, 48000
+    S, sr = 8, 48000
     x = torch.from_numpy(np.stack([synth_input(s, C, 24000, sr) for s in range(S)])).cuda()
     outs = []
+    monkeypatch.setenv("SMST_ALIGN_ALL", "1")
     for env, counter in ((None, "vocoder_aligned"), ("SMST_NO_ALIGN", "vocoder_staged"), ("SMST_NO_STAGE", "vocoder_gather")):
         if env:
             monkeypatch.setenv(env, "1")
         before = pkg.launch_count(counter, hip)
-        b = pkg.StretchBatch(S, C, preset="default", sample_rate=sr, lib=hip)
+        b = pkg.StretchBatch(S, C, preset=preset, sample_rate=sr, lib=hip)
         y1 = b.process(x[:, :, :9000].contiguous(), 11000)
         y2 = b.process(x[:, :, 9000:].contiguous(), 21000)
         b.synchronize()

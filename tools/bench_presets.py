@@ -18,13 +18,18 @@ def main():
     pkg = importlib.import_module("signalsmith-stretch_amd")
     S, C, steps, warm = 256, 2, 4, 2
     rows = []
-    for preset, sr, seconds in (("default", 48000, 10.0), ("cheaper", 48000, 10.0), ("default", 96000, 5.0), ("cheaper", 96000, 5.0), ("default", 44100, 10.0)):
+    table = (("default", 48000, 10.0), ("cheaper", 48000, 10.0), ("default", 96000, 5.0), ("cheaper", 96000, 5.0), ("default", 44100, 10.0))
+    only = [a for a in sys.argv[1:] if not a.startswith("-")]  # e.g. `bench_presets.py default48000 cheaper48000`: a subset
+    fast_only = "--fast-only" in sys.argv
+    for preset, sr, seconds in table:
+        if only and "%s%d" % (preset, sr) not in only:
+            continue
         n_in = int(seconds*sr)
         n_out = int(round(n_in*1.5))
         x = bench.make_inputs(torch, S, C, n_in, torch.device("cuda", 0), sr=sr)
         y = torch.empty((S, C, n_out), dtype=torch.float32, device="cuda")
         row = dict(preset=preset, sample_rate=sr, seconds_per_stream=seconds)
-        for generic in (False, True):
+        for generic in ((False,) if fast_only else (False, True)):
             if generic:
                 os.environ["SMST_NO_FAST_FFT"] = "1"
             else:
