@@ -32,26 +32,29 @@ struct SignalsmithStretch {
 	static constexpr size_t version[3] = {1, 3, 2};
 
 	SignalsmithStretch() : SignalsmithStretch(long(std::random_device{}())) {}
-	SignalsmithStretch(long seed) {
+	SignalsmithStretch(long seed) : seed(seed) {
 		if (smst_create(&handle, seed, defaultDevice()) != SMST_OK) throw std::runtime_error(smst_last_error());
 	}
 	~SignalsmithStretch() { smst_destroy(handle); }
 	// The reference is a plain struct: copyable (the copy carries the whole processing state and continues independently) and
-	// movable.  Here a copy is smst_clone -- a second set of device buffers -- and a move hands the handle over.
-	SignalsmithStretch(const SignalsmithStretch &other) : channels(other.channels) {
-		if (smst_clone(&handle, other.handle) != SMST_OK) throw std::runtime_error(smst_last_error());
+	// movable.  Here a copy is smst_clone -- a second set of device buffers -- and a move hands the handle over.  A MOVED-FROM
+	// object stays a valid one, as the reference's does: its next use creates a fresh, unconfigured instance (h()), and copying
+	// from it copies that.
+	SignalsmithStretch(const SignalsmithStretch &other) : channels(other.channels), seed(other.seed) {
+		if (smst_clone(&handle, other.h()) != SMST_OK) throw std::runtime_error(smst_last_error());
 	}
 	SignalsmithStretch &operator=(const SignalsmithStretch &other) {
 		if (this != &other) {
 			smst_stretch *copy = nullptr;
-			if (smst_clone(&copy, other.handle) != SMST_OK) throw std::runtime_error(smst_last_error());
+			if (smst_clone(&copy, other.h()) != SMST_OK) throw std::runtime_error(smst_last_error());
 			smst_destroy(handle);
 			handle = copy;
 			channels = other.channels;
+			seed = other.seed;
 		}
 		return *this;
 	}
-	SignalsmithStretch(SignalsmithStretch &&other) noexcept : handle(other.handle), channels(other.channels),
+	SignalsmithStretch(SignalsmithStretch &&other) noexcept : handle(other.handle), channels(other.channels), seed(other.seed),
 		inPlanar(std::move(other.inPlanar)), outPlanar(std::move(other.outPlanar)), inPtrs(std::move(other.inPtrs)), outPtrs(std::move(other.outPtrs)) {
 		other.handle = nullptr;
 		other.channels = 0;
@@ -61,6 +64,7 @@ struct SignalsmithStretch {
 			smst_destroy(handle);
 			handle = other.handle;
 			channels = other.channels;
+			seed = other.seed;
 			other.handle = nullptr;
 			other.channels = 0;
 		}
@@ -71,78 +75,83 @@ struct SignalsmithStretch {
 		if (smst_set_default_device(device) != SMST_OK) throw std::runtime_error(smst_last_error());
 	}
 
-	int inputLatency() const { return smst_input_latency(handle); }
-	int outputLatency() const { return smst_output_latency(handle); }
-	void reset() { check(smst_reset(handle)); }
+	int inputLatency() const { return smst_input_latency(h()); }
+	int outputLatency() const { return smst_output_latency(h()); }
+	void reset() { check(smst_reset(h())); }
 
 	void presetDefault(int nChannels, Sample sampleRate, bool splitComputation = false) {
 		channels = nChannels;
-		check(smst_preset_default(handle, nChannels, sampleRate, splitComputation));
+		check(smst_preset_default(h(), nChannels, sampleRate, splitComputation));
 	}
 	void presetCheaper(int nChannels, Sample sampleRate, bool splitComputation = true) {
 		channels = nChannels;
-		check(smst_preset_cheaper(handle, nChannels, sampleRate, splitComputation));
+		check(smst_preset_cheaper(h(), nChannels, sampleRate, splitComputation));
 	}
 	void configure(int nChannels, int blockSamples, int intervalSamples, bool splitComputation = false) {
 		channels = nChannels;
-		check(smst_configure(handle, nChannels, blockSamples, intervalSamples, splitComputation));
+		check(smst_configure(h(), nChannels, blockSamples, intervalSamples, splitComputation));
 	}
-	int blockSamples() const { return smst_block_samples(handle); }
-	int intervalSamples() const { return smst_interval_samples(handle); }
-	bool splitComputation() const { return smst_split_computation(handle) != 0; }
+	int blockSamples() const { return smst_block_samples(h()); }
+	int intervalSamples() const { return smst_interval_samples(h()); }
+	bool splitComputation() const { return smst_split_computation(h()) != 0; }
 
-	void setTransposeFactor(Sample multiplier, Sample tonalityLimit = 0) { check(smst_set_transpose_factor(handle, multiplier, tonalityLimit)); }
-	void setTransposeSemitones(Sample semitones, Sample tonalityLimit = 0) { check(smst_set_transpose_semitones(handle, semitones, tonalityLimit)); }
+	void setTransposeFactor(Sample multiplier, Sample tonalityLimit = 0) { check(smst_set_transpose_factor(h(), multiplier, tonalityLimit)); }
+	void setTransposeSemitones(Sample semitones, Sample tonalityLimit = 0) { check(smst_set_transpose_semitones(h(), semitones, tonalityLimit)); }
 	void setFreqMap(std::function<Sample(Sample)> inputToOutput) {
-		if (!inputToOutput) { check(smst_set_freq_map_table(handle, nullptr, 0)); return; }
+		if (!inputToOutput) { check(smst_set_freq_map_table(h(), nullptr, 0)); return; }
 		const int n = 4096;
 		std::vector<float> table(n);
 		for (int i = 0; i < n; ++i) table[i] = inputToOutput((i + 0.5f)/(2*n));
-		check(smst_set_freq_map_table(handle, table.data(), n));
+		check(smst_set_freq_map_table(h(), table.data(), n));
 	}
-	void setFormantFactor(Sample multiplier, bool compensatePitch = false) { check(smst_set_formant_factor(handle, multiplier, compensatePitch)); }
-	void setFormantSemitones(Sample semitones, bool compensatePitch = false) { check(smst_set_formant_semitones(handle, semitones, compensatePitch)); }
-	void setFormantBase(Sample baseFreq = 0) { check(smst_set_formant_base(handle, baseFreq)); }
+	void setFormantFactor(Sample multiplier, bool compensatePitch = false) { check(smst_set_formant_factor(h(), multiplier, compensatePitch)); }
+	void setFormantSemitones(Sample semitones, bool compensatePitch = false) { check(smst_set_formant_semitones(h(), semitones, compensatePitch)); }
+	void setFormantBase(Sample baseFreq = 0) { check(smst_set_formant_base(h(), baseFreq)); }
 
 	template <class Inputs>
 	void seek(Inputs &&inputs, int inputSamples, double playbackRate) {
 		gather(inputs, inputSamples, 0);
-		check(smst_seek(handle, inPtrs.data(), inputSamples, playbackRate));
+		check(smst_seek(h(), inPtrs.data(), inputSamples, playbackRate));
 	}
-	int seekLength() const { return smst_seek_length(handle); }
+	int seekLength() const { return smst_seek_length(h()); }
 	template <class Inputs>
 	void outputSeek(Inputs &&inputs, int inputLength) {
 		gather(inputs, inputLength, 0);
-		check(smst_output_seek(handle, inPtrs.data(), inputLength));
+		check(smst_output_seek(h(), inPtrs.data(), inputLength));
 	}
-	int outputSeekLength(Sample playbackRate) const { return smst_output_seek_length(handle, playbackRate); }
+	int outputSeekLength(Sample playbackRate) const { return smst_output_seek_length(h(), playbackRate); }
 
 	template <class Inputs, class Outputs>
 	void process(Inputs &&inputs, int inputSamples, Outputs &&outputs, int outputSamples) {
 		gather(inputs, inputSamples, 0);
 		prepareOut(outputSamples);
-		check(smst_process(handle, inPtrs.data(), inputSamples, outPtrs.data(), outputSamples));
+		check(smst_process(h(), inPtrs.data(), inputSamples, outPtrs.data(), outputSamples));
 		scatter(outputs, outputSamples);
 	}
 	template <class Outputs>
 	void flush(Outputs &&outputs, int outputSamples, Sample playbackRate = 0) {
 		prepareOut(outputSamples);
-		check(smst_flush(handle, outPtrs.data(), outputSamples, playbackRate));
+		check(smst_flush(h(), outPtrs.data(), outputSamples, playbackRate));
 		scatter(outputs, outputSamples);
 	}
 	template <class Inputs, class Outputs>
 	bool exact(Inputs &&inputs, int inputSamples, Outputs &&outputs, int outputSamples) {
 		gather(inputs, inputSamples, 0);
 		prepareOut(outputSamples);
-		int rc = smst_exact(handle, inPtrs.data(), inputSamples, outPtrs.data(), outputSamples);
+		int rc = smst_exact(h(), inPtrs.data(), inputSamples, outPtrs.data(), outputSamples);
 		if (rc != SMST_OK && rc != SMST_ERR_SHORT) check(rc);
 		scatter(outputs, outputSamples);
 		return rc == SMST_OK;
 	}
 
 private:
-	smst_stretch *handle = nullptr;
+	mutable smst_stretch *handle = nullptr; // null only in a moved-from object, until its next use
 	int channels = 0;
+	long seed = 0;
+	smst_stretch *h() const {
+		if (!handle && smst_create(&handle, seed, defaultDevice()) != SMST_OK) throw std::runtime_error(smst_last_error());
+		return handle;
+	}
 	std::vector<float> inPlanar, outPlanar;
 	std::vector<const float *> inPtrs;
 	std::vector<float *> outPtrs;

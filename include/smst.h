@@ -100,10 +100,8 @@ int smst_set_formant_factor(smst_stretch *h, float multiplier, int compensatePit
 int smst_set_formant_semitones(smst_stretch *h, float semitones, int compensatePitch);
 int smst_set_formant_base(smst_stretch *h, float baseFreq);
 /* setFreqMap (signalsmith-stretch.h:120-122) in table form: table[i] = map((i + 0.5)/(2n)), linear in between
- * and beyond; n = 0 removes the map.  In a batch the tables of all streams are stored at ONE resolution, the longest
- * length any stream has been given: a longer table re-evaluates the rows already stored at its resolution, a shorter one
- * is evaluated at the batch's (both exact up to rounding: the tables are piecewise linear); when no stream holds a table
- * any more the next one starts afresh. */
+ * and beyond; n = 0 removes the map.  In a batch every stream keeps its own table, knot for knot, whatever the lengths of
+ * the other streams' tables (no call on one stream changes another stream's map). */
 int smst_set_freq_map_table(smst_stretch *h, const float *table, int n);
 
 /* seek / process / flush: signalsmith-stretch.h:140-165, 210-423, 427-464; main.cpp:68-76 */

@@ -4,6 +4,7 @@
 #include "smst_engine.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdlib>
 #include <memory>
@@ -284,17 +285,26 @@ int smst_create(smst_stretch **out, long seed, int device) {
 }
 void smst_destroy(smst_stretch *h) { delete h; }
 
-static int g_defaultDevice = -1;
+// the device new single-stream handles are created on: SMST_DEVICE (validated against the device count, once) or the setter
+static std::atomic<int> g_defaultDevice{-1};
 int smst_default_device(void) {
-	if (g_defaultDevice < 0) {
-		const char *env = std::getenv("SMST_DEVICE");
-		g_defaultDevice = env ? std::max(0, atoi(env)) : 0;
+	int v = g_defaultDevice.load(std::memory_order_acquire);
+	if (v < 0) {
+		v = 0;
+		if (const char *env = std::getenv("SMST_DEVICE")) {
+			char *end = nullptr;
+			const long asked = std::strtol(env, &end, 10);
+			const int n = smst_device_count();
+			if (end != env && *end == '\0' && asked >= 0 && (n <= 0 || asked < n)) v = int(asked); // an ordinal this process cannot see falls back to 0
+		}
+		int expected = -1;
+		if (!g_defaultDevice.compare_exchange_strong(expected, v, std::memory_order_acq_rel)) v = expected; // another thread (or the setter) was first
 	}
-	return g_defaultDevice;
+	return v;
 }
 int smst_set_default_device(int device) {
 	if (device < 0 || device >= smst_device_count()) return fail("device ordinal out of range");
-	g_defaultDevice = device;
+	g_defaultDevice.store(device, std::memory_order_release);
 	return SMST_OK;
 }
 int smst_clone(smst_stretch **out, const smst_stretch *src) {

@@ -546,17 +546,11 @@ void Batch::setFreqMapTable(int stream, const float *table, int n) { // table fo
 	if (n < 2) throw Error("frequency-map table needs at least 2 points");
 	if (stream >= S) throw Error("stream index out of range");
 	SMST_HIP(hipSetDevice(dev));
-	// One resolution per batch = the LONGEST table any stream has been given so far: a longer table makes the batch's array grow
-	// and the rows it already holds are re-evaluated at the finer resolution (exact for the piecewise-linear functions they are, up
-	// to rounding); a shorter table is evaluated at the batch's resolution.  When no stream holds a table any more the next one
-	// starts afresh.  (Round 2 froze the first table's length: a 2-point table followed by a 1024-point one collapsed the latter.)
-	auto evaluate = [](const float *t, int tn, float freq) {
-		float pos = freq*2*float(tn) - 0.5f;
-		if (pos <= 0) return t[0] + (t[1] - t[0])*pos;
-		if (pos >= tn - 1) return t[tn - 1] + (t[tn - 1] - t[tn - 2])*(pos - (tn - 1));
-		const int lo = int(std::floor(pos));
-		return t[lo] + (t[lo + 1] - t[lo])*(pos - lo);
-	};
+	// Every stream keeps ITS OWN table, knot for knot (StreamParams.mapLen points, linear between them, extrapolated beyond: the
+	// reference evaluates each instance's own function, :874, :1020); the batch's array only has one row pitch, the longest table
+	// seen so far -- a longer table makes the array grow and the existing rows are copied as they are.  (Rounds 2-3 re-evaluated the
+	// stored rows on the longer table's grid, which cuts the corner at every old knot: a stream's map could change because ANOTHER
+	// stream was given a longer table.)  When no stream holds a table any more the next one starts afresh.
 	bool anyCustom = false;
 	for (int s = 0; s < S; ++s) anyCustom = anyCustom || params[s].hasCustomMap;
 	if (!anyCustom) d.mapTableLen = 0;
@@ -564,7 +558,7 @@ void Batch::setFreqMapTable(int stream, const float *table, int n) { // table fo
 		std::vector<float> grown((size_t)S*n, 0.0f);
 		for (int s = 0; s < S && d.mapTableLen > 0; ++s) {
 			if (!params[s].hasCustomMap) continue;
-			for (int i = 0; i < n; ++i) grown[(size_t)s*n + i] = evaluate(hostMapTable.data() + (size_t)s*d.mapTableLen, d.mapTableLen, (i + 0.5f)/(2*float(n)));
+			std::copy(hostMapTable.begin() + (size_t)s*d.mapTableLen, hostMapTable.begin() + (size_t)s*d.mapTableLen + params[s].mapLen, grown.begin() + (size_t)s*n);
 		}
 		SMST_HIP(hipStreamSynchronize(st)); // kernels of earlier calls may still read the old array
 		if (dMapTable) devFree(dMapTable);
@@ -573,17 +567,11 @@ void Batch::setFreqMapTable(int stream, const float *table, int n) { // table fo
 		d.mapTableLen = n;
 		d.mapTable = dMapTable;
 	}
-	const int len = d.mapTableLen;
-	std::vector<float> resampled;
-	const float *src = table;
-	if (n != len) { // a shorter table: evaluate it (its own interpolation rule) at this batch's sample points
-		resampled.resize(len);
-		for (int i = 0; i < len; ++i) resampled[i] = evaluate(table, n, (i + 0.5f)/(2*float(len)));
-		src = resampled.data();
-	}
+	const int pitch = d.mapTableLen;
 	forStreams(S, stream, [&](int s) {
-		std::copy(src, src + len, hostMapTable.begin() + (size_t)s*len);
+		std::copy(table, table + n, hostMapTable.begin() + (size_t)s*pitch);
 		params[s].hasCustomMap = 1;
+		params[s].mapLen = n;
 	});
 	SMST_HIP(hipStreamSynchronize(st)); // kernels of earlier calls may still read the old table
 	SMST_HIP(hipMemcpy(dMapTable, hostMapTable.data(), hostMapTable.size()*sizeof(float), hipMemcpyHostToDevice));

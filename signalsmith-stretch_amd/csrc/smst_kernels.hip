@@ -820,8 +820,8 @@ __device__ __forceinline__ const float2 *prevRow(const DevBatch &d, const HopDes
 
 __device__ __forceinline__ float mapFreqDev(const DevBatch &d, const StreamParams &p, int sGlobal, float freq) { // :850-856
 	if (p.hasCustomMap) {
-		const float *t = d.mapTable + (size_t)sGlobal*d.mapTableLen;
-		const int n = d.mapTableLen;
+		const float *t = d.mapTable + (size_t)sGlobal*d.mapTableLen; // row pitch: the longest table of the batch
+		const int n = p.mapLen;                                      // this stream's own knots
 		float pos = freq*2*float(n) - 0.5f;
 		if (pos <= 0) return t[0] + (t[1] - t[0])*pos;
 		if (pos >= n - 1) return t[n - 1] + (t[n - 1] - t[n - 2])*(pos - (n - 1));

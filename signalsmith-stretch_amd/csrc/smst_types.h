@@ -51,7 +51,7 @@ struct StreamParams {
 	float formantBaseFreq;    // :134
 	int formantCompensation;  // :127
 	int hasCustomMap;         // :120 (table form)
-	int pad;
+	int mapLen;               // points of this stream's table (the batch's array has one row pitch: the longest table's length)
 };
 
 // fp16 storage of the carried state (opt-in per batch): fp32 <-> half conversions only, no half arithmetic

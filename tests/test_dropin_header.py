@@ -79,3 +79,39 @@ def test_reference_style_code_compiles(tmp_path):
     r = subprocess.run(["g++", "-std=c++11", "-Wall", "-Wextra", "-fsyntax-only", "-I", os.path.join(ROOT, "include"), str(src)],
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-3000:]
+
+
+MOVED_FROM = textwrap.dedent(r'''
+    #include "signalsmith-stretch/signalsmith-stretch.h"
+    #include <cstdio>
+    #include <vector>
+    using Stretch = signalsmith::stretch::SignalsmithStretch<float>;
+    int main() {
+        Stretch a(3L);
+        a.presetCheaper(1, 48000.0f);
+        Stretch b(std::move(a));                 // a is moved-from: still a valid object, as the reference's struct is
+        if (a.blockSamples() >= 0 && b.blockSamples() != 4800) return 1;
+        Stretch c(a);                            // copying a moved-from object copies an unconfigured one
+        a.configure(1, 512, 128);                // ... and it can be configured and used again
+        std::vector<std::vector<float>> in(1, std::vector<float>(2048, 0.25f)), out(1, std::vector<float>(2048));
+        a.process(in, 2048, out, 2048);
+        c = a;                                   // copy assignment from the re-used object
+        if (c.blockSamples() != 512 || a.intervalSamples() != 128) return 2;
+        b = std::move(c);
+        c.presetDefault(2, 44100.0f);            // moved-from by assignment, used again
+        std::printf("ok %d %d\n", b.blockSamples(), c.blockSamples());
+        return (b.blockSamples() == 512 && c.blockSamples() == 5292) ? 0 : 3;
+    }
+''')
+
+
+def test_moved_from_objects_stay_usable(emu, tmp_path):
+    """ADVICE r3: a moved-from drop-in object used to pass a null handle to every call.  Runs against the CPU stand-in."""
+    src, exe = tmp_path / "moved.cpp", tmp_path / "moved"
+    src.write_text(MOVED_FROM)
+    emu_dir = os.path.join(ROOT, "tests", "emu")
+    r = subprocess.run(["g++", "-std=c++11", "-O1", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe), "-L" + emu_dir, "-l:libsmst_emu.so",
+                        "-Wl,-rpath," + emu_dir], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (r.returncode, r.stdout, r.stderr[-2000:])

@@ -603,6 +603,10 @@ def test_random_time_factor_parity(hip, ref):
     _report("random_time_factor_parity", {k.replace("/", "_"): (v if isinstance(v, float) else v.get("spectrum")) for k, v in r.items()})
 
 
+def test_reconfigure_keeps_random_engine(hip, ref):
+    pc.case_reconfigure_keeps_random_engine(hip, ref)
+
+
 def test_fft_teams_equals_per_frame(hip, monkeypatch):
     """kAnalyseTeams (SMST_FFT_TEAMS=1) against kAnalyseFast: bit-identical."""
     pc.case_fft_teams_equals_per_frame(hip, monkeypatch, presets=(("cheaper", 48000), ("default", 48000), ("default", 44100)), streams=5)
