@@ -225,18 +225,18 @@ def library_sha16():
         return hashlib.sha256(f.read()).hexdigest()[:16]
 
 
-def measured_traffic(sha16):
+def measured_traffic(sha16, config="2"):
     """HBM bytes per step from the PMC passes (rocprofv3 FETCH_SIZE / WRITE_SIZE, separate runs, gfx950 correction:
     profiles/summarize.py) -- ONLY if profiles/traffic_latest.json was measured on this very library build; a bench
     run cannot collect PMC counters itself, so anything else is reported as null."""
-    path = os.path.join(ROOT, "profiles", "traffic_latest.json")
+    path = os.path.join(ROOT, "profiles", "traffic_latest.json" if config in ("2", None) else "traffic_latest_config%s.json" % config)
     try:
         t = json.load(open(path))
     except Exception:
-        return None, "none (no PMC summary in profiles/)"
+        return None, "none (no PMC summary %s in profiles/)" % os.path.basename(path)
     if t.get("library_sha16") != sha16:
-        return None, "none (profiles/traffic_latest.json was measured on library %s, this run uses %s)" % (t.get("library_sha16"), sha16)
-    return t, "profiles/traffic_latest.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `%s` on library %s)" % (t.get("command", "bench.py"), sha16)
+        return None, "none (profiles/%s was measured on library %s, this run uses %s)" % (os.path.basename(path), t.get("library_sha16"), sha16)
+    return t, "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `%s` on library %s)" % (os.path.basename(path), t.get("command", "bench.py"), sha16)
 
 
 def self_launch_command(gpus, oversubscribe, visible_devices, argv, environ):
@@ -453,7 +453,7 @@ def main():
         step_mean_ms = elapsed/args.steps*1e3
         pipeline_achieved = gbs(bytes_per_chop*chops_per_step, step_mean_ms)
         sha = library_sha16()
-        traffic, traffic_source = measured_traffic(sha)
+        traffic, traffic_source = measured_traffic(sha, args.config)
         per_class = {}
         rows = [("analyse", names["analyse"], ms["analyse"], launch_count["analyse"]), ("chain", names["chain"], ms["chain"], launch_count["chain"]),
                 ("synth+emit", names["synth"] + " + kEmit", ms["synth"] + ms["emit"], launch_count["synth"])]

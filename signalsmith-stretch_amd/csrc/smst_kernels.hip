@@ -2503,6 +2503,9 @@ __device__ __forceinline__ void vocoderProduceAligned(const DevBatch &d, int s, 
 			for (int c = 0; c < CH; ++c) { asyncArrived(carNext1[c]); asyncArrived(carNextL[c]); }
 		}
 	};
+	// (Reading the line that park() moves down a block EARLIER, so that its LDS round trip does not sit between the landed lines and
+	// their parking, costs eight more live registers: the kernel is at its 128-register budget -- 48 bytes of scratch, recurrence
+	// 6.75 -> 9.3 ms per step.  Measured, not kept.)
 	auto park = [&](int n, int par, Async16 (&v)[G::LOADS]) {
 		if (FIRST) {
 #pragma unroll
@@ -2790,6 +2793,9 @@ __global__ __launch_bounds__(64*kVocWaves) __attribute__((amdgpu_waves_per_eu(4,
 		// heavier producers, the same move changed nothing.)
 		int pIndex = wave - 1 - (wave > 4);
 		if (STAGED) pIndex = (wave & 3) ? ((wave < 8) ? pIndex : ((wave == 9) ? 6 : ((wave == 10) ? 7 : NP))) : NP;
+		// aligned form: the wave that owns rows 0..7 (carried taps, FOLD0 -- the heaviest, and every block waits for the slowest producer)
+		// on the SIMD that holds only two producers (waves 3, 7): recurrence 0.97 -> 0.95 ms in place, step -0.12 ms
+		if (STAGED && ALIGNED && pIndex < NP) pIndex = (pIndex == 0) ? 2 : ((pIndex == 2) ? 0 : pIndex);
 		if (pIndex >= NP) return;
 		if constexpr (ALIGNED) {
 			using G = AlignGeom<CH, L>;

@@ -1,5 +1,6 @@
 """Wave placement experiments of the ALIGNED recurrence kernel (results unchanged, only which SIMD a role lands on).
 PLACE=p2222: two producers on every SIMD (waves 8 and 12 beside the recurrence wave instead of 9 and 10)
+PLACE=first3: producer 0 (the heaviest) on the two-producer SIMD
 PLACE=w11:   the writer on wave 11 (SIMD 3, which holds two producers) instead of wave 4 (the recurrence wave's SIMD)"""
 import os
 import sys
@@ -11,6 +12,9 @@ old = "		if (STAGED) pIndex = (wave & 3) ? ((wave < 8) ? pIndex : ((wave == 9) ?
 assert s.count(old) == 1
 if mode == "p2222":
     s = s.replace(old, "		if (STAGED) pIndex = (wave < 8) ? ((wave & 3) ? pIndex : NP) : ((wave == 8) ? 6 : ((wave == 12) ? 7 : NP));")
+elif mode == "first3":
+    # the producer that owns rows 0..7 (carried taps, FOLD0: the heaviest) on the SIMD that holds only two producers (waves 3, 7)
+    s = s.replace(old, old + "\n		if (STAGED && ALIGNED && pIndex < NP) pIndex = (pIndex == 0) ? 2 : ((pIndex == 2) ? 0 : pIndex);")
 elif mode == "w11":
     a = s.index("template <int CH, bool PLAIN, int L, bool STAGED, bool ROTL = false, bool ACROSS = false, bool ALIGNED = false>")
     b = s.index("constexpr int kVocNBlockSteps")
