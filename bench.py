@@ -236,7 +236,9 @@ def measured_traffic(sha16, config="2"):
         return None, "none (no PMC summary %s in profiles/)" % os.path.basename(path)
     if t.get("library_sha16") != sha16:
         return None, "none (profiles/%s was measured on library %s, this run uses %s)" % (os.path.basename(path), t.get("library_sha16"), sha16)
-    return t, "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `%s` on library %s)" % (os.path.basename(path), t.get("command", "bench.py"), sha16)
+    return t, "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `%s` on library %s%s)" % (
+        os.path.basename(path), t.get("command", "bench.py"), sha16,
+        ("; measured on %d streams and scaled by the stream count: every stream does the same work" % t["streams"]) if t.get("streams") else "")
 
 
 def self_launch_command(gpus, oversubscribe, visible_devices, argv, environ):
@@ -259,7 +261,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--streams", type=int, default=256, help="streams per GPU (BASELINE configs[1]: 256)")
+    ap.add_argument("--streams", type=int, default=None, help="streams per GPU (default: the config's own count -- config 2 = BASELINE configs[1]: 256)")
     ap.add_argument("--seconds", type=float, default=10.0, help="seconds of input per stream per step")
     ap.add_argument("--stretch", type=float, default=1.5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -279,6 +281,9 @@ def main():
     preset, C, sr_cfg = "default", 2, SR
     setup = None
     per_stream = None
+    explicit_streams = args.streams
+    if args.streams is None:
+        args.streams = 256
     if args.config == "3":
         args.streams, args.stretch = 1024, 1.0
         setup = lambda b: b.setTransposeSemitones(12, 8000/48000)  # noqa: E731
@@ -292,6 +297,8 @@ def main():
     elif args.config == "5":
         args.streams, args.seconds, preset, C, sr_cfg = 1024, 2.0, "cheaper", 8, 96000
         per_stream = True
+    if explicit_streams is not None:  # e.g. the PMC passes of the 1024-stream configs run on a subset (rocprofv3's counter collection crashes on the full ones)
+        args.streams = explicit_streams
 
     import torch
     import torch.distributed as dist
@@ -464,7 +471,7 @@ def main():
         roofline = dict(
             bound="hbm", scope="whole hot path: every kernel of one process() step, pipelined (the figure north_star's '% of HBM peak' asks for)",
             achieved=pipeline_achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=(pipeline_achieved/HBM_PEAK_GBS if pipeline_achieved else None),
-            traffic=(traffic.get("bytes_per_step") if traffic else None), traffic_source=traffic_source,
+            traffic=((traffic.get("bytes_per_step")*(S/float(traffic["streams"]) if traffic.get("streams") else 1.0)) if traffic else None), traffic_source=traffic_source,
             algorithmic_bytes_per_channel_hop=bytes_per_chop, channel_hops_per_step=chops_per_step,
             step_ms=dict(mean_wall=step_mean_ms, median=step_ms[len(step_ms)//2], min=step_ms[0], max=step_ms[-1], n=len(step_ms),
                          note="mean_wall = host clock around the K steps / K (the figure `value` uses); median/min/max = device-side period of each step (event stamps)"),

@@ -22,6 +22,15 @@
  *      until a stream passed to smst_batch_signal_stream() has caught up); the
  *      host-side part of a call (silence gate, block scheduler) overlaps the kernels of the previous call.
  *
+ * Limits the reference does not have (signalsmith-stretch.h:71-94 accepts any channel count and block size); configure / create
+ * return SMST_ERR_INVALID with the limit in smst_last_error() beyond them:
+ *   - 1 ... 8 channels per stream (the bin recurrence keeps one lane's channels in registers / one LDS ring per channel);
+ *   - fftSamples/2 = 2^k * {1, 3, 5} bands (the reference's own fast sizes) with bands*16 bytes <= 150 KiB, i.e. <= 9600 bands:
+ *     a frame's FFT runs inside one CU's LDS (every preset up to 192 kHz fits; presetDefault at 96 kHz has 6144 bands);
+ *   - interval >= fftSamples/62 (the vertical step of the phase prediction, round(fftSamples/interval), has to fit the wavefront's
+ *     skew); interval <= block.
+ *   - Sample = float arithmetic only (the C++ drop-in accepts double buffers and converts at the boundary).
+ *
  * Every function returns 0 on success and a negative code on failure (the reference has no error channel:
  * signalsmith-stretch.h is UB when unconfigured; only exact() reports, :471-480).  smst_last_error()
  * returns the message of the last failure on the calling thread.

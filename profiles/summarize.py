@@ -1,7 +1,7 @@
 """Turns the rocprofv3 CSVs collected by tools/prof/prof_counters.sh (kernel trace + stats, FETCH_SIZE / WRITE_SIZE / SQ
 passes, each in its own run) into the small summaries committed under profiles/.
 usage: python profiles/summarize.py gpurun_out/<tag> r1 [steps profiled, default 3] [bench config, default 2: traffic_latest.json;
-       another config N writes traffic_latest_configN.json, which `bench.py --config N` quotes]
+       another config N writes traffic_latest_configN.json, which `bench.py --config N` quotes] [streams the passes ran on, if a subset]
 HBM bytes per launch follow /opt/skills/guides/MI355X_MICROARCH.md (HBM section): FETCH_SIZE and WRITE_SIZE are in KiB;
 on gfx950 FETCH_SIZE counts half of the bytes of a coalesced stream, so traffic = (2*FETCH_SIZE + WRITE_SIZE)*1024.
 (Calibration in this repo: kAnalyse writes exactly S*hops*C*2*24576 B per launch and WRITE_SIZE reports that number;
@@ -62,7 +62,8 @@ def main():
     lib = os.path.join(os.path.dirname(here), "signalsmith-stretch_amd", "libsmst_hip.so")
     sha = hashlib.sha256(open(lib, "rb").read()).hexdigest()[:16]
     config = sys.argv[4] if len(sys.argv) > 4 else "2"
-    latest = {"library_sha16": sha, "bytes_per_step": per_step, "kernels": traffic, "steps_profiled": steps, "config": config,
+    streams = int(sys.argv[5]) if len(sys.argv) > 5 else None  # passes that ran on a subset of the config's streams (bench.py --streams)
+    latest = {"library_sha16": sha, "bytes_per_step": per_step, "kernels": traffic, "steps_profiled": steps, "config": config, "streams": streams,
               "command": "bench.py%s --steps 2 --warmup 1 --no-cpu-baseline --no-serial-pass (tools/prof/prof_counters.sh)" % ("" if config == "2" else " --config " + config),
               "summary": tag + "_pmc_summary.json"}
     json.dump(latest, open(os.path.join(here, "traffic_latest.json" if config == "2" else "traffic_latest_config%s.json" % config), "w"), indent=1, sort_keys=True)
