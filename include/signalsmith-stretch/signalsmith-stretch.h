@@ -121,12 +121,27 @@ struct SignalsmithStretch {
 	}
 	int outputSeekLength(Sample playbackRate) const { return smst_output_seek_length(h(), playbackRate); }
 
+	// The reference's profiling hooks (:211-213, :329-331, :402-404, :420-422): START and END bracket the call as they do there.  The
+	// per-step hooks have no counterpart -- the spectral steps of a call run as kernels over the whole call, not interleaved with
+	// the output samples on the host -- so STEP is reported once (step 0 of 1) and ENDSTEP once, after the device work.
 	template <class Inputs, class Outputs>
 	void process(Inputs &&inputs, int inputSamples, Outputs &&outputs, int outputSamples) {
+#ifdef SIGNALSMITH_STRETCH_PROFILE_PROCESS_START
+		SIGNALSMITH_STRETCH_PROFILE_PROCESS_START(inputSamples, outputSamples);
+#endif
 		gather(inputs, inputSamples, 0);
 		prepareOut(outputSamples);
+#ifdef SIGNALSMITH_STRETCH_PROFILE_PROCESS_STEP
+		SIGNALSMITH_STRETCH_PROFILE_PROCESS_STEP(size_t(0), size_t(1));
+#endif
 		check(smst_process(h(), inPtrs.data(), inputSamples, outPtrs.data(), outputSamples));
+#ifdef SIGNALSMITH_STRETCH_PROFILE_PROCESS_ENDSTEP
+		SIGNALSMITH_STRETCH_PROFILE_PROCESS_ENDSTEP();
+#endif
 		scatter(outputs, outputSamples);
+#ifdef SIGNALSMITH_STRETCH_PROFILE_PROCESS_END
+		SIGNALSMITH_STRETCH_PROFILE_PROCESS_END();
+#endif
 	}
 	template <class Outputs>
 	void flush(Outputs &&outputs, int outputSamples, Sample playbackRate = 0) {

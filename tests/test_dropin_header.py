@@ -8,6 +8,12 @@ import textwrap
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 SOURCE = textwrap.dedent(r'''
+    // the reference's profiling hooks (signalsmith-stretch.h:211-213, :329-331, :402-404, :420-422), defined as cmd/main-dev.cpp defines them
+    static int profileCalls = 0;
+    #define SIGNALSMITH_STRETCH_PROFILE_PROCESS_START(inputSamples, outputSamples) (profileCalls += (inputSamples) >= 0 && (outputSamples) >= 0)
+    #define SIGNALSMITH_STRETCH_PROFILE_PROCESS_STEP(step, count) (profileCalls += (step) < (count))
+    #define SIGNALSMITH_STRETCH_PROFILE_PROCESS_ENDSTEP() (++profileCalls)
+    #define SIGNALSMITH_STRETCH_PROFILE_PROCESS_END() (++profileCalls)
     #include "signalsmith-stretch/signalsmith-stretch.h"
     #include <vector>
     #include <array>
