@@ -29,5 +29,8 @@ __device__ __forceinline__ void asyncArrived(Async16 &r) { asm volatile("" : "+v
 __device__ __forceinline__ void asyncArrived(Async8 &r) { asm volatile("" : "+v"(r.v)); }
 __device__ __forceinline__ float4 asyncValue(const Async16 &r) { return make_float4(r.v.x, r.v.y, r.v.z, r.v.w); }
 __device__ __forceinline__ float2 asyncValue(const Async8 &r) { return make_float2(r.v.x, r.v.y); }
+// An empty statement that "uses and redefines" x: what produced x can no longer be sunk into a later conditional (the compiler turns
+// `c ? a + lds[i] : a` into a branch around the read and waits for every read on its own: 24 LDS round trips in sequence).
+__device__ __forceinline__ void keepUnconditional(float &x) { asm volatile("" : "+v"(x)); }
 
 } // namespace smst

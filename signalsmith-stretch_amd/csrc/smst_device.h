@@ -24,6 +24,7 @@ struct DevBatch {
 	int noFastFft;                // SMST_NO_FAST_FFT: the generic radix-4/2/3/5 ladder even where a register-blocked FFT exists (cross-check)
 	int fftTeams;                 // analysis / synthesis by persistent workgroups of three free-running teams, tables in LDS (default; SMST_FFT_TEAMS=0: one frame per workgroup; =2: teams even for tiles with few frames per team -- tests)
 	int teamsGrid;                // their grid: one workgroup per CU, a multiple of 8
+	int synthEmit;                // synthesis + overlap-add + emission in one kernel (kSynthEmitTeams) where it applies (default 1; SMST_SYNTH_EMIT=0: kSynthTeams + kEmit; =2: also for small tiles -- tests)
 	int noStage;                  // SMST_NO_STAGE: producers of the fused kernel gather from HBM even where staging applies
 	int alignAll;                 // SMST_ALIGN_ALL: the line-aligned producers for every geometry they are valid for (default: L = 4 only)
 	int noAlign;                  // SMST_NO_ALIGN: staged producers with per-row windows and lag L+1 (round 3) instead of the line-aligned form
@@ -48,6 +49,8 @@ struct DevBatch {
 	float *hist[2];                   // last B+I input samples              [S][C][B+I]
 	float *carrySum[2];               // overlap-add partial sums            [S][C][B+I]
 	float *carryWp[2];                // window products                     [S][B+I]
+	float *wpHead;                    // kSynthEmitTeams: the window products of a tile's first samples (those the carry reaches into), [S][wpHeadLen], written by kEmitProducts
+	int wpHeadLen;                    // (ceil(B/I) + 2)*I
 	float *stFreq;                    // freqEstimateWeighted / Weight       [S][2]
 	const StreamParams *params;       // [S]
 	const float *mapTable;            // [S][mapTableLen] custom frequency maps (table form of setFreqMap)
@@ -105,7 +108,7 @@ __host__ __device__ inline bool analysisWindowInCall(int B, int M, int I, int in
 // form" tests assert through these that BOTH forms really ran.
 enum LaunchKind {
 	LK_VOC_ALIGNED, LK_VOC_STAGED, LK_VOC_GATHER, LK_VOC_N, LK_VOC_ONE, LK_VOC_ACROSS, LK_CHAIN_UNFUSED,
-	LK_ANALYSE_TEAMS, LK_ANALYSE_FAST, LK_ANALYSE_GENERIC, LK_SYNTH_TEAMS, LK_SYNTH_FAST, LK_SYNTH_GENERIC, LK_COUNT
+	LK_ANALYSE_TEAMS, LK_ANALYSE_FAST, LK_ANALYSE_GENERIC, LK_SYNTH_TEAMS, LK_SYNTH_FAST, LK_SYNTH_GENERIC, LK_SYNTH_EMIT, LK_COUNT
 };
 long long launchCount(const char *name); // -1: unknown name
 
@@ -123,6 +126,7 @@ bool acrossSupported(const DevBatch &d);
 void launchVocoderAcross(const DevBatch &d, int sBase, int nStreams, int hopBase, bool plain, hipStream_t st); // the same tiles, mono / stereo: lanes of the recurrence wave = streams
 void launchSynth(const DevBatch &d, int sBase, int nStreams, int hopBase, int tileHops, hipStream_t st);
 void launchEmit(const DevBatch &d, const IoArgs &io, int sBase, int nStreams, int tileIndex, int maxSpan, hipStream_t st);
+bool launchSynthEmit(const DevBatch &d, const IoArgs &io, int sBase, int nStreams, int tileHops, int tileIndex, hipStream_t st); // false: not applicable, nothing launched
 void launchCarryFeed(const DevBatch &d, int sBase, int nStreams, int hopBase, bool anyFormants, hipStream_t st);
 void launchCarryOut(const DevBatch &d, int sBase, int nStreams, hipStream_t st);
 void launchHistory(const DevBatch &d, const IoArgs &io, hipStream_t st);

@@ -186,6 +186,8 @@ void Batch::construct(const FftPlan &plan, long seed) {
 	d.feedSerial = std::getenv("SMST_FEED_SERIAL") != nullptr;
 	d.fftTeams = 1;
 	if (const char *env = std::getenv("SMST_FFT_TEAMS")) d.fftTeams = atoi(env);
+	d.synthEmit = 1;
+	if (const char *env = std::getenv("SMST_SYNTH_EMIT")) d.synthEmit = atoi(env);
 	{
 		int cus = 0;
 		SMST_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
@@ -325,6 +327,8 @@ void Batch::construct(const FftPlan &plan, long seed) {
 		d.carrySum[h] = reinterpret_cast<float *>(devAlloc<unsigned char>((size_t)S*C*d.carryLen*sizeof(float)/stateScale));
 		d.carryWp[h] = devAlloc<float>((size_t)S*d.carryLen);
 	}
+	d.wpHeadLen = ((B + I - 1)/I + 2)*I;
+	d.wpHead = devAlloc<float>((size_t)S*d.wpHeadLen);
 	d.stFreq = devAlloc<float>((size_t)S*2);
 	dParams = devAlloc<StreamParams>(S);
 	d.params = dParams;
@@ -962,8 +966,13 @@ void Batch::process(const float *in, long long inSS, long long inCS, const int *
 				SMST_HIP(hipEventRecord(evChain[slot], sC));
 				SMST_HIP(hipStreamWaitEvent(sS, evChain[slot], 0));
 			}
-			if (th[0]) timed(timings.synthMs, [&] { launchSynth(dd, sBase, ns, hopBase, tileHops, sS); if (profiling) ++timings.synthLaunches; });
-			timed(timings.emitMs, [&] { launchEmit(dd, io, sBase, ns, t, maxSpanV[(size_t)sub*nTiles + t], sS); if (profiling) ++timings.emitLaunches; });
+			bool emitted = false; // synthesis + overlap-add + emission in one kernel where the geometry and the batch allow it
+			if (th[0]) timed(timings.synthMs, [&] {
+				emitted = launchSynthEmit(dd, io, sBase, ns, tileHops, t, sS);
+				if (!emitted) launchSynth(dd, sBase, ns, hopBase, tileHops, sS);
+				if (profiling) ++timings.synthLaunches;
+			});
+			if (!emitted) timed(timings.emitMs, [&] { launchEmit(dd, io, sBase, ns, t, maxSpanV[(size_t)sub*nTiles + t], sS); if (profiling) ++timings.emitLaunches; });
 			checkLaunch("synthesis / emission");
 			if (!serial) SMST_HIP(hipEventRecord(evSynth[slot], sS));
 		}

@@ -365,17 +365,29 @@ __device__ __forceinline__ void dftLast(float2 (&v)[R3]) {
 // the synthesis).  The 15 stage-A twiddles w^n come from six loaded ones (w^1..w^4, w^8, w^12: three 16-byte loads instead of
 // eight) and nine products of two of them: one extra rounding each.
 struct BlockSync { __device__ __forceinline__ void operator()() const { __syncthreads(); } };
+struct NoHook { __device__ __forceinline__ void operator()() const {} };
+struct NoArrival { __device__ __forceinline__ float2 operator()(float2 v, int) const { return v; } };
 // t / sync: a workgroup may hold several TEAMS of 256 threads, each transforming its own frame in its own `lds` at its own pace;
-// t is then the index within the team and sync() the team's barrier
-template <int SIGN, int R3, bool LEAN, typename Load, typename Prep, typename Store, typename Sync = BlockSync>
+// t is then the index within the team and sync() the team's barrier.  Hooks of kSynthEmitTeams: lastRead() is called once the last
+// stage's operands have left `lds` (a barrier there lets `store` write into the same buffer); requested() once the frame's loads have
+// been issued and before anything is written to `lds` (the previous frame's overlap-add runs under the loads' latency), firstWritten()
+// after the first stage's writes
+template <int SIGN, int R3, bool LEAN, typename Load, typename Prep, typename Store, typename Sync = BlockSync, typename LastRead = NoHook,
+          typename Requested = NoHook, typename FirstWritten = NoHook, typename Arrived = NoArrival>
 __device__ __forceinline__ void fftFast(float2 *lds, const float4 *__restrict__ twA, const float4 *__restrict__ twB, Load load, Prep prep, Store store,
-                                        const int t = threadIdx.x, Sync sync = Sync()) {
+                                        const int t = threadIdx.x, Sync sync = Sync(), LastRead lastRead = LastRead(), Requested requested = Requested(),
+                                        FirstWritten firstWritten = FirstWritten(), Arrived arrived = Arrived()) {
 	constexpr int MA = 16*R3;
 	float2 v[16];
 	// stage A: radix 16, stride 1
 	if (t < MA) {
 #pragma unroll
 		for (int k = 0; k < 16; ++k) v[k] = load(t + MA*k, k);
+	}
+	requested();
+	if (t < MA) {
+#pragma unroll
+		for (int k = 0; k < 16; ++k) v[k] = arrived(v[k], t + MA*k); // (anything `load` did to its value would be waited for in front of requested())
 		float2 w[16]; // w[n] = w_H^(n t) (conjugated for the inverse transform)
 		if constexpr (LEAN) {
 			const float4 a = twA[t], b = twA[MA + t], c = twA[2*MA + t]; // (w1, w2) (w3, w4) (w8, w12)
@@ -407,6 +419,7 @@ __device__ __forceinline__ void fftFast(float2 *lds, const float4 *__restrict__ 
 			lds[17*t + n] = val; // padded index of 16 t + n
 		}
 	}
+	firstWritten();
 	sync();
 	// stage B: radix 16, stride 16
 	const int p = t >> 4, q0 = t & 15;
@@ -440,6 +453,7 @@ __device__ __forceinline__ void fftFast(float2 *lds, const float4 *__restrict__ 
 		float2 u[R3];
 #pragma unroll
 		for (int k = 0; k < R3; ++k) u[k] = lds[t + 256*k];
+		lastRead();
 		constexpr int CHUNK = R3 <= 12 ? R3 : (R3 == 24 ? 6 : 5); // outputs prepared ahead of their stores (R3 = 20 / 24: four rounds, or the registers cost a wave of occupancy)
 		decltype(prep(0, 0)) ready[CHUNK];
 #pragma unroll
@@ -721,6 +735,197 @@ __global__ __launch_bounds__(256*TEAMS) void kSynthTeams(DevBatch d, const HopDe
 				if (m >= H - halfB) frame[m - H + halfB] = (2*v.y)*r.w;
 			}, t, sync);
 		sync(); // the last stage's LDS reads, before the next frame's first-stage writes
+	}
+}
+
+// The window-product sum under output sample i of a tile (i counted from the tile's first sample): what the carry holds there, then
+// the covering frames' products oldest first -- kEmit's sum, term for term.
+__device__ __forceinline__ float windowProductAt(const DevBatch &d, const EmitDesc &ed, const float *__restrict__ carryWpOld, int i) {
+	float wp = i < d.carryLen ? carryWpOld[i] : 1e-30f;
+	if (ed.hopCount > 0) {
+		const int rel = ed.nLo + i - ed.firstHopPos - d.delta, B = d.B, I = d.I;
+		int qHi = rel >= 0 ? rel/I : -1;
+		const int qLo = (rel - B + 1 > 0) ? (rel - B + 1 + I - 1)/I : 0;
+		if (qHi > ed.hopCount - 1) qHi = ed.hopCount - 1;
+		for (int q = qLo; q <= qHi; ++q) wp += d.wprod[rel - q*I];
+	}
+	return wp;
+}
+// kSynthEmitTeams' companion: the window products do not depend on the channel or on the data, and from the sample on that the carried
+// sums no longer reach they repeat with the interval -- the teams keep that steady pattern in registers.  What is left is per stream: the
+// products under the tile's first wpHeadLen samples (-> wpHead) and under what the next tile starts from (-> the new carry).
+__global__ __launch_bounds__(256) void kEmitProducts(DevBatch d, int sBase, int tileIndex) {
+	const int sg = sBase + blockIdx.y;
+	const EmitDesc ed = d.emit[(size_t)sg*d.emitStride + tileIndex];
+	const int span = ed.nHi - ed.nLo, CL = d.carryLen;
+	const float *carryWpOld = d.carryWp[d.carryCur] + (size_t)sg*CL;
+	const int i = blockIdx.x*blockDim.x + threadIdx.x;
+	if (i < d.wpHeadLen) d.wpHead[(size_t)sg*d.wpHeadLen + i] = windowProductAt(d, ed, carryWpOld, i);
+	else if (i - d.wpHeadLen < CL) d.carryWp[d.carryCur ^ 1][(size_t)sg*CL + (i - d.wpHeadLen)] = windowProductAt(d, ed, carryWpOld, span + (i - d.wpHeadLen));
+}
+
+// K4a + K4b in one kernel: synthesis, overlap-add, window-product normalisation and emission (signalsmith-stretch.h:397-415) without
+// the frames ever reaching HBM.  A team of 256 threads takes ONE (stream, channel) of the tile and synthesises its hops in order;
+// the overlap-add ring (the carried partial sums in front, NI = QN + 1 intervals) lives in the team's registers -- thread t owns
+// the positions r = t + 256*slot of every interval.  Per hop: kSynthTeams' transform; its windowed outputs go to the team's own
+// transform buffer (free once the last stage has read it) instead of HBM; each thread adds its positions of the QN intervals the frame
+// covers, oldest frame first as kEmit (and the reference's ring) sums them; the interval that no later frame reaches is divided by
+// its window products (kEmitProducts) and stored; the ring moves on by one interval.  The previous frame's additions run while the
+// next frame's spectrum is on its way in.  Two teams per workgroup (the ring takes NI*SLOTS registers on top of the transform's), one
+// workgroup per CU.  Same operations in the same order on the same values as kSynthTeams + kEmit: bit-identical output and carry
+// (test_synth_emit_equals_two_kernels).
+template <int R3, int QN, int SLOTS, bool SPLIT>
+__global__ __launch_bounds__(512) void kSynthEmitTeams(DevBatch d, IoArgs io, int sBase, int tileIndex, int nStreams) {
+	constexpr int TEAMS = 2, MA = 16*R3, H = 256*R3, N = 2*H, NI = QN + 1, DQ = SPLIT ? 1 : 0;
+	extern __shared__ __attribute__((aligned(16))) unsigned char smemRaw[];
+	const int team = __builtin_amdgcn_readfirstlane(threadIdx.x >> 8), t = threadIdx.x & 255;
+	const int B = d.B, halfB = B/2, I = d.I, CL = d.carryLen;
+	float4 *synLds = reinterpret_cast<float4 *>(smemRaw); // (e^{+i pi m/N}, the two window samples of output m)
+	float4 *twALds = synLds + H;
+	float4 *twBLds = twALds + 8*MA;
+	float2 *lds = reinterpret_cast<float2 *>(twBLds + 8*R3) + (size_t)team*(H + H/16);
+	volatile int *words = reinterpret_cast<volatile int *>(reinterpret_cast<float2 *>(twBLds + 8*R3) + (size_t)TEAMS*(H + H/16));
+	for (int i = threadIdx.x; i < H; i += blockDim.x) synLds[i] = d.synTab[i];
+	for (int i = threadIdx.x; i < 8*MA; i += blockDim.x) twALds[i] = d.twA4[i];
+	for (int i = threadIdx.x; i < 8*R3; i += blockDim.x) twBLds[i] = d.twB4[i];
+	if (threadIdx.x < 16) words[threadIdx.x] = 0;
+	__syncthreads();
+	int generation = 0;
+	const TeamSync sync{words + team, &generation};
+	float *ex = reinterpret_cast<float *>(lds); // the frame, B floats, in the transform buffer
+	float steady[SLOTS]; // the window products under a sample that only this tile's frames cover: oldest frame first, as the ring sums them
+#pragma unroll
+	for (int slot = 0; slot < SLOTS; ++slot) {
+		const int r = 256*slot + t;
+		steady[slot] = 1e-30f;
+#pragma unroll
+		for (int a = QN - 1; a >= 0; --a) {
+			if (r < I && a*I + r < B) steady[slot] += d.wprod[a*I + r];
+		}
+		keepUnconditional(steady[slot]);
+	}
+	const int items = nStreams*d.C;
+	for (int item = blockIdx.x*TEAMS + team; item < items; item += gridDim.x*TEAMS) {
+		const int s = item/d.C, c = item - s*d.C, sg = sBase + s;
+		const EmitDesc ed = d.emit[(size_t)sg*d.emitStride + tileIndex];
+		const int cnt = ed.hopCount, span = ed.nHi - ed.nLo;
+		const size_t carryRow = ((size_t)sg*d.C + c)*(size_t)CL;
+		const float *wpOld = d.carryWp[d.carryCur] + (size_t)sg*CL;
+		const float *wpHead = d.wpHead + (size_t)sg*d.wpHeadLen; // (kEmitProducts; it also writes the new carry's products)
+		float *out = io.out + (size_t)sg*io.outStreamStride + (size_t)c*io.outChannelStride;
+		auto carryAt = [&](int i) { return i < CL ? loadCarrySum(d, d.carryCur, carryRow + i) : 0.0f; };
+		auto wpAt = [&](int i) { return i < CL ? wpOld[i] : 1e-30f; };
+		auto place = [&](int n, float sum, float wp) { // output sample n of the call: final, or part of what the next tile starts from
+			if (n < ed.nHi) out[n] = sum/wp;
+			else if (n - ed.nHi < CL) storeCarrySum(d, d.carryCur ^ 1, carryRow + (n - ed.nHi), sum);
+		};
+		if (cnt == 0) { // nothing synthesised for this stream in this tile: the carried sums are emitted / move up
+			for (int i = t; i < span + CL; i += 256) place(ed.nLo + i, carryAt(i), wpAt(i));
+			continue;
+		}
+		const int off = ed.firstHopPos - ed.nLo; // samples in front of the tile's first hop (the first tile of a call only)
+		for (int i = t; i < off; i += 256) place(ed.nLo + i, carryAt(i), wpAt(i));
+		float acc[NI][SLOTS];
+#pragma unroll
+		for (int u = 0; u < NI; ++u) {
+#pragma unroll
+			for (int slot = 0; slot < SLOTS; ++slot) {
+				const int r = 256*slot + t, i = off + u*I + r;
+				acc[u][slot] = r < I ? carryAt(i) : 0.0f;
+			}
+		}
+		// (waited for HERE: a register that is still "being loaded" when the hop loop is entered makes the compiler wait for ALL loads at
+		// its first use inside the loop -- i.e. for the spectrum that was requested just before)
+#pragma unroll
+		for (int u = 0; u < NI; ++u) {
+#pragma unroll
+			for (int slot = 0; slot < SLOTS; ++slot) keepUnconditional(acc[u][slot]);
+		}
+		// frame q - 1 is added to the ring while frame q's spectrum is on its way in, and its finished interval leaves after frame
+		// q's first-stage writes (no store between a load and its use: vmcnt counts both)
+		auto overlapAdd = [&]() {
+			float e[QN][SLOTS]; // all reads in flight together, no branch around any of them
+#pragma unroll
+			for (int a = 0; a < QN; ++a) {
+#pragma unroll
+				for (int slot = 0; slot < SLOTS; ++slot) {
+					const int r = 256*slot + t, i = a*I + r;
+					e[a][slot] = ex[r < I && i < B ? i : 0];
+				}
+			}
+#pragma unroll
+			for (int a = 0; a < QN; ++a) {
+#pragma unroll
+				for (int slot = 0; slot < SLOTS; ++slot) {
+					const int r = 256*slot + t, i = a*I + r;
+					keepUnconditional(e[a][slot]);
+					acc[a + DQ][slot] = (r < I && i < B) ? acc[a + DQ][slot] + e[a][slot] : acc[a + DQ][slot];
+				}
+			}
+		};
+		auto emitInterval = [&](int q) {
+			const int n0 = ed.firstHopPos + q*I;
+			float wp[SLOTS];
+#pragma unroll
+			for (int slot = 0; slot < SLOTS; ++slot) wp[slot] = steady[slot];
+			if (q < NI) { // the carried sums may reach into this interval
+#pragma unroll
+				for (int slot = 0; slot < SLOTS; ++slot) {
+					const int r = 256*slot + t;
+					if (r < I) wp[slot] = wpHead[off + q*I + r];
+				}
+			}
+			if (n0 + I <= ed.nHi) { // (all but a call's last hop)
+#pragma unroll
+				for (int slot = 0; slot < SLOTS; ++slot) {
+					const int r = 256*slot + t;
+					if (r < I) out[n0 + r] = acc[0][slot]/wp[slot];
+				}
+			} else {
+#pragma unroll
+				for (int slot = 0; slot < SLOTS; ++slot) {
+					const int r = 256*slot + t;
+					if (r < I) place(n0 + r, acc[0][slot], wp[slot]);
+				}
+			}
+#pragma unroll
+			for (int u = 0; u + 1 < NI; ++u) {
+#pragma unroll
+				for (int slot = 0; slot < SLOTS; ++slot) acc[u][slot] = acc[u + 1][slot];
+			}
+#pragma unroll
+			for (int slot = 0; slot < SLOTS; ++slot) acc[NI - 1][slot] = 0.0f;
+		};
+		for (int q = 0; q < cnt; ++q) {
+			const float2 *X = d.OUT + rowOf(d, s, q, c);
+			fftFast<+1, R3, false>(lds, twALds, twBLds,
+				[&](int j, int) { const int kk = 2*j; return X[kk >= H ? N - 1 - kk : kk]; }, // one load at a selected address (see kSynthFast) ...
+				[&](int m, int) { return synLds[m]; },
+				[&](int m, float2 u, float4 r, int) {
+					const float2 v = cmulcPlain(u, make_float2(r.x, r.y)); // * e^{+i pi m / N}
+					if (m < B - halfB) ex[m + halfB] = (2*v.x)*r.z;
+					if (m >= H - halfB) ex[m - H + halfB] = (2*v.y)*r.w;
+				}, t, sync, sync,
+				[&]() {
+					if (q > 0) overlapAdd();
+					sync(); // the previous frame has been read (or the previous item's last one), before this transform's first-stage writes
+				},
+				[&]() { if (q > 0) emitInterval(q - 1); },
+				[&](float2 v, int j) { if (2*j >= H) v.y = -v.y; return v; }); // ... conjugated once it is there
+			sync(); // the frame is complete
+		}
+		overlapAdd();
+		sync();
+		emitInterval(cnt - 1);
+		const int n0 = ed.firstHopPos + cnt*I; // what the ring still holds: the start of the next tile's sums
+#pragma unroll
+		for (int u = 0; u < NI; ++u) {
+#pragma unroll
+			for (int slot = 0; slot < SLOTS; ++slot) {
+				const int r = 256*slot + t;
+				if (r < I) place(n0 + u*I + r, acc[u][slot], 1.0f); // (all of it behind the call's last final sample)
+			}
+		}
 	}
 }
 
@@ -3592,7 +3797,7 @@ static inline int divUp(int a, int b) { return (a + b - 1)/b; }
 static std::atomic<long long> gLaunchCounts[LK_COUNT];
 static const char *const kLaunchNames[LK_COUNT] = {
 	"vocoder_aligned", "vocoder_staged", "vocoder_gather", "vocoder_n", "vocoder_one", "vocoder_across", "chain_unfused",
-	"analyse_teams", "analyse_fast", "analyse_generic", "synth_teams", "synth_fast", "synth_generic"};
+	"analyse_teams", "analyse_fast", "analyse_generic", "synth_teams", "synth_fast", "synth_generic", "synth_emit"};
 static inline void countLaunch(LaunchKind k) { gLaunchCounts[k].fetch_add(1, std::memory_order_relaxed); }
 long long launchCount(const char *name) {
 	for (int i = 0; i < LK_COUNT; ++i) if (name && std::strcmp(name, kLaunchNames[i]) == 0) return gLaunchCounts[i].load(std::memory_order_relaxed);
@@ -3873,6 +4078,29 @@ void launchSynth(const DevBatch &d, int sBase, int nStreams, int hopBase, int ti
 	}
 	size_t lds = 2*(size_t)d.M*sizeof(float2);
 	hipLaunchKernelGGL(kSynth, grid, dim3(256), lds, st, d, sBase, hopBase);
+}
+bool launchSynthEmit(const DevBatch &d, const IoArgs &io, int sBase, int nStreams, int tileHops, int tileIndex, hipStream_t st) {
+	if (d.noFastFft || !d.fftTeams || d.fftLean || !d.synthEmit || !(d.M == 256*10 || d.M == 256*12)) return false;
+	if (!(d.delta == 0 || d.delta == d.I)) return false;
+	const int QN = d.M == 256*10 ? 3 : 4, SLOTS = d.M == 256*10 ? 8 : 6; // the presets' block / interval ratios (2.5 and 4)
+	if (QN*d.I < d.B || d.I > 256*SLOTS || d.B > d.N) return false;
+	// one (stream, channel) per team, its hops in sequence: worth it only where that fills the chip's two teams per CU in whole rounds
+	const int items = nStreams*d.C, slots = 2*d.teamsGrid, rounds = divUp(items, slots);
+	if (d.synthEmit != 2 && (tileHops < 8 || 4*items < 3*rounds*slots)) return false;
+	const int wgs = std::min(divUp(items, 2), d.teamsGrid);
+	const size_t fastLds = ((size_t)d.M + d.M/16)*sizeof(float2);
+	const size_t lds = ((size_t)d.M + d.M/2 + d.M/32)*sizeof(float4) + 2*fastLds + 64;
+	const bool split = d.delta != 0;
+	hipLaunchKernelGGL(kEmitProducts, dim3(divUp(d.wpHeadLen + d.carryLen, 256), nStreams), dim3(256), 0, st, d, sBase, tileIndex);
+	if (d.M == 256*10) {
+		if (split) hipLaunchKernelGGL((kSynthEmitTeams<10, 3, 8, true>), dim3(wgs), dim3(512), lds, st, d, io, sBase, tileIndex, nStreams);
+		else hipLaunchKernelGGL((kSynthEmitTeams<10, 3, 8, false>), dim3(wgs), dim3(512), lds, st, d, io, sBase, tileIndex, nStreams);
+	} else {
+		if (split) hipLaunchKernelGGL((kSynthEmitTeams<12, 4, 6, true>), dim3(wgs), dim3(512), lds, st, d, io, sBase, tileIndex, nStreams);
+		else hipLaunchKernelGGL((kSynthEmitTeams<12, 4, 6, false>), dim3(wgs), dim3(512), lds, st, d, io, sBase, tileIndex, nStreams);
+	}
+	countLaunch(LK_SYNTH_EMIT);
+	return true;
 }
 void launchEmit(const DevBatch &d, const IoArgs &io, int sBase, int nStreams, int tileIndex, int maxSpan, hipStream_t st) {
 	hipLaunchKernelGGL(kEmit, dim3(divUp(divUp(maxSpan + d.carryLen, 4), 256), d.C, nStreams), dim3(256), 0, st, d, io, sBase, tileIndex);

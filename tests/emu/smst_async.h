@@ -13,5 +13,6 @@ static inline void asyncArrived(Async16 &) {}
 static inline void asyncArrived(Async8 &) {}
 static inline float4 asyncValue(const Async16 &r) { return r.v; }
 static inline float2 asyncValue(const Async8 &r) { return r.v; }
+static inline void keepUnconditional(float &) {}
 
 } // namespace smst

@@ -988,6 +988,42 @@ def case_fft_teams_equals_per_frame(lib, monkeypatch, presets=(("cheaper", 48000
         assert np.array_equal(outs[0], outs[1]), (preset, sr, float(np.abs(outs[0] - outs[1]).max()))
 
 
+def case_synth_emit_equals_two_kernels(lib, monkeypatch, presets=(("cheaper", 48000), ("default", 48000)), seconds=0.6, streams=3, channels=2,
+                                       splits=(False, True), half_state=False):
+    """Synthesis + overlap-add + emission in one kernel (kSynthEmitTeams: the overlap-add ring in a team's registers, no frames in
+    HBM) against kSynthTeams + kEmit: the same values added in the same order, so output AND carried sums are bit-identical -- over
+    three calls with ragged lengths (the second and third start from the carry the first left; the last one is short, so a stream
+    ends inside a tile), with and without split computation (the frame lands one interval later), then a flush of what the ring holds."""
+    pkg = package()
+    for preset, sr in presets:
+        n = int(seconds*sr)
+        x = np.stack([synth_input(s, channels, n, sr) for s in range(streams)])
+        for split in splits:
+            outs = []
+            for fusedKernel in (True, False):
+                monkeypatch.setenv("SMST_FFT_TEAMS", "2")
+                monkeypatch.setenv("SMST_SYNTH_EMIT", "2" if fusedKernel else "0")
+                names = ("synth_emit", "synth_teams")
+                counts = [pkg.launch_count(k, lib) for k in names]
+                b = pkg.StretchBatch(streams, channels, preset=preset, sample_rate=sr, split=split, lib=lib, **({"half_state": True} if half_state else {}))
+                b.setTransposeSemitones(4.0, 0.2, stream=1)
+                c1, c2 = n//2, n*5//6
+                n_in = np.array([c1 - 17*s for s in range(streams)], np.int32)
+                y1 = np.array(b.process(np.ascontiguousarray(x[:, :, :c1]), (n_in*1.4).astype(np.int32), in_samples=n_in), copy=True)
+                y2 = np.array(b.process(np.ascontiguousarray(x[:, :, c1:c2]), int((c2 - c1)*0.8)), copy=True)
+                n_in3 = np.array([max(64, (n - c2) - 301*s) for s in range(streams)], np.int32)
+                y3 = np.array(b.process(np.ascontiguousarray(x[:, :, c2:]), (n_in3*1.1).astype(np.int32), in_samples=n_in3), copy=True)
+                tail = np.array(b.flush(b.outputLatency() + 100), copy=True)
+                b.close()
+                outs.append(np.concatenate([y1, y2, y3, tail], axis=2))
+                grew = [pkg.launch_count(k, lib) - c for k, c in zip(names, counts)]
+                assert (grew[0] > 0 and grew[1] == 0) if fusedKernel else (grew[0] == 0 and grew[1] > 0), (fusedKernel, grew)
+            monkeypatch.delenv("SMST_FFT_TEAMS", raising=False)
+            monkeypatch.delenv("SMST_SYNTH_EMIT", raising=False)
+            assert np.abs(outs[0]).max() > 0.05
+            assert np.array_equal(outs[0], outs[1]), (preset, sr, split, float(np.abs(outs[0] - outs[1]).max()))
+
+
 def case_clone(lib):
     """smst_clone (the drop-in's copy constructor): the copy continues exactly as the original does, and independently of it."""
     pkg = package()

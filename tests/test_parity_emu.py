@@ -169,6 +169,11 @@ def test_fft_teams_equals_per_frame_emu(emu, monkeypatch):
     pc.case_fft_teams_equals_per_frame(emu, monkeypatch, presets=(("default", 44100),), seconds=0.4, streams=2)
 
 
+def test_synth_emit_equals_two_kernels_emu(emu, monkeypatch):
+    pc.case_synth_emit_equals_two_kernels(emu, monkeypatch, presets=(("cheaper", 48000),), seconds=0.45, streams=3)
+    pc.case_synth_emit_equals_two_kernels(emu, monkeypatch, presets=(("default", 44100),), seconds=0.4, streams=2, channels=1, splits=(True,))
+
+
 def test_hop_magnitudes_per_stream_parameters_small(emu, ref):
     """The per-stream form of the phase-free instrument (every stream its own stretch factor and transposition, ragged input spans in
     one batched call) at the small geometry, 3 channels, split mode -- the GPU suite runs it on BASELINE config 5 as named."""

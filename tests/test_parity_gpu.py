@@ -607,6 +607,13 @@ def test_reconfigure_keeps_random_engine(hip, ref):
     pc.case_reconfigure_keeps_random_engine(hip, ref)
 
 
+def test_synth_emit_equals_two_kernels(hip, monkeypatch):
+    """kSynthEmitTeams against kSynthTeams + kEmit: output and carry bit-identical."""
+    pc.case_synth_emit_equals_two_kernels(hip, monkeypatch, presets=(("cheaper", 48000), ("default", 48000), ("default", 44100), ("cheaper", 44100)), streams=5)
+    pc.case_synth_emit_equals_two_kernels(hip, monkeypatch, presets=(("default", 48000),), streams=3, channels=1)
+    pc.case_synth_emit_equals_two_kernels(hip, monkeypatch, presets=(("default", 48000),), streams=2, channels=2, splits=(False,), half_state=True)
+
+
 def test_fft_teams_equals_per_frame(hip, monkeypatch):
     """kAnalyseTeams (SMST_FFT_TEAMS=1) against kAnalyseFast: bit-identical."""
     pc.case_fft_teams_equals_per_frame(hip, monkeypatch, presets=(("cheaper", 48000), ("default", 48000), ("default", 44100)), streams=5)
