@@ -445,6 +445,10 @@ def main():
                  "chain": "kVocoder" if C <= 2 else "kVocoderN",
                  "synth": "kSynthTeams" if teams else ("kSynthFast" if M in (5120, 6144, 2560, 3072) else "kSynth"), "emit": "kEmit"}
         launch_count = {k: launches[k] for k in ("analyse", "predict", "chain", "synth", "emit")}
+        one_kernel = teams and launch_count["emit"] == 0 and launch_count["synth"] > 0  # synthesis + overlap-add + emission in kSynthEmitTeams
+        if one_kernel:
+            names["synth"] = "kSynthEmitTeams"
+
         dom = max(launch_count, key=lambda k: ms[k])  # the class with the largest stand-alone time per step
         avg_ms_alone = ms[dom]/max(launch_count[dom], 1) or float("nan")
         avg_ms_in_place = avg_ms_alone
@@ -463,7 +467,7 @@ def main():
         traffic, traffic_source = measured_traffic(sha, args.config)
         per_class = {}
         rows = [("analyse", names["analyse"], ms["analyse"], launch_count["analyse"]), ("chain", names["chain"], ms["chain"], launch_count["chain"]),
-                ("synth+emit", names["synth"] + " + kEmit", ms["synth"] + ms["emit"], launch_count["synth"])]
+                ("synth+emit", names["synth"] + ("" if one_kernel else " + kEmit"), ms["synth"] + ms["emit"], launch_count["synth"])]
         for key, label, alone, count in rows:
             if count:
                 per_class[label] = dict(ms_per_step_alone=round(alone, 3), launches_per_step=count, own_algorithmic_bytes_per_channel_hop=own[key],

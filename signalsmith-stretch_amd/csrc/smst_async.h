@@ -21,16 +21,22 @@ typedef float async_f4 __attribute__((ext_vector_type(4)));
 typedef float async_f2 __attribute__((ext_vector_type(2)));
 struct Async16 { async_f4 v; };
 struct Async8 { async_f2 v; };
+struct Async4 { float v; };
 
 __device__ __forceinline__ void asyncLoad16(Async16 &r, const void *p) { asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(r.v) : "v"(p) : "memory"); }
 __device__ __forceinline__ void asyncLoad8(Async8 &r, const void *p) { asm volatile("global_load_dwordx2 %0, %1, off" : "=&v"(r.v) : "v"(p) : "memory"); }
+__device__ __forceinline__ void asyncLoad4(Async4 &r, const void *p) { asm volatile("global_load_dword %0, %1, off" : "=&v"(r.v) : "v"(p) : "memory"); }
+__device__ __forceinline__ void asyncClear(Async8 &r) { r.v = 0.0f; } // (a defined value for lanes that never request)
 template <int N> __device__ __forceinline__ void asyncWait() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
 __device__ __forceinline__ void asyncArrived(Async16 &r) { asm volatile("" : "+v"(r.v)); }
 __device__ __forceinline__ void asyncArrived(Async8 &r) { asm volatile("" : "+v"(r.v)); }
+__device__ __forceinline__ void asyncArrived(Async4 &r) { asm volatile("" : "+v"(r.v)); }
+__device__ __forceinline__ float asyncValue(const Async4 &r) { return r.v; }
 __device__ __forceinline__ float4 asyncValue(const Async16 &r) { return make_float4(r.v.x, r.v.y, r.v.z, r.v.w); }
 __device__ __forceinline__ float2 asyncValue(const Async8 &r) { return make_float2(r.v.x, r.v.y); }
 // An empty statement that "uses and redefines" x: what produced x can no longer be sunk into a later conditional (the compiler turns
 // `c ? a + lds[i] : a` into a branch around the read and waits for every read on its own: 24 LDS round trips in sequence).
 __device__ __forceinline__ void keepUnconditional(float &x) { asm volatile("" : "+v"(x)); }
+__device__ __forceinline__ void keepUnconditional(int &x) { asm volatile("" : "+v"(x)); }
 
 } // namespace smst

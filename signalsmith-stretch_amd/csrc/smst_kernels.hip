@@ -372,7 +372,7 @@ struct NoArrival { __device__ __forceinline__ float2 operator()(float2 v, int) c
 // stage's operands have left `lds` (a barrier there lets `store` write into the same buffer); requested() once the frame's loads have
 // been issued and before anything is written to `lds` (the previous frame's overlap-add runs under the loads' latency), firstWritten()
 // after the first stage's writes
-template <int SIGN, int R3, bool LEAN, typename Load, typename Prep, typename Store, typename Sync = BlockSync, typename LastRead = NoHook,
+template <int SIGN, int R3, bool LEAN, int ROUNDS = 0, typename Load, typename Prep, typename Store, typename Sync = BlockSync, typename LastRead = NoHook,
           typename Requested = NoHook, typename FirstWritten = NoHook, typename Arrived = NoArrival>
 __device__ __forceinline__ void fftFast(float2 *lds, const float4 *__restrict__ twA, const float4 *__restrict__ twB, Load load, Prep prep, Store store,
                                         const int t = threadIdx.x, Sync sync = Sync(), LastRead lastRead = LastRead(), Requested requested = Requested(),
@@ -454,7 +454,7 @@ __device__ __forceinline__ void fftFast(float2 *lds, const float4 *__restrict__ 
 #pragma unroll
 		for (int k = 0; k < R3; ++k) u[k] = lds[t + 256*k];
 		lastRead();
-		constexpr int CHUNK = R3 <= 12 ? R3 : (R3 == 24 ? 6 : 5); // outputs prepared ahead of their stores (R3 = 20 / 24: four rounds, or the registers cost a wave of occupancy)
+		constexpr int CHUNK = ROUNDS ? R3/ROUNDS : (R3 <= 12 ? R3 : (R3 == 24 ? 6 : 5)); // outputs prepared ahead of their stores (R3 = 20 / 24: four rounds, or the registers cost a wave of occupancy; ROUNDS: the caller's choice)
 		decltype(prep(0, 0)) ready[CHUNK];
 #pragma unroll
 		for (int i = 0; i < CHUNK; ++i) { // the first round's loads fly during the butterflies
@@ -845,11 +845,13 @@ __global__ __launch_bounds__(512) void kSynthEmitTeams(DevBatch d, IoArgs io, in
 		// q's first-stage writes (no store between a load and its use: vmcnt counts both)
 		auto overlapAdd = [&]() {
 			float e[QN][SLOTS]; // all reads in flight together, no branch around any of them
+			int tt = t;
+			keepUnconditional(tt); // (the 24 addresses are formed here, per hop: held across the loop they cost the registers the next spectrum needs)
 #pragma unroll
 			for (int a = 0; a < QN; ++a) {
 #pragma unroll
 				for (int slot = 0; slot < SLOTS; ++slot) {
-					const int r = 256*slot + t, i = a*I + r;
+					const int r = 256*slot + tt, i = a*I + r;
 					e[a][slot] = ex[r < I && i < B ? i : 0];
 				}
 			}
@@ -868,11 +870,18 @@ __global__ __launch_bounds__(512) void kSynthEmitTeams(DevBatch d, IoArgs io, in
 			float wp[SLOTS];
 #pragma unroll
 			for (int slot = 0; slot < SLOTS; ++slot) wp[slot] = steady[slot];
-			if (q < NI) { // the carried sums may reach into this interval
+			if (q < NI) { // the carried sums may reach into this interval (loads of the kernel's own here too: see `next`)
+				Async4 head[SLOTS];
 #pragma unroll
 				for (int slot = 0; slot < SLOTS; ++slot) {
 					const int r = 256*slot + t;
-					if (r < I) wp[slot] = wpHead[off + q*I + r];
+					asyncLoad4(head[slot], wpHead + (r < I ? off + q*I + r : 0));
+				}
+				asyncWait<0>();
+#pragma unroll
+				for (int slot = 0; slot < SLOTS; ++slot) {
+					asyncArrived(head[slot]);
+					if (256*slot + t < I) wp[slot] = asyncValue(head[slot]);
 				}
 			}
 			if (n0 + I <= ed.nHi) { // (all but a call's last hop)
@@ -896,10 +905,29 @@ __global__ __launch_bounds__(512) void kSynthEmitTeams(DevBatch d, IoArgs io, in
 #pragma unroll
 			for (int slot = 0; slot < SLOTS; ++slot) acc[NI - 1][slot] = 0.0f;
 		};
-		for (int q = 0; q < cnt; ++q) {
+		// frame q + 1's spectrum is requested as soon as frame q's first stage has taken its own out of the registers
+		// (loads the kernel waits for itself, smst_async.h: a compiler-tracked load whose value crosses the loop's back-edge makes the
+		// compiler wait for EVERYTHING at the next barrier's counter update, i.e. right behind the request)
+		Async8 next[16];
+#pragma unroll
+		for (int k = 0; k < 16; ++k) asyncClear(next[k]);
+		auto request = [&](int q) {
 			const float2 *X = d.OUT + rowOf(d, s, q, c);
-			fftFast<+1, R3, false>(lds, twALds, twBLds,
-				[&](int j, int) { const int kk = 2*j; return X[kk >= H ? N - 1 - kk : kk]; }, // one load at a selected address (see kSynthFast) ...
+			if (t < MA) {
+#pragma unroll
+				for (int k = 0; k < 16; ++k) { const int kk = 2*(t + MA*k); asyncLoad8(next[k], X + (kk >= H ? N - 1 - kk : kk)); } // one load at a selected address (see kSynthFast) ...
+			}
+		};
+		auto landed = [&]() { // at the END of a hop, in front of the back-edge: nothing of the compiler's may touch a register in flight
+			asyncWait<0>();
+#pragma unroll
+			for (int k = 0; k < 16; ++k) asyncArrived(next[k]);
+		};
+		request(0);
+		landed();
+		for (int q = 0; q < cnt; ++q) {
+			fftFast<+1, R3, false, 2>(lds, twALds, twBLds, // (two rounds of prepared outputs: the ring and the next spectrum need the registers)
+				[&](int, int k) { return asyncValue(next[k]); },
 				[&](int m, int) { return synLds[m]; },
 				[&](int m, float2 u, float4 r, int) {
 					const float2 v = cmulcPlain(u, make_float2(r.x, r.y)); // * e^{+i pi m / N}
@@ -910,9 +938,13 @@ __global__ __launch_bounds__(512) void kSynthEmitTeams(DevBatch d, IoArgs io, in
 					if (q > 0) overlapAdd();
 					sync(); // the previous frame has been read (or the previous item's last one), before this transform's first-stage writes
 				},
-				[&]() { if (q > 0) emitInterval(q - 1); },
+				[&]() {
+					if (q > 0) emitInterval(q - 1);
+					request(q + 1 < cnt ? q + 1 : q);
+				},
 				[&](float2 v, int j) { if (2*j >= H) v.y = -v.y; return v; }); // ... conjugated once it is there
 			sync(); // the frame is complete
+			landed();
 		}
 		overlapAdd();
 		sync();
@@ -4084,9 +4116,10 @@ bool launchSynthEmit(const DevBatch &d, const IoArgs &io, int sBase, int nStream
 	if (!(d.delta == 0 || d.delta == d.I)) return false;
 	const int QN = d.M == 256*10 ? 3 : 4, SLOTS = d.M == 256*10 ? 8 : 6; // the presets' block / interval ratios (2.5 and 4)
 	if (QN*d.I < d.B || d.I > 256*SLOTS || d.B > d.N) return false;
-	// one (stream, channel) per team, its hops in sequence: worth it only where that fills the chip's two teams per CU in whole rounds
-	const int items = nStreams*d.C, slots = 2*d.teamsGrid, rounds = divUp(items, slots);
-	if (d.synthEmit != 2 && (tileHops < 8 || 4*items < 3*rounds*slots)) return false;
+	// one (stream, channel) per team, its hops in sequence.  Measured on 256 CUs (profiles/r4_synth_emit_sweep.txt): ahead of the two
+	// kernels from 32 stereo streams on, at every batch size up to 1024 -- also where the last round of teams is mostly empty
+	const int items = nStreams*d.C;
+	if (d.synthEmit != 2 && (tileHops < 8 || items < 64)) return false;
 	const int wgs = std::min(divUp(items, 2), d.teamsGrid);
 	const size_t fastLds = ((size_t)d.M + d.M/16)*sizeof(float2);
 	const size_t lds = ((size_t)d.M + d.M/2 + d.M/32)*sizeof(float4) + 2*fastLds + 64;

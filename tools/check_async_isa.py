@@ -5,8 +5,8 @@ inline-assembly load is pending, so a register copy it inserts on its own (a loo
 body, a live-range split) would read garbage -- seen once, in the first version of vocoderProduceAligned.
 
 Method: per function, basic blocks and their successors from the labels and branches; forward data flow of the ORDERED list of
-outstanding vector-memory operations (loads with their destination registers, stores as place holders: vmcnt counts both and
-retires in order); `s_waitcnt vmcnt(N)` keeps the N youngest.  At a join the longer list wins if the shorter one is its suffix,
+outstanding vector-memory operations (inline-assembly loads with their destination registers; the compiler's own loads, which it
+waits for itself, and stores as place holders: vmcnt counts them all and retires in order); `s_waitcnt vmcnt(N)` keeps the N youngest.  At a join the longer list wins if the shorter one is its suffix,
 otherwise the two are concatenated (conservative).  Any VGPR operand that belongs to an outstanding load is reported.
 
 usage: tools/check_async_isa.py <file.s> [substring of the mangled kernel names to check ...]   exit status 1 if a hazard is found."""
@@ -61,7 +61,12 @@ def join(a, b):
 
 def check_function(name, body, path):
     blocks, labels, cur = [], {}, []
+    in_asm = False
     for ln, line in body:
+        if "#ASMSTART" in line:
+            in_asm = True
+        elif "#ASMEND" in line:
+            in_asm = False
         text = line.split(";")[0].strip()
         if not text:
             continue
@@ -74,7 +79,7 @@ def check_function(name, body, path):
             continue
         if text.startswith("."):
             continue
-        cur.append((ln, text))
+        cur.append((ln, text, in_asm))
         if text.split()[0] in ("s_branch", "s_endpgm") or text.startswith("s_cbranch"):
             blocks.append(cur)
             cur = []
@@ -104,7 +109,7 @@ def check_function(name, body, path):
         rounds += 1
         i = work.pop()
         st = list(state_in[i])
-        for ln, text in blocks[i]:
+        for ln, text, from_asm in blocks[i]:
             parts = text.replace(",", " ").split()
             op, args = parts[0], parts[1:]
             if op == "s_waitcnt":
@@ -119,7 +124,9 @@ def check_function(name, body, path):
             if hit:
                 hazards[ln] = "%s:%d: %s: %s touches registers %s of a load that may still be in flight" % (path, ln, name[:60], text, sorted(hit))
             if op.startswith(("global_load", "buffer_load", "flat_load", "scratch_load")):
-                st.append(regs(args[0]))
+                # only the kernel's own (inline-assembly) loads can be touched too early: the compiler waits for the ones it tracks,
+                # which still take their place in the order vmcnt retires in
+                st.append(regs(args[0]) if from_asm else frozenset())
             elif op.startswith(("global_store", "buffer_store", "flat_store", "global_atomic", "scratch_store")):
                 st.append(frozenset())
             st = st[-CAP:]
@@ -148,7 +155,7 @@ def scratch_users(path, wanted):
 
 
 if __name__ == "__main__":
-    wanted = sys.argv[2:] or ["ELb1ELb0ELb0ELb1EEEv"]  # kVocoder<..., ALIGNED = true>
+    wanted = sys.argv[2:] or ["ELb1ELb0ELb0ELb1EEEv", "15kSynthEmitTeams"]  # kVocoder<..., ALIGNED = true>, kSynthEmitTeams
     total = 0
     checked = 0
     for name, size in scratch_users(sys.argv[1], wanted):
