@@ -18,6 +18,11 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# The engine pipelines a step over three HIP streams (+ one for its tables); HIP maps streams onto GPU_MAX_HW_QUEUES hardware queues
+# (default 4), and two pipeline streams that share a queue run in submission order.  An RCCL communicator brings streams of its own:
+# with the default, the same step took 15.8 instead of 14.0 ms once torch.distributed was initialised (profiles/r4_hw_queues.txt).
+# Set before the HIP runtime starts (INTEGRATION.md says the same to applications).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 SR = 48000
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md

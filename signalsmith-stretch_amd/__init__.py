@@ -15,6 +15,9 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
+# The engine's three pipeline streams must not share a hardware queue with each other ("Hardware queues"): effective
+# only if the HIP runtime has not started yet -- import this package (or set the variable) before the first torch.cuda / HIP call.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 # SMST_LIBRARY: measurement hook of bench.py / tools/ -- another BUILD of the same library (an A/B variant, an instrumented trace
 # build under variants/), never another implementation; unset in every product use, and announced on stderr when set.  A build that
 # lacks entry points of include/smst.h is refused at load unless SMST_LIBRARY_ALLOW_MISSING=1 (A/B against an older revision).
