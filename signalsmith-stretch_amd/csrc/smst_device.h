@@ -126,7 +126,11 @@ bool acrossSupported(const DevBatch &d);
 void launchVocoderAcross(const DevBatch &d, int sBase, int nStreams, int hopBase, bool plain, hipStream_t st); // the same tiles, mono / stereo: lanes of the recurrence wave = streams
 void launchSynth(const DevBatch &d, int sBase, int nStreams, int hopBase, int tileHops, hipStream_t st);
 void launchEmit(const DevBatch &d, const IoArgs &io, int sBase, int nStreams, int tileIndex, int maxSpan, hipStream_t st);
-bool launchSynthEmit(const DevBatch &d, const IoArgs &io, int sBase, int nStreams, int tileHops, int tileIndex, hipStream_t st); // false: not applicable, nothing launched
+// synthesis + overlap-add + emission in one kernel: whether it applies to a tile; its window products (needs nothing of the tile's
+// spectra: launched ahead of the recurrence's completion); the kernel itself
+bool synthEmitApplies(const DevBatch &d, int nStreams, int tileHops);
+void launchEmitProducts(const DevBatch &d, int sBase, int nStreams, int tileIndex, hipStream_t st);
+void launchSynthEmit(const DevBatch &d, const IoArgs &io, int sBase, int nStreams, int tileIndex, hipStream_t st);
 void launchCarryFeed(const DevBatch &d, int sBase, int nStreams, int hopBase, bool anyFormants, hipStream_t st);
 void launchCarryOut(const DevBatch &d, int sBase, int nStreams, hipStream_t st);
 void launchHistory(const DevBatch &d, const IoArgs &io, hipStream_t st);

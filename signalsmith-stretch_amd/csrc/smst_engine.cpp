@@ -962,14 +962,17 @@ void Batch::process(const float *in, long long inSS, long long inCS, const int *
 				});
 			}
 			checkLaunch("bin recurrence");
+			// synthesis + overlap-add + emission in one kernel where the geometry and the batch allow it; its window products depend on
+			// nothing the recurrence writes: queued in front of the wait for it
+			const bool emitted = th[0] && synthEmitApplies(dd, ns, tileHops);
+			if (emitted) timed(timings.otherMs, [&] { launchEmitProducts(dd, sBase, ns, t, sS); });
 			if (!serial) {
 				SMST_HIP(hipEventRecord(evChain[slot], sC));
 				SMST_HIP(hipStreamWaitEvent(sS, evChain[slot], 0));
 			}
-			bool emitted = false; // synthesis + overlap-add + emission in one kernel where the geometry and the batch allow it
 			if (th[0]) timed(timings.synthMs, [&] {
-				emitted = launchSynthEmit(dd, io, sBase, ns, tileHops, t, sS);
-				if (!emitted) launchSynth(dd, sBase, ns, hopBase, tileHops, sS);
+				if (emitted) launchSynthEmit(dd, io, sBase, ns, t, sS);
+				else launchSynth(dd, sBase, ns, hopBase, tileHops, sS);
 				if (profiling) ++timings.synthLaunches;
 			});
 			if (!emitted) timed(timings.emitMs, [&] { launchEmit(dd, io, sBase, ns, t, maxSpanV[(size_t)sub*nTiles + t], sS); if (profiling) ++timings.emitLaunches; });

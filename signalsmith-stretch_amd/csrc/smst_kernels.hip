@@ -4111,20 +4111,24 @@ void launchSynth(const DevBatch &d, int sBase, int nStreams, int hopBase, int ti
 	size_t lds = 2*(size_t)d.M*sizeof(float2);
 	hipLaunchKernelGGL(kSynth, grid, dim3(256), lds, st, d, sBase, hopBase);
 }
-bool launchSynthEmit(const DevBatch &d, const IoArgs &io, int sBase, int nStreams, int tileHops, int tileIndex, hipStream_t st) {
+bool synthEmitApplies(const DevBatch &d, int nStreams, int tileHops) {
 	if (d.noFastFft || !d.fftTeams || d.fftLean || !d.synthEmit || !(d.M == 256*10 || d.M == 256*12)) return false;
 	if (!(d.delta == 0 || d.delta == d.I)) return false;
 	const int QN = d.M == 256*10 ? 3 : 4, SLOTS = d.M == 256*10 ? 8 : 6; // the presets' block / interval ratios (2.5 and 4)
 	if (QN*d.I < d.B || d.I > 256*SLOTS || d.B > d.N) return false;
 	// one (stream, channel) per team, its hops in sequence.  Measured on 256 CUs (profiles/r4_synth_emit_sweep.txt): ahead of the two
 	// kernels from 32 stereo streams on, at every batch size up to 1024 -- also where the last round of teams is mostly empty
+	return d.synthEmit == 2 || (tileHops >= 8 && nStreams*d.C >= 64);
+}
+void launchEmitProducts(const DevBatch &d, int sBase, int nStreams, int tileIndex, hipStream_t st) {
+	hipLaunchKernelGGL(kEmitProducts, dim3(divUp(d.wpHeadLen + d.carryLen, 256), nStreams), dim3(256), 0, st, d, sBase, tileIndex);
+}
+void launchSynthEmit(const DevBatch &d, const IoArgs &io, int sBase, int nStreams, int tileIndex, hipStream_t st) {
 	const int items = nStreams*d.C;
-	if (d.synthEmit != 2 && (tileHops < 8 || items < 64)) return false;
 	const int wgs = std::min(divUp(items, 2), d.teamsGrid);
 	const size_t fastLds = ((size_t)d.M + d.M/16)*sizeof(float2);
 	const size_t lds = ((size_t)d.M + d.M/2 + d.M/32)*sizeof(float4) + 2*fastLds + 64;
 	const bool split = d.delta != 0;
-	hipLaunchKernelGGL(kEmitProducts, dim3(divUp(d.wpHeadLen + d.carryLen, 256), nStreams), dim3(256), 0, st, d, sBase, tileIndex);
 	if (d.M == 256*10) {
 		if (split) hipLaunchKernelGGL((kSynthEmitTeams<10, 3, 8, true>), dim3(wgs), dim3(512), lds, st, d, io, sBase, tileIndex, nStreams);
 		else hipLaunchKernelGGL((kSynthEmitTeams<10, 3, 8, false>), dim3(wgs), dim3(512), lds, st, d, io, sBase, tileIndex, nStreams);
@@ -4133,7 +4137,6 @@ bool launchSynthEmit(const DevBatch &d, const IoArgs &io, int sBase, int nStream
 		else hipLaunchKernelGGL((kSynthEmitTeams<12, 4, 6, false>), dim3(wgs), dim3(512), lds, st, d, io, sBase, tileIndex, nStreams);
 	}
 	countLaunch(LK_SYNTH_EMIT);
-	return true;
 }
 void launchEmit(const DevBatch &d, const IoArgs &io, int sBase, int nStreams, int tileIndex, int maxSpan, hipStream_t st) {
 	hipLaunchKernelGGL(kEmit, dim3(divUp(divUp(maxSpan + d.carryLen, 4), 256), d.C, nStreams), dim3(256), 0, st, d, io, sBase, tileIndex);
