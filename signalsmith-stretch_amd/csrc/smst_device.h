@@ -38,7 +38,7 @@ struct DevBatch {
 	const float4 *win4;        // (winA[m], winB[m]) interleaved: one 16-byte load per element in the fast analysis kernel
 	const float4 *synTab;      // (halfTw[m], window[m+B/2] or 0, window[m-M+B/2] or 0): one 16-byte load per synthesis output
 	const float4 *twA4, *twB4; // stage twiddles of the register-blocked FFT, rows (2i, 2i+1) paired: [8][16*R3], [8][R3]
-	const unsigned *lcgPow;    // 16807^(j+1) mod (2^31 - 1), j < 2M: jump-ahead factors of the reference's random engine (smst_kernels.hip: engineDraw)
+	const unsigned *lcgPow;    // 16807^(j+1) mod (2^31 - 1), j < 2M: jump-ahead factors of the reference's random engine (smst_kernels_common.h: engineDraw)
 	const float4 *twA6;        // lean form of twA4: (w^1, w^2), (w^3, w^4), (w^8, w^12) per thread, [3][16*R3]
 	const float2 *win2, *syn2; // lean forms of win4 / synTab: the two window samples of an element only, [M]
 	const float *window;   // analysis == synthesis window (Kaiser, perfect reconstruction)

@@ -317,7 +317,7 @@ void Batch::construct(const FftPlan &plan, long seed) {
 	d.stInput = devAlloc<float2>(bandRows);
 	d.stPrev = devAlloc<float2>(bandRows);
 	// carried state that the fp16 option narrows (the typed pointers then address half-sized allocations; every access goes
-	// through the accessors at the top of smst_kernels.hip)
+	// through the accessors at the top of smst_kernels_common.h)
 	const size_t stateScale = halfState ? 2 : 1;
 	d.stOut = reinterpret_cast<float2 *>(devAlloc<unsigned char>(bandRows*sizeof(float2)/stateScale));
 	d.stEnergy = reinterpret_cast<float *>(devAlloc<unsigned char>(bandRows*sizeof(float)/stateScale));
@@ -359,7 +359,7 @@ void Batch::construct(const FftPlan &plan, long seed) {
 
 	sched.assign(S, StreamSched());
 	lastHop.assign(S, LastHop());
-	// std::default_random_engine (libstdc++: minstd_rand0) of a reference instance constructed with seed + s (:39; smst_kernels.hip: engineDraw)
+	// std::default_random_engine (libstdc++: minstd_rand0) of a reference instance constructed with seed + s (:39; smst_kernels_common.h: engineDraw)
 	for (int s = 0; s < S; ++s) {
 		const unsigned long long u = (unsigned long long)(seed + s); // `long` -> the engine's unsigned 64-bit result_type
 		sched[s].seed = unsigned(u % 2147483647ull);

@@ -17,7 +17,7 @@ struct StreamSched { // reference members: signalsmith-stretch.h:494-529
 	float seekTimeFactor = 1;           // :529
 	size_t silenceCounter = 0;          // :510
 	bool silenceFirst = true;           // :511
-	unsigned seed = 0;                  // randomEngine, :616 -- the state of libstdc++'s minstd_rand0 (smst_kernels.hip: engineDraw)
+	unsigned seed = 0;                  // randomEngine, :616 -- the state of libstdc++'s minstd_rand0 (smst_kernels_common.h: engineDraw)
 };
 
 struct BatchTimings { // filled when profiling is enabled (hipEvent pairs around each kernel class)

@@ -152,7 +152,7 @@ def case_random_call_sequences(lib, ref, seeds=range(6), cfg=SMALL, calls=14):
     of up to 2.3 intervals, reset() -- replayed on the product, the checker and the perturbed checkers (check_scenario).  Short walks (a
     few dozen hops), so the sample-domain comparison stays informative; 1-3 channels.  Stretches beyond 2x (output without input, long
     flushes, the first hop after a start or reset) draw random time factors: product and checker are constructed with the same seed
-    and the product replicates the checker's std::default_random_engine (smst_kernels.hip: engineDraw), so they stay comparable."""
+    and the product replicates the checker's std::default_random_engine (smst_kernels_common.h: engineDraw), so they stay comparable."""
     sr = 48000
     seeds = list(seeds)
     uninformative = []
@@ -510,7 +510,7 @@ def case_random_time_factor_seeds(lib, ref, cfg=None, streams=8, stretch=2.5, se
 def case_random_time_factor_parity(lib, ref, geometries=(SMALL,), seeds=(0, 12345, -7)):
     """Beyond 2x the reference draws a time factor per bin and direction from std::default_random_engine (:639-640, :749, :769) --
     implementation-defined in general, but defined for the checker (g++ / libstdc++: minstd_rand0 through
-    uniform_real_distribution<float>), and the product replicates exactly that engine (smst_kernels.hip: engineDraw; the host advances
+    uniform_real_distribution<float>), and the product replicates exactly that engine (smst_kernels_common.h: engineDraw; the host advances
     every stream's engine state by 2M - 2 draws per randomised hop).  So with the same seed the SAMPLES are comparable: teacher-forced
     single hops at 2.5x, free-running 2.5x and 4x over short horizons, output without input, and a flush of several intervals."""
     worst = {}
