@@ -26,7 +26,8 @@
  * return SMST_ERR_INVALID with the limit in smst_last_error() beyond them:
  *   - 1 ... 8 channels per stream (the bin recurrence keeps one lane's channels in registers / one LDS ring per channel);
  *   - fftSamples/2 = 2^k * {1, 3, 5} bands (the reference's own fast sizes) with bands*16 bytes <= 150 KiB, i.e. <= 9600 bands:
- *     a frame's FFT runs inside one CU's LDS (every preset up to 192 kHz fits; presetDefault at 96 kHz has 6144 bands);
+ *     a frame's FFT runs inside one CU's LDS (the presets fit up to 96 kHz -- presetDefault there has 6144 bands; at 192 kHz they would
+ *     need 10240 / 12288 bands and are refused);
  *   - interval >= fftSamples/62 (the vertical step of the phase prediction, round(fftSamples/interval), has to fit the wavefront's
  *     skew); interval <= block.
  *   - Sample = float arithmetic only (the C++ drop-in accepts double buffers and converts at the boundary).

@@ -614,6 +614,19 @@ def test_synth_emit_equals_two_kernels(hip, monkeypatch):
     pc.case_synth_emit_equals_two_kernels(hip, monkeypatch, presets=(("default", 48000),), streams=2, channels=2, splits=(False,), half_state=True)
 
 
+def test_oracle_parity_through_one_kernel_synthesis(hip, ref, monkeypatch):
+    """The oracle-parity cases that the launcher's thresholds would route through kSynthTeams + kEmit (few streams), forced through
+    kSynthEmitTeams: the API walk at presetDefault @ 48 kHz (process / flush / reset / seek / parameter changes between calls: every
+    way the carry is handed over) and the first streams of config 2 at the benchmark's own length."""
+    pkg = pc.package()
+    monkeypatch.setenv("SMST_FFT_TEAMS", "2")
+    monkeypatch.setenv("SMST_SYNTH_EMIT", "2")
+    before = pkg.launch_count("synth_emit", hip)
+    pc.case_api_surface(hip, ref, cfg=D48, scale=12)
+    _batch_vs_ref(hip, ref, 4, 2, 48000, 480000, 720000, D48, "default", "config2-one-kernel")
+    assert pkg.launch_count("synth_emit", hip) > before
+
+
 def test_fft_teams_equals_per_frame(hip, monkeypatch):
     """kAnalyseTeams (SMST_FFT_TEAMS=1) against kAnalyseFast: bit-identical."""
     pc.case_fft_teams_equals_per_frame(hip, monkeypatch, presets=(("cheaper", 48000), ("default", 48000), ("default", 44100)), streams=5)
