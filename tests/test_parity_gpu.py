@@ -612,6 +612,7 @@ def test_synth_emit_equals_two_kernels(hip, monkeypatch):
     pc.case_synth_emit_equals_two_kernels(hip, monkeypatch, presets=(("cheaper", 48000), ("default", 48000), ("default", 44100), ("cheaper", 44100)), streams=5)
     pc.case_synth_emit_equals_two_kernels(hip, monkeypatch, presets=(("default", 48000),), streams=3, channels=1)
     pc.case_synth_emit_equals_two_kernels(hip, monkeypatch, presets=(("default", 48000),), streams=2, channels=2, splits=(False,), half_state=True)
+    pc.case_synth_emit_equals_two_kernels(hip, monkeypatch, presets=(("cheaper", 48000),), streams=3, channels=5, splits=(True,))
 
 
 def test_oracle_parity_through_one_kernel_synthesis(hip, ref, monkeypatch):
