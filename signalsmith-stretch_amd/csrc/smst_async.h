@@ -26,10 +26,6 @@ struct Async4 { float v; };
 __device__ __forceinline__ void asyncLoad16(Async16 &r, const void *p) { asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(r.v) : "v"(p) : "memory"); }
 __device__ __forceinline__ void asyncLoad8(Async8 &r, const void *p) { asm volatile("global_load_dwordx2 %0, %1, off" : "=&v"(r.v) : "v"(p) : "memory"); }
 __device__ __forceinline__ void asyncLoad4(Async4 &r, const void *p) { asm volatile("global_load_dword %0, %1, off" : "=&v"(r.v) : "v"(p) : "memory"); }
-// base + lane offset + immediate: `base` has to be the same in every lane (it travels in scalar registers), byteOffset >= 0
-template <int OFF> __device__ __forceinline__ void asyncLoad4At(Async4 &r, const void *base, int byteOffset) {
-	asm volatile("global_load_dword %0, %1, %2 offset:%3" : "=&v"(r.v) : "v"(byteOffset), "s"(base), "n"(OFF) : "memory");
-}
 __device__ __forceinline__ void asyncClear(Async8 &r) { r.v = 0.0f; } // (a defined value for lanes that never request)
 template <int N> __device__ __forceinline__ void asyncWait() { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory"); }
 __device__ __forceinline__ void asyncArrived(Async16 &r) { asm volatile("" : "+v"(r.v)); }

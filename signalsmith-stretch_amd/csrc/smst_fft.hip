@@ -444,15 +444,10 @@ struct TeamSync { // LDS operations of a wave complete in order: a wave's counte
 	}
 };
 
-template <int SLOT, typename F>
-__device__ __forceinline__ void forEachSlot(F f) { // f(integral_constant<int, SLOT>) for the 16 element slots of a thread's first-stage butterfly
-	if constexpr (SLOT < 16) { f(std::integral_constant<int, SLOT>()); forEachSlot<SLOT + 1>(f); }
-}
-
 // EXACT: block = 15/16 of the FFT size (windowPad = 0: the geometry is then a compile-time constant); otherwise see windowPad.
 // Either way the arithmetic is kAnalyseFast's, element for element (an absent half contributes a zero: sample x zero weight).
 template <int R3, int TEAMS, bool EXACT>
-__global__ __launch_bounds__(256*TEAMS) void kAnalyseTeams(DevBatch d, IoArgs io, const HopDesc *__restrict__ hopTable, const int *__restrict__ inSamples, int sBase, int hopBase, int tileHops, int nStreams) {
+__global__ __launch_bounds__(256*TEAMS) void kAnalyseTeams(DevBatch d, IoArgs io, const HopDesc *__restrict__ hopTable, int sBase, int hopBase, int tileHops, int nStreams) {
 	static_assert(16*R3 <= 256, "a team is 256 threads");
 	extern __shared__ __attribute__((aligned(16))) unsigned char smemRaw[];
 	constexpr int MA = 16*R3, H = 256*R3, N = 2*H;
@@ -472,57 +467,21 @@ __global__ __launch_bounds__(256*TEAMS) void kAnalyseTeams(DevBatch d, IoArgs io
 	int generation = 0;
 	const TeamSync sync{words + team, &generation};
 	const int stride = gridDim.x*TEAMS;
-	// The team's jobs in order: lin = blockIdx + grid*(team + TEAMS*round) (the same residue mod 8 for all of a workgroup's teams), those
-	// it may take (see analysisWindowInCall).  The samples of job n+1 are requested while job n is transformed -- BEFORE job n's spectrum
-	// is stored, through loads the kernel waits for itself (smst_async.h): vmcnt retires in order, so a load issued after the stores
-	// could only be waited for together with them (2.0 of the per-frame kernel's 4.9 ms were that wait, EXPERIMENTS.md 3.7), and the
-	// compiler's own bookkeeping falls back to "everything" at the loop's back-edge.  Everything else the loop reads is a scalar load.
-	struct Job { int lin; const float *x0, *x1; float2 *dst; };
-	auto nextJob = [&](int lin) {
-		Job job{total, nullptr, nullptr, nullptr};
-		for (; lin < total; lin += stride) {
-			// (the coordinates are the same in every lane, but the divisions that form them run on the vector unit: made scalar again, so
-			// that the job's descriptor is a SCALAR load)
-			BlockCoord bc = xcdAwareCoord(lin, tileHops, 2*d.C, nStreams);
-			bc.x = __builtin_amdgcn_readfirstlane(bc.x); bc.y = __builtin_amdgcn_readfirstlane(bc.y); bc.s = __builtin_amdgcn_readfirstlane(bc.s);
-			const HopDesc hd = hopTable[(size_t)(sBase + bc.s)*d.hopStride + hopBase + bc.x];
-			const int c = bc.y >> 1, which = bc.y & 1;
-			if (!(hd.flags & HOP_ACTIVE) || !(hd.flags & HOP_NEW_SPECTRUM) || (which && !(hd.flags & HOP_REANALYSE_PREV)) || !analysisWindowInCall(B, H, d.I, hd.inputOffset, which, inSamples[sBase + bc.s])) continue; // (inSamples = io.inSamples as a restrict argument: a scalar load as well)
-			const int base = hd.inputOffset - (which ? d.I : 0) - B;
-			const float *x = io.in + (size_t)(sBase + bc.s)*io.inStreamStride + (size_t)c*io.inChannelStride;
-			job = Job{lin, x + base + halfB, x + base - H + halfB, (which ? d.Xprev : d.Xcur) + rowOf(d, bc.s, bc.x, c)};
-			break;
-		}
-		return job;
-	};
-	Async4 s0[15], s1[15]; // x0 of slots 0..14, x1 of slots 1..15 (whole slots: see windowPad)
-	const int lo = 4*(tA + 4*MA), hi = 4*(tA + 12*MA); // lane offsets of slots 4 and 12: the others are immediates around them
-	auto request = [&](const Job &job) {
-		forEachSlot<0>([&](auto slotConstant) { // (the immediates have to be constant expressions: a compile-time loop)
-			constexpr int slot = decltype(slotConstant)::value, around = slot < 8 ? 4 : 12;
-			const int lane = slot < 8 ? lo : hi;
-			if constexpr (slot < 15) asyncLoad4At<4*MA*(slot - around)>(s0[slot], job.x0, lane);
-			if constexpr (slot > 0) asyncLoad4At<4*MA*(slot - around)>(s1[slot - 1], job.x1, lane);
-		});
-	};
-	auto landed = [&]() {
-#pragma unroll
-		for (int i = 0; i < 15; ++i) { asyncArrived(s0[i]); asyncArrived(s1[i]); }
-	};
-	Job job = nextJob(blockIdx.x + gridDim.x*team);
-	if (job.lin >= total) return;
-	request(job);
-	asyncWait<0>();
-	landed();
-	for (;;) {
-		const Job next = nextJob(job.lin + stride);
-		float2 *dst = job.dst;
+	for (int lin = blockIdx.x + gridDim.x*team; lin < total; lin += stride) { // the same residue mod 8 for all of a workgroup's teams
+		const BlockCoord bc = xcdAwareCoord(lin, tileHops, 2*d.C, nStreams);
+		const HopDesc hd = hopTable[(size_t)(sBase + bc.s)*d.hopStride + hopBase + bc.x];
+		const int c = bc.y >> 1, which = bc.y & 1;
+		if (!(hd.flags & HOP_ACTIVE) || !(hd.flags & HOP_NEW_SPECTRUM) || (which && !(hd.flags & HOP_REANALYSE_PREV)) || !analysisWindowInCall(B, H, d.I, hd.inputOffset, which, io.inSamples[sBase + bc.s])) continue;
+		const int base = hd.inputOffset - (which ? d.I : 0) - B;
+		const float *x = io.in + (size_t)(sBase + bc.s)*io.inStreamStride + (size_t)c*io.inChannelStride;
+		const float *x0 = x + base + halfB, *x1 = x + base - H + halfB;
+		float2 *dst = (which ? d.Xprev : d.Xcur) + rowOf(d, bc.s, bc.x, c);
 		fftFast<-1, R3, false>(lds, twALds, twBLds,
-			[&](int, int slot) { // kAnalyseFast's roundings: round(xi*b + round(xr*a)), the absent half an exact zero
+			[&](int m, int slot) { // kAnalyseFast's roundings: round(xi*b + round(xr*a)), the absent half an exact zero
 				const float4 w = winLds[tA + MA*slot];
 				float2 r = make_float2(0.f, 0.f);
-				if (slot < 15) { const float xr = asyncValue(s0[slot < 15 ? slot : 0]); r = make_float2(xr*w.x, xr*w.y); }
-				if (slot > 0) { const float xi = asyncValue(s1[slot > 0 ? slot - 1 : 0]); r = make_float2(fmaf(xi, w.z, r.x), fmaf(xi, w.w, r.y)); }
+				if (slot < 15) { const float xr = x0[m]; r = make_float2(xr*w.x, xr*w.y); }
+				if (slot > 0) { const float xi = x1[m]; r = make_float2(fmaf(xi, w.z, r.x), fmaf(xi, w.w, r.y)); }
 				return r;
 			},
 			[](int, int) { return 0; },
@@ -530,13 +489,8 @@ __global__ __launch_bounds__(256*TEAMS) void kAnalyseTeams(DevBatch d, IoArgs io
 				const int kk = 2*j;
 				if (kk < H) dst[kk] = u;
 				else dst[N - 1 - kk] = cconj(u);
-			}, t, sync, NoHook(),
-			[&]() { request(next.lin < total ? next : job); }); // (always 30 requests and R3 stores per frame: the wait below counts on it)
+			}, t, sync);
 		sync(); // the last stage's LDS reads, before the next frame's first-stage writes
-		asyncWait<R3>(); // the R3 stores of this frame's spectrum are younger than the requests and may stay in flight
-		landed();        // (also behind the last job, whose request was a repeat: one path through the loop's end for tools/check_async_isa.py)
-		if (next.lin >= total) break;
-		job = next;
 	}
 }
 
@@ -621,8 +575,7 @@ __global__ __launch_bounds__(256*TEAMS) void kSynthTeams(DevBatch d, const HopDe
 	const TeamSync sync{words + team, &generation};
 	const int stride = gridDim.x*TEAMS;
 	for (int lin = blockIdx.x + gridDim.x*team; lin < total; lin += stride) {
-		BlockCoord bc = xcdAwareCoord(lin, tileHops, d.C, nStreams); // x: hop, y: channel (made scalar: see kAnalyseTeams)
-		bc.x = __builtin_amdgcn_readfirstlane(bc.x); bc.y = __builtin_amdgcn_readfirstlane(bc.y); bc.s = __builtin_amdgcn_readfirstlane(bc.s);
+		const BlockCoord bc = xcdAwareCoord(lin, tileHops, d.C, nStreams); // x: hop, y: channel
 		const HopDesc hd = hopTable[(size_t)(sBase + bc.s)*d.hopStride + hopBase + bc.x];
 		if (!(hd.flags & HOP_ACTIVE)) continue;
 		const float2 *X = d.OUT + rowOf(d, bc.s, bc.x, bc.y);
@@ -1096,11 +1049,11 @@ void launchAnalyse(const DevBatch &d, const IoArgs &io, int sBase, int nStreams,
 		const WindowPad pad = windowPad(d.B, d.M);
 		const bool slots = pad.lo == 0 && pad.hi == 0;
 		if (d.M == 256*10) {
-			if (slots) hipLaunchKernelGGL((kAnalyseTeams<10, 3, true>), dim3(wgs), dim3(768), lds, st, d, io, d.hops, io.inSamples, sBase, hopBase, tileHops, nStreams);
-			else hipLaunchKernelGGL((kAnalyseTeams<10, 3, false>), dim3(wgs), dim3(768), lds, st, d, io, d.hops, io.inSamples, sBase, hopBase, tileHops, nStreams);
+			if (slots) hipLaunchKernelGGL((kAnalyseTeams<10, 3, true>), dim3(wgs), dim3(768), lds, st, d, io, d.hops, sBase, hopBase, tileHops, nStreams);
+			else hipLaunchKernelGGL((kAnalyseTeams<10, 3, false>), dim3(wgs), dim3(768), lds, st, d, io, d.hops, sBase, hopBase, tileHops, nStreams);
 		} else {
-			if (slots) hipLaunchKernelGGL((kAnalyseTeams<12, 3, true>), dim3(wgs), dim3(768), lds, st, d, io, d.hops, io.inSamples, sBase, hopBase, tileHops, nStreams);
-			else hipLaunchKernelGGL((kAnalyseTeams<12, 3, false>), dim3(wgs), dim3(768), lds, st, d, io, d.hops, io.inSamples, sBase, hopBase, tileHops, nStreams);
+			if (slots) hipLaunchKernelGGL((kAnalyseTeams<12, 3, true>), dim3(wgs), dim3(768), lds, st, d, io, d.hops, sBase, hopBase, tileHops, nStreams);
+			else hipLaunchKernelGGL((kAnalyseTeams<12, 3, false>), dim3(wgs), dim3(768), lds, st, d, io, d.hops, sBase, hopBase, tileHops, nStreams);
 		}
 		countLaunch(LK_ANALYSE_TEAMS);
 		if (!anyLate) return;

@@ -20,7 +20,6 @@
 #include <hip/hip_runtime.h>
 #include <atomic>
 #include <cstring>
-#include <type_traits>
 #include "smst_device.h"
 #include <smst_complex.h> // angle brackets: tests/emu shadows this header for the CPU stand-in
 #include <smst_async.h>   // likewise

@@ -10,7 +10,6 @@ struct Async4 { float v; };
 static inline void asyncLoad16(Async16 &r, const void *p) { r.v = *static_cast<const float4 *>(p); }
 static inline void asyncLoad8(Async8 &r, const void *p) { r.v = *static_cast<const float2 *>(p); }
 static inline void asyncLoad4(Async4 &r, const void *p) { r.v = *static_cast<const float *>(p); }
-template <int OFF> static inline void asyncLoad4At(Async4 &r, const void *base, int byteOffset) { r.v = *reinterpret_cast<const float *>(static_cast<const char *>(base) + byteOffset + OFF); }
 static inline void asyncClear(Async8 &r) { r.v = make_float2(0.0f, 0.0f); }
 template <int N> static inline void asyncWait() {}
 static inline void asyncArrived(Async16 &) {}

@@ -155,7 +155,7 @@ def scratch_users(path, wanted):
 
 
 if __name__ == "__main__":
-    wanted = sys.argv[2:] or ["ELb1ELb0ELb0ELb1EEEv", "15kSynthEmitTeams", "13kAnalyseTeams"]  # kVocoder<..., ALIGNED = true>, kSynthEmitTeams, kAnalyseTeams
+    wanted = sys.argv[2:] or ["ELb1ELb0ELb0ELb1EEEv", "15kSynthEmitTeams"]  # kVocoder<..., ALIGNED = true>, kSynthEmitTeams
     total = 0
     checked = 0
     for name, size in scratch_users(sys.argv[1], wanted):
