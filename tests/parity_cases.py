@@ -1010,7 +1010,9 @@ def case_synth_emit_equals_two_kernels(lib, monkeypatch, presets=(("cheaper", 48
                 c1, c2 = n//2, n*5//6
                 n_in = np.array([c1 - 17*s for s in range(streams)], np.int32)
                 y1 = np.array(b.process(np.ascontiguousarray(x[:, :, :c1]), (n_in*1.4).astype(np.int32), in_samples=n_in), copy=True)
-                y2 = np.array(b.process(np.ascontiguousarray(x[:, :, c1:c2]), int((c2 - c1)*0.8)), copy=True)
+                n_in2 = np.full(streams, c2 - c1, np.int32)
+                n_in2[1 % streams] = 0  # a stream that sits this call out: no hops, no samples -- its carry has to pass through the tile untouched
+                y2 = np.array(b.process(np.ascontiguousarray(x[:, :, c1:c2]), (n_in2*0.8).astype(np.int32), in_samples=n_in2), copy=True)
                 n_in3 = np.array([max(64, (n - c2) - 301*s) for s in range(streams)], np.int32)
                 y3 = np.array(b.process(np.ascontiguousarray(x[:, :, c2:]), (n_in3*1.1).astype(np.int32), in_samples=n_in3), copy=True)
                 tail = np.array(b.flush(b.outputLatency() + 100), copy=True)
