@@ -7,7 +7,7 @@ from collections import defaultdict
 
 
 def cls(name):
-    for key in ("kVocoder", "kAnalyseTeams", "kSynthTeams", "kAnalyseFast", "kSynthFast", "kEmit", "kCarryFeed", "kCarryOut", "kPredict", "kChain", "kFeed", "kHistory"):
+    for key in ("kVocoder", "kAnalyseTeams", "kSynthEmitTeams", "kEmitProducts", "kSynthTeams", "kAnalyseFast", "kSynthFast", "kEmit", "kCarryFeed", "kCarryOut", "kPredict", "kChain", "kFeed", "kHistory"):
         if key in name:
             return key
     return "other"
