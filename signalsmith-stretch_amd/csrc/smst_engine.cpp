@@ -320,8 +320,8 @@ void Batch::construct(const FftPlan &plan, long seed) {
 	// through the accessors at the top of smst_kernels_common.h)
 	const size_t stateScale = halfState ? 2 : 1;
 	d.stOut = reinterpret_cast<float2 *>(devAlloc<unsigned char>(bandRows*sizeof(float2)/stateScale));
-	d.stEnergy = reinterpret_cast<float *>(devAlloc<unsigned char>(bandRows*sizeof(float)/stateScale));
-	SMST_HIP(hipMemset(d.stEnergy, 0, bandRows*sizeof(float)/stateScale));
+	d.stEnergy = reinterpret_cast<float *>(devAlloc<unsigned char>(bandRows*sizeof(float)/stateScale + 16)); // (+16: PrevEnergy::at reads 8 bytes at an element)
+	SMST_HIP(hipMemset(d.stEnergy, 0, bandRows*sizeof(float)/stateScale + 16));
 	for (int h = 0; h < 2; ++h) {
 		d.hist[h] = devAlloc<float>((size_t)S*C*d.histLen);
 		d.carrySum[h] = reinterpret_cast<float *>(devAlloc<unsigned char>((size_t)S*C*d.carryLen*sizeof(float)/stateScale));
@@ -451,7 +451,7 @@ void Batch::allocateWorkspace() {
 				w = TileBuffers{};
 				w.Xcur = devAlloc<float2>(rows);
 				w.Xprev = devAlloc<float2>(rows);
-				w.PE = devAlloc<PredEntry>(rows);
+				w.PE = devAlloc<PredEntry>(rows + 2); // (+2 entries: PrevEnergy::at reads 8 bytes at an entry's third float)
 				w.OUT = devAlloc<float2>(rows);
 				if (needRecords) {
 					w.REC = devAlloc<float4>((size_t)subS*d.recSteps*d.recPitch);

@@ -215,19 +215,45 @@ struct RecordSource {
 struct PrevEnergy {
 	bool carried;        // the tile's first hop: the carried state, element carriedBase + bin
 	size_t carriedBase;
-	const float *row;    // inside a mapped tile: third float of hop k-1's 12-byte entries (stride 3)
-	const float2 *input; // inside a plain tile: hop k-1's input spectrum
-	__device__ __forceinline__ float at(const DevBatch &d, int bc) const {
-		if (carried) return loadCarriedEnergy(d, carriedBase + bc);
-		if (input) return cnorm(input[bc]);
-		return row[(size_t)bc*3];
+	const float *row;    // inside a mapped tile: third float of hop k-1's 12-byte entries (stride 3); a valid row also when `carried`
+	const float2 *input; // inside a plain tile: hop k-1's input spectrum; likewise
+	// ONE 8-byte load at a selected address, the value picked out of it afterwards -- a three-way branch with a load in every arm ended
+	// the basic block at every call: the record producers of kVocoderN waited for memory nine times per record where two or three
+	// round trips are what the data dependences ask for (ISA of the round-3 build; EXPERIMENTS.md 4.11).  The load may reach 4 bytes
+	// past the element (the next float of the row): the engine allocates stEnergy and PE with that slack.
+	struct Raw { float x, y; bool odd; }; // the 8 bytes at the element, not looked at yet
+	template <bool PLAIN>
+	__device__ __forceinline__ Raw load(const DevBatch &d, int bc) const {
+		const bool half = d.halfState;
+		const size_t ci = carriedBase + bc;
+		const char *const state = reinterpret_cast<const char *>(d.stEnergy);
+		const char *const fromState = state + (half ? (ci & ~size_t(1))*2 : ci*4); // fp16: the dword that holds the element
+		const char *const fromTile = PLAIN ? reinterpret_cast<const char *>(input + bc) : reinterpret_cast<const char *>(row + (size_t)bc*3);
+		const float *const address = reinterpret_cast<const float *>(carried ? fromState : fromTile);
+		return Raw{address[0], address[1], bool(ci & 1)};
+	}
+	// (called once EVERY load of the record's second round trip has been issued: the empty asm statements keep the two loads
+	// unconditional -- the compiler otherwise sinks the second one into a conditional of its own and waits for it there -- and nothing
+	// is scheduled across them)
+	template <bool PLAIN>
+	__device__ __forceinline__ float value(const DevBatch &d, Raw r) const {
+		keepUnconditional(r.x);
+		keepUnconditional(r.y);
+		const unsigned bits = (unsigned)__float_as_int(r.x);
+		const unsigned short hbits = r.odd ? (unsigned short)(bits >> 16) : (unsigned short)(bits & 0xffffu);
+		const float a = float(__builtin_bit_cast(half_t, hbits));
+		const float asState = d.halfState ? a*a : r.x;
+		return carried ? asState : (PLAIN ? cnorm(make_float2(r.x, r.y)) : r.x);
 	}
 };
-// coefficient multiplying the previous hop's final output at bin bx (bx = b+1 or b+L), see the record description
+// coefficient multiplying the previous hop's final output at bin bx (bx = b+1 or b+L), see the record description -- in two parts: every
+// load and what follows from it except the previous hop's energy (twistParts), and the division by max(E_prev, E_now) (twistFinish),
+// so that a record's two twists have ALL their loads in flight before the first of them is waited for
+struct TwistParts { float2 r; float eNow; PrevEnergy::Raw ePrev; };
 template <int CH, bool PLAIN>
-__device__ __forceinline__ float2 twistAt(const RecordSource<CH, PLAIN> &src, int mc, int bx, float2 mp, bool rotate, const float2 *in,
-                                          const float2 *pv, const PrevEnergy &prevE, float tfDown, float stepMul,
-                                          const float2 *rot) {
+__device__ __forceinline__ TwistParts twistParts(const RecordSource<CH, PLAIN> &src, int mc, int bx, float2 mp, bool rotate, const float2 *in,
+                                                 const float2 *pv, const PrevEnergy &prevE, float tfDown, float stepMul,
+                                                 const float2 *rot) {
 	// bx may be one past the last bin for the callers' masked-out cases: every access below clamps; mp = mapAt(min(bx, M-1))
 	const DevBatch &d = src.d;
 	const int M = src.M;
@@ -248,13 +274,19 @@ __device__ __forceinline__ float2 twistAt(const RecordSource<CH, PLAIN> &src, in
 	const float4 pe = src.PE(mc, bc);
 	const float2 Px = make_float2(pe.x, pe.y);
 	const float2 TW = cmul(rotB, cmulc(Px, Q));
-	const float eNow = pe.z;
-	const float ePrev = prevE.at(d, bc);
-	const float den = fmaxf(ePrev, eNow) + 1e-15f; // :716
 	const float2 down = cmulc(Px, lerpBand(in, lerpIndex(mp.x - stepMul*tfDown), M));
-	const float2 r = cmulc(TW, down);
+	TwistParts t;
+	t.r = cmulc(TW, down);
+	t.eNow = pe.z;
+	t.ePrev = prevE.template load<PLAIN>(d, bc);
+	return t;
+}
+template <bool PLAIN>
+__device__ __forceinline__ float2 twistFinish(const DevBatch &d, const PrevEnergy &prevE, const TwistParts &t) {
+	const float ePrev = prevE.template value<PLAIN>(d, t.ePrev);
+	const float den = fmaxf(ePrev, t.eNow) + 1e-15f; // :716
 	const float inv = __builtin_amdgcn_rcpf(den); // 1-ulp hardware reciprocal (an IEEE division costs ten instructions per record)
-	return make_float2(r.x*inv, r.y*inv);
+	return make_float2(t.r.x*inv, t.r.y*inv);
 }
 
 // Fills one record.  Per-channel fields: see recordChannelFields.  (LOCK: kept in the signature for the call sites, always false.)
@@ -317,13 +349,15 @@ __device__ __forceinline__ void computeRecord(const DevBatch &d, const HopDesc &
 		PrevEnergy prevE;
 		prevE.carried = k == 0;
 		prevE.carriedBase = stateRow(d, sg, cm);
-		prevE.input = (PLAIN && k > 0) ? inputRow(d, hp, s, sg, cm) : nullptr;
-		prevE.row = (!PLAIN && k > 0) ? reinterpret_cast<const float *>(d.PE + rowOf(d, s, k - 1, cm)) + 2 : nullptr;
+		prevE.input = inputRow(d, hp, s, sg, cm);                                                           // (k == 0: some valid row, unused)
+		prevE.row = reinterpret_cast<const float *>(d.PE + rowOf(d, s, k > 0 ? k - 1 : 0, cm)) + 2;
 		const float2 zero = make_float2(0.f, 0.f);
 		A = cmulc(Pcm, lerpBand(in, lerpIndex(mp.x - tfUp), M));
 		B = cmulc(Pcm, lerpBand(in, lerpIndex(mp.x - L*tfUp), M));
-		Cc = twistAt<CH, PLAIN>(src, cm, b + 1, mp1, rotate, in, pv, prevE, tfDn, 1.0f, rot);
-		Dc = twistAt<CH, PLAIN>(src, cm, b + L, mpL, rotate, in, pv, prevE, tfDn, float(L), rot);
+		const TwistParts t1 = twistParts<CH, PLAIN>(src, cm, b + 1, mp1, rotate, in, pv, prevE, tfDn, 1.0f, rot);
+		const TwistParts tL = twistParts<CH, PLAIN>(src, cm, b + L, mpL, rotate, in, pv, prevE, tfDn, float(L), rot);
+		Cc = twistFinish<PLAIN>(d, prevE, t1);
+		Dc = twistFinish<PLAIN>(d, prevE, tL);
 		if (!(b > 0)) A = zero;      // :748
 		if (!(b >= L)) B = zero;     // :756
 		if (!(b < M - 1)) Cc = zero; // :765
