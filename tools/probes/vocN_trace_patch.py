@@ -5,9 +5,13 @@ SRC = sys.argv[1]  # required: a copy of csrc/
 assert "/tmp/" in SRC or "variant" in SRC, "refusing to patch anything but a temporary copy of the sources"
 p = SRC + '/smst_kernels.hip'
 s=open(p).read()
-anchor="// ------------------------------------------------------------------------------------------------------\n// K2b-e: channel-summed energy"
-assert anchor in s
-s=s.replace(anchor,"__device__ int gUnit;\n__device__ unsigned long long gTrace[12*400 + 8];\n#define TRP(slot) do { if (blockIdx.x == 0 && threadIdx.x == 64) gTrace[(slot)*400 + (gUnit % 400)] = clock64(); } while (0)\nvoid traceRead(void *dst) { hipMemcpyFromSymbol(dst, HIP_SYMBOL(gTrace), sizeof(gTrace)); }\n#define TR(slot, n) do { if (s == 0 && k == 0 && (n) < 400) { gTrace[(slot)*400 + (n)] = clock64(); if ((slot) == 5 && ((n) == 100 || (n) == 300)) gTrace[12*400 + ((n) == 300)] = wall_clock64(); } } while (0)\n"+anchor,1)
+hp = SRC + '/smst_kernels_common.h'
+h = open(hp).read()
+tail = "\n} // namespace smst\n"
+assert h.rstrip().endswith("} // namespace smst")
+h = h.rstrip()[:-len("} // namespace smst")] + "__device__ int gUnit;\n__device__ unsigned long long gTrace[12*400 + 8];\n#define TRP(slot) do { if (blockIdx.x == 0 && threadIdx.x == 64) gTrace[(slot)*400 + (gUnit % 400)] = clock64(); } while (0)\ninline void traceReadImpl(void *dst) { hipMemcpyFromSymbol(dst, HIP_SYMBOL(gTrace), sizeof(gTrace)); }\n#define TR(slot, n) do { if (s == 0 && k == 0 && (n) < 400) { gTrace[(slot)*400 + (n)] = clock64(); if ((slot) == 5 && ((n) == 100 || (n) == 300)) gTrace[12*400 + ((n) == 300)] = wall_clock64(); } } while (0)\n" + tail
+open(hp, 'w').write(h)
+s += "\nnamespace smst { void traceRead(void *dst) { traceReadImpl(dst); } }\n"
 def rep(old,new):
     global s
     assert s.count(old)==1, (s.count(old), old[:60])
@@ -70,6 +74,9 @@ rep("""			asm volatile("" ::: "memory");
 		}
 	}
 }""")
+open(p,'w').write(s)
+p = SRC + '/smst_recurrence.h'
+s=open(p).read()
 rep("""	int mc = 0; // maximum-energy channel, first maximum wins (:729-737)
 	float eMax = e[0];""","""	asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 	TRP(9);
