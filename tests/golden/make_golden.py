@@ -146,6 +146,71 @@ def only(names):
     case = real
 
 
+def split_event_scenarios(interval, n_in, pre_intervals, post_intervals, offsets, rate=1.0, pre_mapped=None):
+    """Op lists of the split-computation fixtures: process() up to `off` samples into an interval, an event, more process().
+    Events: flush of one interval / of a third of it, setTransposeSemitones 3 -> 7 (the block in flight is already mapped: findPeaks
+    reads the live parameters, signalsmith-stretch.h:850-856), 0 -> 4 (`mappedFrequencies` was latched at the block's start, :300),
+    reset(), seek()."""
+    out = []
+    for event in ("flush", "flush_short", "param", "param_unmapped", "reset", "seek"):
+        for off in offsets:
+            nout = (pre_mapped if (event == "param" and pre_mapped) else pre_intervals)*interval + off  # (a transposed run of the small geometry drifts from the WASM by 2e-3 within ten hops: keep it short)
+            nin = int(round(nout*rate))
+            ops = []
+            if event == "param":  # only this event needs a mapped block in flight; the others stay un-transposed, where the fixtures resolve 1e-6
+                ops.append(dict(op="setTransposeSemitones", args=[3, 0]))
+            ops.append(dict(op="process", inStart=0, inLen=nin, outLen=nout))
+            pos = nin
+            if event == "flush":
+                ops.append(dict(op="flush", outLen=interval))
+            elif event == "flush_short":
+                ops.append(dict(op="flush", outLen=max(1, interval//3)))
+            elif event == "param":
+                ops.append(dict(op="setTransposeSemitones", args=[7, 0]))
+            elif event == "param_unmapped":
+                ops.append(dict(op="setTransposeSemitones", args=[4, 0]))
+            elif event == "reset":
+                ops.append(dict(op="reset"))
+            elif event == "seek":
+                ops.append(dict(op="seek", inStart=pos, inLen=interval*3, rate=1.0))
+                pos += interval*3
+            npost = post_intervals*interval
+            ops.append(dict(op="process", inStart=pos, inLen=int(round(npost*rate)), outLen=npost))
+            assert pos + int(round(npost*rate)) <= n_in
+            out.append(("%s_%d" % (event, off), ops))
+    return out
+
+
+def split_event_fixtures():
+    """tests/golden/split_events/: what the reference's shipped WASM build does when something happens BETWEEN two interval
+    boundaries in split-computation mode (signalsmith-stretch.h:292-296,321-325,407-415: the block's steps are spread over the
+    interval, the output is read from the stashed ring).  The step partition of analyseSteps() / synthesiseSteps() lives in
+    signalsmith-linear, which only the WASM contains: these fixtures pin it.  One file per geometry: the input once, one output
+    per scenario."""
+    out_dir = os.path.join(HERE, "split_events")
+    os.makedirs(out_dir, exist_ok=True)
+    sr = 48000
+    geoms = {
+        # the small geometry of tests/parity_cases.py (SMALL_SPLIT): 24 steps per stereo block, one step per ~5 samples
+        "small_stereo": dict(cfg=dict(preset="configure", block=512, interval=128, split=True), channels=2, interval=128, n=6000,
+                             pre=10, pre_mapped=3, post=4, offsets=(1, 5, 8, 12, 16, 32, 46, 47, 54, 55, 64, 80, 100, 110, 115, 116, 121, 122, 124, 127)),  # 46|47: findPeaks of a mapped stereo block (step 8 of 24); 54|55: first main-prediction chunk of an unmapped one (step 8 of 20); 115|116, 121|122: its two synthesis steps
+        # presetCheaper at 48 kHz (always split in the WASM ABI, web/emscripten/main.cpp:46-48), mono
+        "cheaper_48k_mono": dict(cfg=dict(preset="cheaper"), channels=1, interval=1920, n=26000,
+                                 pre=4, post=3, offsets=(5, 700, 1500, 1850, 1919)),
+    }
+    for name, g in geoms.items():
+        C = g["channels"]
+        x = (synth_input(0, C, g["n"], sr) + 0.3*synth_input(3, C, g["n"], sr)).astype(np.float32)  # tonal: the fixtures must resolve single steps, not chaos
+        scen = split_event_scenarios(g["interval"], g["n"], g["pre"], g["post"], g["offsets"], pre_mapped=g.get("pre_mapped"))
+        blob = dict(x=x, cfg=json.dumps(g["cfg"]), names=json.dumps([s[0] for s in scen]))
+        for key, ops in scen:
+            y, info = wasm_oracle.run(x, ops, **g["cfg"])
+            blob["ops_" + key] = json.dumps(ops)
+            blob["y_" + key] = y.astype(np.float32)
+        blob["info"] = json.dumps(info)
+        np.savez_compressed(os.path.join(out_dir, name + ".npz"), **blob)
+        print(name, len(scen), "scenarios", info)
+
 if __name__ == "__main__":
     if len(sys.argv) > 2 and sys.argv[1] == "only":
         only(set(sys.argv[2:]))
@@ -155,5 +220,8 @@ if __name__ == "__main__":
         sys.exit(0)
     if len(sys.argv) > 1 and sys.argv[1] == "seek":
         seek_rate_fixtures()
+        sys.exit(0)
+    if len(sys.argv) > 1 and sys.argv[1] == "split":
+        split_event_fixtures()
         sys.exit(0)
     main()

@@ -229,3 +229,42 @@ def test_seek_rate_revision_measured(ref, rate, lo, hi):
     err = rel_rms(out, y)
     assert lo <= err <= hi, (rate, err)
     assert abs(float(np.sqrt(np.mean(out**2)/np.mean(y**2))) - 1) < 1e-5
+
+
+@pytest.mark.parametrize("geometry", scenarios.split_event_geometries())
+def test_ref_matches_wasm_split_events(ref, geometry):
+    """Split computation (signalsmith-stretch.h:292-296,321-325,407-415), events BETWEEN interval boundaries: the step partition
+    (stft.analyseSteps() / synthesiseSteps(), in signalsmith-linear) and what stft.reset() clears decide which steps of the block in
+    flight see a flush / parameter change / seek / reset.  The shipped WASM holds the real L1; oracle/_ref (the shim) must reproduce
+    it at every offset, including the single samples at which a step moves to the other side of the event (46|47, 54|55, 115|116,
+    121|122 at the small geometry)."""
+    if getattr(ref, "is_port", False):
+        pytest.skip("needs oracle/_ref")
+    x, cfg, scen = scenarios.load_split_events(geometry)
+    worst = {}
+    for name, ops, y in scen:
+        obj = ref.RefStretch()
+        scenarios.configure(obj, x.shape[0], cfg)
+        out = scenarios.replay(obj, x, ops)
+        assert out.shape == y.shape
+        e = scenarios.split_event_errors(out, y, ops, obj.intervalSamples())
+        tol_seg, tol_after = scenarios.split_event_tolerance(name)
+        assert all(v <= tol_seg for _, v in e["segments"]) and all(v <= tol_after for v in e["after"]), (geometry, name, e)
+        kind = name.rsplit("_", 1)[0]
+        worst[kind] = max(worst.get(kind, 0.0), max(e["after"]))
+    print(geometry, {k: "%.1e" % v for k, v in worst.items()})
+
+
+def test_split_event_fixtures_resolve_single_steps():
+    """The fixtures are only worth something if a step on the wrong side of the event is visible: neighbouring offsets across a step
+    boundary differ by far more than the tolerance (flush 115|116: the first synthesised channel appears in the flushed tail)."""
+    x, cfg, scen = scenarios.load_split_events("small_stereo")
+    by = {n: (ops, y) for n, ops, y in scen}
+    def tail(name):
+        ops, y = by[name]
+        k, p, n = scenarios.segments(ops)[1]
+        assert k == "flush"
+        return y[:, p:p + n]
+    for a, b in (("flush_115", "flush_116"), ("flush_121", "flush_122")):
+        assert rel_rms(tail(a), tail(b)) > 0.2, (a, b)
+    assert rel_rms(tail("flush_116"), tail("flush_121")) < 0.2  # same steps executed: the tails differ only by five samples of ring position
