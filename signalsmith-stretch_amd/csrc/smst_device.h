@@ -53,6 +53,10 @@ struct DevBatch {
 	int wpHeadLen;                    // (ceil(B/I) + 2)*I
 	float *stFreq;                    // freqEstimateWeighted / Weight       [S][2]
 	const StreamParams *params;       // [S]
+	// split computation spreads a block's steps over its interval (signalsmith-stretch.h:321-325) and the steps read the LIVE parameters:
+	// findPeaks (:874), updateFormants step 0 (:982-983) and step 2 (:1020-1021) of the block in flight may each see other values.  In every
+	// other launch the three point at `params`.
+	const StreamParams *paramsPeaks, *paramsForm0, *paramsForm2;
 	const float *mapTable;            // [S][mapTableLen] custom frequency maps (table form of setFreqMap)
 	// per-call tables
 	const HopDesc *hops;   // [S][hopStride]
@@ -135,7 +139,13 @@ void launchCarryFeed(const DevBatch &d, int sBase, int nStreams, int hopBase, bo
 void launchCarryOut(const DevBatch &d, int sBase, int nStreams, hipStream_t st);
 void launchHistory(const DevBatch &d, const IoArgs &io, hipStream_t st);
 void launchPassThrough(const DevBatch &d, const IoArgs &io, const int *passFlags, int maxOut, hipStream_t st);
-void launchResetStreams(const DevBatch &d, const int *flags, int allBits, const float *seedWp, hipStream_t st); // flags: per-stream bit masks or null = allBits for every stream
+// flags: per-stream bit masks or null = allBits for every stream.  keep (may be null): per stream, the first samples of the overlap-add ring that
+// stft.reset() does NOT reach -- split computation reads the rest of the interval from its stashed copy of the ring (signalsmith-stretch.h:407-415)
+void launchResetStreams(const DevBatch &d, const int *flags, int allBits, const float *seedWp, hipStream_t st, const int *keep = nullptr);
+// split computation: the spectra of the block in flight (analysed at the block's start, :293,:356-373) -> row 0 of the tile that runs the block
+void launchPendingToTile(const DevBatch &d, int sBase, int nStreams, const float2 *pendIn, const float2 *pendPrev, hipStream_t st);
+// ... and a flush() that fell between two synthesis steps (:397-399): channels from synthChannels[stream] on contribute no frame (negative: all do)
+void launchMaskOutRows(const DevBatch &d, int sBase, int nStreams, const int *synthChannels, hipStream_t st);
 void launchSeekHistory(const DevBatch &d, const IoArgs &io, const int *seekFlags, hipStream_t st);
 void launchAddPreRoll(const DevBatch &d, const float *preRoll, int length, const int *offsets, hipStream_t st);
 void launchComplexSelfTest(const float *in, float *out, int n, hipStream_t st); // smst_complex.h against its documented formulas (test hook)

@@ -331,7 +331,7 @@ void Batch::construct(const FftPlan &plan, long seed) {
 	d.wpHead = devAlloc<float>((size_t)S*d.wpHeadLen);
 	d.stFreq = devAlloc<float>((size_t)S*2);
 	dParams = devAlloc<StreamParams>(S);
-	d.params = dParams;
+	d.params = d.paramsPeaks = d.paramsForm0 = d.paramsForm2 = dParams;
 	dEnergy = devAlloc<float>((size_t)S*kEnergyParts);
 	for (int i = 0; i < 2; ++i) {
 		callSets[i].inSamples = devAlloc<int>(S);
@@ -343,11 +343,16 @@ void Batch::construct(const FftPlan &plan, long seed) {
 		callSets[i].hEnergy = pinnedAlloc<float>((size_t)S*kEnergyParts);
 		callSets[i].resetBits = devAlloc<int>(S);
 		callSets[i].hResetBits = pinnedAlloc<int>(S);
+		if (split) {
+			callSets[i].pendHops = devAlloc<HopDesc>(S);
+			callSets[i].hPendHops = pinnedAlloc<HopDesc>(S);
+		}
 	}
 	dSeedWp = devAlloc<float>(d.carryLen);
 	SMST_HIP(hipMemcpy(dSeedWp, seedCarryWp.data(), d.carryLen*sizeof(float), hipMemcpyHostToDevice));
 	hopFirst.assign(S, 0);
 	hopCount.assign(S, 0);
+	leavesPendingV.assign(S, 0);
 	passV.assign(S, 0);
 	dInSamples = callSets[0].inSamples;
 	dOutSamples = callSets[0].outSamples;
@@ -355,6 +360,7 @@ void Batch::construct(const FftPlan &plan, long seed) {
 	dAux0 = devAlloc<int>(S);
 	dAux1 = devAlloc<int>(S);
 	dResetBits = devAlloc<int>(S);
+	dKeep = devAlloc<int>(S);
 	resetBitsV.assign(S, 0);
 
 	sched.assign(S, StreamSched());
@@ -372,6 +378,32 @@ void Batch::construct(const FftPlan &plan, long seed) {
 	paramsDirty = true;
 
 	allocateWorkspace();
+	pend.assign(S, PendingBlock());
+	keepV.assign(S, 0);
+	if (split) { // the block in flight: its spectra, and the tables of the run that completes it (PendingBlock, smst_engine.h)
+		const size_t rows = (size_t)S*C*d.Mp;
+		dPendIn = devAlloc<float2>(rows);
+		dPendPrev = devAlloc<float2>(rows);
+		SMST_HIP(hipMemset(dPendIn, 0, rows*sizeof(float2)));
+		SMST_HIP(hipMemset(dPendPrev, 0, rows*sizeof(float2)));
+		const int nSub = (S + subS - 1)/subS;
+		for (int i = 0; i < 2; ++i) {
+			PendSet &ps = pendSets[i];
+			ps.hops = devAlloc<HopDesc>(S); ps.hHops = pinnedAlloc<HopDesc>(S);
+			ps.emit = devAlloc<EmitDesc>(S); ps.hEmit = pinnedAlloc<EmitDesc>(S);
+			ps.tileInfo = devAlloc<int>((size_t)nSub*2*subS); ps.hTileInfo = pinnedAlloc<int>((size_t)nSub*2*subS);
+			ps.bits = devAlloc<int>(S); ps.hBits = pinnedAlloc<int>(S);
+			ps.synthChannels = devAlloc<int>(S); ps.hSynthChannels = pinnedAlloc<int>(S);
+			for (int j = 0; j < 3; ++j) { ps.prm[j] = devAlloc<StreamParams>(S); ps.hPrm[j] = pinnedAlloc<StreamParams>(S); }
+			SMST_HIP(hipEventCreateWithFlags(&ps.done, hipEventDisableTiming));
+			ps.used = false;
+		}
+		dZeroCounts = devAlloc<int>(S);
+		SMST_HIP(hipMemset(dZeroCounts, 0, S*sizeof(int)));
+		pendList.reserve(S);
+		pendTileHas.assign((size_t)nSub*8, 0);
+		pendMaxSpan.assign(nSub, 0);
+	}
 	reset();
 }
 
@@ -394,6 +426,8 @@ void Batch::releaseAll() {
 		if (callSets[i].done) hipEventDestroy(callSets[i].done);
 		if (callSets[i].tables) hipEventDestroy(callSets[i].tables);
 		callSets[i].done = callSets[i].tables = nullptr;
+		if (pendSets[i].done) hipEventDestroy(pendSets[i].done);
+		pendSets[i].done = nullptr;
 	}
 	if (evStart) hipEventDestroy(evStart);
 	if (evOrder) hipEventDestroy(evOrder);
@@ -490,9 +524,10 @@ void Batch::uploadParams() {
 // stft.reset(0.1) / Band clearing for a set of streams (bit masks, see kResetStreams): one upload + one launch, instead
 // of six API calls per stream.  `bitsHost` == nullptr: `allBits` for every stream.  Not on the steady-state path (reset,
 // flush, first silent block), so the small synchronous upload is fine.
-void Batch::resetStreams(const int *bitsHost, int allBits) {
+void Batch::resetStreams(const int *bitsHost, int allBits, const int *keepHost) {
 	if (bitsHost) SMST_HIP(hipMemcpy(dResetBits, bitsHost, S*sizeof(int), hipMemcpyHostToDevice));
-	launchResetStreams(d, bitsHost ? dResetBits : nullptr, allBits, dSeedWp, st);
+	if (keepHost) SMST_HIP(hipMemcpy(dKeep, keepHost, S*sizeof(int), hipMemcpyHostToDevice));
+	launchResetStreams(d, bitsHost ? dResetBits : nullptr, allBits, dSeedWp, st, keepHost ? dKeep : nullptr);
 }
 
 void Batch::reset() { // signalsmith-stretch.h:49-60
@@ -500,6 +535,7 @@ void Batch::reset() { // signalsmith-stretch.h:49-60
 	SMST_HIP(hipMemsetAsync(d.stFreq, 0, (size_t)S*2*sizeof(float), st));
 	resetStreams(nullptr, 1 | 2 | 4 | 8);
 	for (auto &lh : lastHop) lh = LastHop();
+	for (auto &pb : pend) pb = PendingBlock(); // blockProcess = {}
 	d.histCur = 0;
 	d.carryCur = 0;
 	for (auto &sc : sched) {
@@ -517,6 +553,7 @@ template <typename F> static void forStreams(int S, int stream, F &&f) {
 }
 void Batch::setTransposeFactor(int stream, float multiplier, float tonalityLimit) { // :107-115
 	forStreams(S, stream, [&](int s) {
+		freezePendingParams(s);
 		params[s].freqMultiplier = multiplier;
 		params[s].freqTonalityLimit = (tonalityLimit > 0) ? tonalityLimit/std::sqrt(multiplier) : 1.0f;
 		params[s].hasCustomMap = 0;
@@ -528,6 +565,7 @@ void Batch::setTransposeSemitones(int stream, float semitones, float tonalityLim
 }
 void Batch::setFormantFactor(int stream, float multiplier, bool compensatePitch) { // :124-128
 	forStreams(S, stream, [&](int s) {
+		freezePendingParams(s);
 		params[s].formantMultiplier = multiplier;
 		params[s].invFormantMultiplier = 1/multiplier;
 		params[s].formantCompensation = compensatePitch ? 1 : 0;
@@ -538,10 +576,13 @@ void Batch::setFormantSemitones(int stream, float semitones, bool compensatePitc
 	setFormantFactor(stream, float(std::pow(2, semitones/12)), compensatePitch);
 }
 void Batch::setFormantBase(int stream, float baseFreq) { // :133-135
-	forStreams(S, stream, [&](int s) { params[s].formantBaseFreq = baseFreq; });
+	forStreams(S, stream, [&](int s) { freezePendingParams(s); params[s].formantBaseFreq = baseFreq; });
 	paramsDirty = true;
 }
 void Batch::setFreqMapTable(int stream, const float *table, int n) { // table form of :120-122
+	// (split computation: the table itself is not snapshotted -- a block in flight whose findPeaks has already run keeps its flag and
+	// length but would read the NEW knots in updateFormants' step 2; the reference's std::function is replaced as a whole, :120-122)
+	forStreams(S, stream, [&](int s) { freezePendingParams(s); });
 	if (n <= 0 || !table) {
 		forStreams(S, stream, [&](int s) { params[s].hasCustomMap = 0; });
 		paramsDirty = true;
@@ -660,6 +701,246 @@ void Batch::signalStream(hipStream_t other) {
 	SMST_HIP(hipStreamWaitEvent(other, evOrder, 0));
 }
 
+// ---- split computation: the reference's step schedule -----------------------------------------------------
+StepLayout Batch::stepLayout(unsigned flags) const { // the order of signalsmith-stretch.h:332-400 / :642-812, counted as :304-318 / :620-632 count it
+	StepLayout l;
+	int i = 0;
+	const bool nw = (flags & HOP_NEW_SPECTRUM) != 0;
+	if (nw) {
+		if (flags & HOP_REANALYSE_PREV) { l.reanalyse0 = i; i += C + 1; } // analyseSteps() = one per channel (pinned by tests/golden/split_events), + the copy
+		l.analyse0 = i; i += C;
+		l.copyIn = i; i += 1;
+		i += C; // rotation
+	}
+	if (flags & HOP_MAPPED) { i += 3; l.peaks = i; i += 1; } // smoothEnergy x 3, findPeaks
+	i += 1;                                                   // output map
+	if (flags & HOP_FORMANTS) { l.form0 = i; l.form2 = i + 2; i += 3; }
+	i += C;                                                   // preliminary prediction
+	l.main0 = i; i += 8;                                     // splitMainPrediction
+	if (nw) { l.prevCopy = i; i += 1; }
+	l.spectrum = i; i += 1;
+	l.synth0 = i; i += C;                                     // synthesiseSteps() = one per channel, the first adds the window product
+	l.steps = i;
+	return l;
+}
+size_t Batch::stepsExecuted(size_t steps, size_t k) const { // after k samples of the interval, :321-325 (fp32 as there)
+	const float processRatio = float(k)/float(size_t(I));
+	return std::min<size_t>(steps, size_t((float(steps) + 0.999f)*processRatio));
+}
+// A setter is about to change params[s]: the steps of the block in flight that have already run saw the OLD values (:874, :982, :1020)
+void Batch::freezePendingParams(int s) {
+	if (!split) return;
+	PendingBlock &pb = pend[s];
+	if (!pb.valid) return;
+	const StepLayout l = stepLayout(pb.flags);
+	const size_t e = stepsExecuted(size_t(l.steps), sched[s].samplesSinceLast);
+	if (l.peaks >= 0 && e > size_t(l.peaks) && !pb.frozenPeaks) { pb.peaks = params[s]; pb.frozenPeaks = true; }
+	if (l.form0 >= 0 && e > size_t(l.form0) && !pb.frozenForm0) { pb.form0 = params[s]; pb.frozenForm0 = true; }
+	if (l.form2 >= 0 && e > size_t(l.form2) && !pb.frozenForm2) { pb.form2 = params[s]; pb.frozenForm2 = true; }
+}
+
+// The blocks in flight of the streams in `pendList` run to their end: one tile of one hop per stream whose spectra come from the
+// pending buffers; it consumes no input and emits no sample -- the frame goes into the overlap-add ring at the point where the block's
+// interval ends (outPos = -samples since the block began; split computation delays every frame by one interval, :292-296).
+// synthChannels (host, per stream, may be null): a flush() caught the block between two synthesis steps (:397-399).
+void Batch::runPendingBlocks(const int *synthChannels) {
+	if (pendList.empty()) return;
+	uploadParams();
+	pendCur ^= 1;
+	PendSet &ps = pendSets[pendCur];
+	if (ps.used) SMST_HIP(hipEventSynchronize(ps.done));
+	const int nSub = (S + subS - 1)/subS;
+	std::memset(ps.hHops, 0, S*sizeof(HopDesc));
+	std::memset(ps.hEmit, 0, S*sizeof(EmitDesc));
+	std::memset(ps.hTileInfo, 0, (size_t)nSub*2*subS*sizeof(int));
+	std::fill(pendTileHas.begin(), pendTileHas.end(), 0);
+	std::fill(pendMaxSpan.begin(), pendMaxSpan.end(), 0);
+	bool anyFrozen = false, anyZeroPrev = false;
+	for (int s : pendList) {
+		const PendingBlock &pb = pend[s];
+		HopDesc &hd = ps.hHops[s];
+		hd.flags = pb.flags;
+		hd.timeFactor = pb.timeFactor;
+		hd.seed = pb.seed;
+		hd.startBin = pb.startBin;
+		hd.outPos = -int(sched[s].samplesSinceLast);
+		const bool nw = (pb.flags & HOP_NEW_SPECTRUM) != 0;
+		hd.inSrc = nw ? 0 : SRC_STATE;
+		hd.prevSrc = (nw && (pb.flags & HOP_REANALYSE_PREV)) ? SRC_REANALYSED : SRC_STATE;
+		EmitDesc &ed = ps.hEmit[s];
+		ed.firstHopPos = hd.outPos;
+		ed.hopCount = 1;
+		const int sub = s/subS, sl = s%subS;
+		int *info = ps.hTileInfo + (size_t)sub*2*subS;
+		info[sl] = 1;
+		info[subS + sl] = nw ? 0 : -1;
+		unsigned char *th = pendTileHas.data() + (size_t)sub*8;
+		th[0] = 1;
+		if (pb.flags & HOP_MAPPED) th[1] = 1;
+		if (pb.flags & HOP_FORMANTS) th[2] = 1;
+		if (pb.flags & HOP_RANDOM_TF) th[4] = 1;
+		if (pb.startBin > 0) th[7] = 1;
+		anyFrozen = anyFrozen || pb.frozenPeaks || pb.frozenForm0 || pb.frozenForm2;
+		anyZeroPrev = anyZeroPrev || pb.zeroPrevAfter;
+		LastHop &lh = lastHop[s];
+		lh.slot = sub & 1;
+		lh.local = 0;
+		lh.subLocal = sl;
+		lh.mapped = (pb.flags & HOP_MAPPED) != 0;
+	}
+	SMST_HIP(hipMemcpyAsync(ps.hops, ps.hHops, S*sizeof(HopDesc), hipMemcpyHostToDevice, st));
+	SMST_HIP(hipMemcpyAsync(ps.emit, ps.hEmit, S*sizeof(EmitDesc), hipMemcpyHostToDevice, st));
+	SMST_HIP(hipMemcpyAsync(ps.tileInfo, ps.hTileInfo, (size_t)nSub*2*subS*sizeof(int), hipMemcpyHostToDevice, st));
+	if (anyFrozen) { // some step of some block ran before a setter: that step keeps the values it saw
+		for (int s = 0; s < S; ++s) ps.hPrm[0][s] = ps.hPrm[1][s] = ps.hPrm[2][s] = params[s];
+		for (int s : pendList) {
+			const PendingBlock &pb = pend[s];
+			if (pb.frozenPeaks) ps.hPrm[0][s] = pb.peaks;
+			if (pb.frozenForm0) ps.hPrm[1][s] = pb.form0;
+			if (pb.frozenForm2) ps.hPrm[2][s] = pb.form2;
+		}
+		for (int j = 0; j < 3; ++j) SMST_HIP(hipMemcpyAsync(ps.prm[j], ps.hPrm[j], S*sizeof(StreamParams), hipMemcpyHostToDevice, st));
+		d.paramsPeaks = ps.prm[0]; d.paramsForm0 = ps.prm[1]; d.paramsForm2 = ps.prm[2];
+	}
+	if (synthChannels) {
+		for (int s = 0; s < S; ++s) ps.hSynthChannels[s] = -1;
+		for (int s : pendList) ps.hSynthChannels[s] = synthChannels[s];
+		SMST_HIP(hipMemcpyAsync(ps.synthChannels, ps.hSynthChannels, S*sizeof(int), hipMemcpyHostToDevice, st));
+	}
+	d.hops = ps.hops;
+	d.emit = ps.emit;
+	d.hopStride = 1;
+	d.emitStride = 1;
+	const IoArgs io{nullptr, nullptr, 0, 0, 0, 0, dZeroCounts, dZeroCounts};
+	runTiles(TileRun{&io, 1, 1, pendTileHas.data(), pendMaxSpan.data(), ps.tileInfo, true, synthChannels ? ps.synthChannels : nullptr});
+	d.paramsPeaks = d.paramsForm0 = d.paramsForm2 = dParams;
+	if (anyZeroPrev) {
+		for (int s = 0; s < S; ++s) ps.hBits[s] = 0;
+		for (int s : pendList) if (pend[s].zeroPrevAfter) ps.hBits[s] = 4;
+		SMST_HIP(hipMemcpyAsync(ps.bits, ps.hBits, S*sizeof(int), hipMemcpyHostToDevice, st));
+		launchResetStreams(d, ps.bits, 0, dSeedWp, st);
+	}
+	SMST_HIP(hipEventRecord(ps.done, st));
+	ps.used = true;
+	for (int s : pendList) pend[s] = PendingBlock();
+	pendList.clear();
+}
+
+// The tiles of a call (or of a run of blocks in flight): analysis, feed-forward passes, recurrence, synthesis and emission, pipelined
+// over three HIP streams and two workspaces.
+void Batch::runTiles(const TileRun &run) {
+	const IoArgs &io = *run.io;
+	const int T = d.T, nTiles = run.nTiles, maxHops = run.maxHops;
+	const int nSub = (S + subS - 1)/subS;
+	const int carryBase = d.carryCur;
+	// Three HIP streams: `st` runs the feed-forward kernels of tile q, `stChain` the recurrence of tile q (a few
+	// hundred waves, instruction-issue bound), `stSynth` synthesis + emission.  Two workspaces alternate, so the bulk
+	// kernels of the next tile fill the machine while the recurrence of the current one is in flight.
+	const bool serial = profiling || !overlap || run.pendingRun;
+	const bool singleHop = singleHopSupported(d) && !noSingleHop;
+	hipStream_t sF = st, sC = serial ? st : stChain, sS = serial ? st : stSynth;
+	if (!serial) {
+		SMST_HIP(hipEventRecord(evStart, st));
+		SMST_HIP(hipStreamWaitEvent(sC, evStart, 0));
+		SMST_HIP(hipStreamWaitEvent(sS, evStart, 0));
+	}
+	int q = 0;
+	for (int sub = 0; sub < nSub; ++sub) {
+		const int sBase = sub*subS;
+		const int ns = std::min(subS, S - sBase);
+		for (int t = 0; t < nTiles; ++t, ++q) {
+			const unsigned char *th = run.tileHas + (size_t)(sub*nTiles + t)*8;
+			const int hopBase = t*T;
+			const int tileHops = std::min(T, std::max(1, maxHops - hopBase));
+			const int slot = q & 1;
+			const bool plain = !(th[1] || th[2]);
+			const bool fused = fusedSupported(d) && !noFuse; // mono/stereo: records stay in LDS (kVocoder)
+			const TileBuffers &w = slots[slot];
+			DevBatch dd = d;
+			dd.Xcur = w.Xcur; dd.Xprev = w.Xprev; dd.PE = w.PE; dd.OUT = w.OUT; dd.REC = w.REC; dd.dump = w.dump;
+			dd.map = w.map; dd.ratio = w.ratio; dd.energyT = w.energyT; dd.smoothT = w.smoothT; dd.peaksT = w.peaksT; dd.est = w.est; dd.freqEst = w.freqEst; dd.frames = w.frames;
+			dd.carryCur = (carryBase + t) & 1;
+			dd.nHops = run.dTileInfo + ((size_t)(sub*nTiles + t)*2)*subS;
+			dd.lastNewHop = dd.nHops + subS;
+			if (run.pendingRun) dd.synthEmit = 0; // (a one-hop tile whose hop began before the call: kSynthTeams + kEmit place it)
+			if (!serial && q >= 2) { // this workspace was last used by tile q-2
+				SMST_HIP(hipStreamWaitEvent(sF, evChain[slot], 0));
+				SMST_HIP(hipStreamWaitEvent(sF, evSynth[slot], 0));
+			}
+			if (!serial && fused && !plain && q >= 1) SMST_HIP(hipStreamWaitEvent(sF, evChain[slot ^ 1], 0)); // pass A reads the carried state
+			if (th[0]) {
+				if (run.pendingRun) timed(timings.otherMs, [&] { launchPendingToTile(dd, sBase, ns, dPendIn, dPendPrev, sF); });
+				else if (th[3]) timed(timings.analyseMs, [&] { launchAnalyse(dd, io, sBase, ns, hopBase, tileHops, th[5] != 0, th[6] != 0, sF); if (profiling) ++timings.analyseLaunches; });
+				bool passADone = false;
+				if (th[1] || th[2]) timed(timings.feedMs, [&] { passADone = launchFeed(dd, sBase, ns, hopBase, tileHops, th[2] != 0, sF); });
+				timed(timings.predictMs, [&] {
+					if (fused) launchPredictFused(dd, sBase, ns, hopBase, tileHops, plain, passADone, sF);
+					else launchPredict(dd, sBase, ns, hopBase, tileHops, plain, passADone, sF);
+					if (profiling) ++timings.predictLaunches;
+				});
+				// the carried feed-forward state (Band.input/.prevInput, Prediction.energy) may only move on once every
+				// reader of the OLD state has run: in the fused path the producers inside kVocoder still read it
+				if (!fused) timed(timings.otherMs, [&] { launchCarryFeed(dd, sBase, ns, hopBase, th[2] != 0, sF); });
+			}
+			checkLaunch("analysis / feed-forward kernels");
+			if (!serial) {
+				SMST_HIP(hipEventRecord(evFeed[slot], sF));
+				SMST_HIP(hipStreamWaitEvent(sC, evFeed[slot], 0));
+			}
+			if (th[0]) {
+				hipEvent_t liveA = nullptr, liveB = nullptr;
+				if (liveTiming && !serial) {
+					if (liveEvents.size() == livePool.size()) growLivePool(livePool.size() + 64); // only if a run outgrows what enableProfiling() made
+					liveA = livePool[liveEvents.size()].first;
+					liveB = livePool[liveEvents.size()].second;
+					SMST_HIP(hipEventRecord(liveA, sC));
+				}
+				timed(timings.chainMs, [&] {
+					// (th[7]: a block that a flush() interrupted inside its main prediction -- only kVocoderOne knows HopDesc.startBin)
+					if (fused && tileHops == 1 && singleHop && !noAcross && acrossSupported(dd) && !th[7]) launchVocoderAcross(dd, sBase, ns, hopBase, plain, sC);
+					else if (fused && tileHops == 1 && singleHop) launchVocoderOne(dd, sBase, ns, hopBase, plain, sC);
+					else if (fused) launchVocoder(dd, sBase, ns, hopBase, plain, !th[4], sC);
+					else launchChain(dd, sBase, ns, hopBase, sC);
+					if (profiling) ++timings.chainLaunches;
+				});
+				if (liveA) {
+					SMST_HIP(hipEventRecord(liveB, sC));
+					liveEvents.emplace_back(liveA, liveB);
+				}
+				timed(timings.otherMs, [&] {
+					if (fused) launchCarryFeed(dd, sBase, ns, hopBase, th[2] != 0, sC);
+					launchCarryOut(dd, sBase, ns, sC);
+					if (run.dSynthChannels) launchMaskOutRows(dd, sBase, ns, run.dSynthChannels, sC);
+				});
+			}
+			checkLaunch("bin recurrence");
+			// synthesis + overlap-add + emission in one kernel where the geometry and the batch allow it; its window products depend on
+			// nothing the recurrence writes: queued in front of the wait for it
+			const bool emitted = th[0] && synthEmitApplies(dd, ns, tileHops);
+			if (emitted) timed(timings.otherMs, [&] { launchEmitProducts(dd, sBase, ns, t, sS); });
+			if (!serial) {
+				SMST_HIP(hipEventRecord(evChain[slot], sC));
+				SMST_HIP(hipStreamWaitEvent(sS, evChain[slot], 0));
+			}
+			if (th[0]) timed(timings.synthMs, [&] {
+				if (emitted) launchSynthEmit(dd, io, sBase, ns, t, sS);
+				else launchSynth(dd, sBase, ns, hopBase, tileHops, sS);
+				if (profiling) ++timings.synthLaunches;
+			});
+			if (!emitted) timed(timings.emitMs, [&] { launchEmit(dd, io, sBase, ns, t, run.maxSpan[(size_t)sub*nTiles + t], sS); if (profiling) ++timings.emitLaunches; });
+			checkLaunch("synthesis / emission");
+			if (!serial) SMST_HIP(hipEventRecord(evSynth[slot], sS));
+		}
+	}
+	if (!serial) { // everything the caller can observe is ordered on `st` again
+		for (int i = 0; i < 2 && i < q; ++i) {
+			SMST_HIP(hipStreamWaitEvent(st, evChain[i], 0));
+			SMST_HIP(hipStreamWaitEvent(st, evSynth[i], 0));
+		}
+	}
+	d.carryCur = (carryBase + nTiles) & 1;
+}
+
 void Batch::process(const float *in, long long inSS, long long inCS, const int *inSamples,
                     float *out, long long outSS, long long outCS, const int *outSamples, const unsigned char *active) {
 	SMST_HIP(hipSetDevice(dev));
@@ -696,10 +977,12 @@ void Batch::process(const float *in, long long inSS, long long inCS, const int *
 	int *clearBits = cs.hResetBits; // per CALL (pinned + its own device copy): a shared buffer could be overwritten by the next call's upload before this call's kResetStreams has run
 	bool anyPass = false, anyClear = false;
 	int maxHops = 0;
+	pendList.clear();
 	for (int s = 0; s < S; ++s) {
 		passFlags[s] = 0;
 		hopFirst[s] = 0;
 		hopCount[s] = 0;
+		leavesPendingV[s] = 0;
 		clearBits[s] = 0;
 		if (active && !active[s]) continue;
 		lastHop[s].slot = -1; // smst_batch_debug_get_map reports the newest hop of THIS call only
@@ -711,6 +994,7 @@ void Batch::process(const float *in, long long inSS, long long inCS, const int *
 				if (sc.silenceFirst) {
 					sc.silenceFirst = false;
 					sc.samplesSinceLast = SIZE_MAX; // blockProcess = {}
+					pend[s] = PendingBlock();       // ... which drops the block in flight
 					clearBits[s] = 2 | 4 | 8;       // Band.input / .prevInput / .output := 0
 					anyClear = true;
 				}
@@ -726,13 +1010,23 @@ void Batch::process(const float *in, long long inSS, long long inCS, const int *
 		}
 		const int first = (sc.samplesSinceLast >= size_t(I)) ? 0 : int(size_t(I) - sc.samplesSinceLast);
 		hopFirst[s] = first;
-		hopCount[s] = (nOut[s] > first) ? (nOut[s] - first + I - 1)/I : 0;
+		const int starts = (nOut[s] > first) ? (nOut[s] - first + I - 1)/I : 0; // blocks that begin in this call (:281)
+		if (split) {
+			// split computation: a block is finished when its interval is (:321-325).  The block in flight from earlier calls runs now if
+			// this call reaches the end of its interval; the last block that begins here stays in flight unless its interval ends here too
+			if (pend[s].valid && nOut[s] >= first) pendList.push_back(s);
+			hopCount[s] = (nOut[s] > first) ? (nOut[s] - first)/I : 0;
+			leavesPendingV[s] = starts > hopCount[s];
+		} else {
+			hopCount[s] = starts;
+		}
 		maxHops = std::max(maxHops, hopCount[s]);
 	}
 	if (anyClear) { // asynchronous: the masks travel on `st`, ahead of the launch that reads them
 		SMST_HIP(hipMemcpyAsync(cs.resetBits, clearBits, S*sizeof(int), hipMemcpyHostToDevice, st));
 		launchResetStreams(d, cs.resetBits, 0, dSeedWp, st);
 	}
+	if (!pendList.empty()) runPendingBlocks(nullptr);
 	const int nTiles = std::max(1, (maxHops + T - 1)/T);
 	const int hopStride = nTiles*T;
 	const int nSub = (S + subS - 1)/subS;
@@ -783,19 +1077,23 @@ void Batch::process(const float *in, long long inSS, long long inCS, const int *
 	std::fill(tileHasV.begin(), tileHasV.end(), 0);
 
 	// K0, pass 2: block scheduler, exactly as signalsmith-stretch.h:280-319 does it per stream, straight into the tables
+	bool anyPendAnalysis = false, pendInCall = false, pendLate = false;
 	for (int s = 0; s < S; ++s) {
 		const int sub = s/subS, sl = s%subS;
 		HopDesc *list = hopsAll + (size_t)s*hopStride;
 		const int nh = hopCount[s];
-		if (nh > 0) {
+		const int nStart = nh + (leavesPendingV[s] ? 1 : 0); // split computation: the last block that begins here may stay in flight
+		if (split) cs.hPendHops[s] = HopDesc{};
+		if (nStart > 0) {
 			StreamSched &sc = sched[s];
 			const StreamParams &prm = params[s];
 			const bool mapped = prm.hasCustomMap || prm.freqMultiplier != 1; // :300
 			const bool formants = prm.formantMultiplier != 1 || (prm.formantCompensation && mapped); // :310
 			int lastNew = -1;
 			int o = hopFirst[s];
-			for (int j = 0; j < nh; ++j, o += I) {
-				HopDesc &hd = list[j];
+			for (int j = 0; j < nStart; ++j, o += I) {
+				HopDesc inFlight{};
+				HopDesc &hd = (j < nh) ? list[j] : inFlight;
 				int inputOffset = int(std::round(o*float(nIn[s])/nOut[s])); // :288 (fp32 on purpose)
 				int inputInterval = inputOffset - sc.prevInputOffset;
 				sc.prevInputOffset = inputOffset;
@@ -819,6 +1117,24 @@ void Batch::process(const float *in, long long inSS, long long inCS, const int *
 				hd.flags = flags;
 				hd.seed = sc.seed; // the engine's state before this hop's draws
 				if (flags & HOP_RANDOM_TF) sc.seed = unsigned((unsigned long long)sc.seed*lcgHopJump % 2147483647ull); // 2M - 2 draws later
+				if (j == nh) {
+					// in flight at the end of the call: analysed now, from the input as it stands (:293 stashes it), into the pending buffers;
+					// everything else when its interval is complete -- or when a flush() needs to know how far it has come
+					PendingBlock &pb = pend[s];
+					pb = PendingBlock();
+					pb.valid = true;
+					pb.flags = flags;
+					pb.timeFactor = tf;
+					pb.seed = hd.seed;
+					HopDesc &ph = cs.hPendHops[s];
+					ph.inputOffset = inputOffset;
+					ph.flags = flags & (HOP_ACTIVE | HOP_NEW_SPECTRUM | HOP_REANALYSE_PREV);
+					if (newSpectrum) {
+						anyPendAnalysis = true;
+						for (int which = 0; which < (reanalyse ? 2 : 1); ++which) (analysisWindowInCall(d.B, d.M, d.I, inputOffset, which, nIn[s]) ? pendInCall : pendLate) = true;
+					}
+					continue;
+				}
 				const int tile = j/T;
 				const bool lastInTile = lastNew >= 0 && lastNew/T == tile;
 				hd.inSrc = newSpectrum ? j%T : (lastInTile ? lastNew%T : SRC_STATE);
@@ -875,6 +1191,7 @@ void Batch::process(const float *in, long long inSS, long long inCS, const int *
 	SMST_HIP(hipMemcpyAsync(dEmit, emitAll, needEmit*sizeof(EmitDesc), hipMemcpyHostToDevice, stGate));
 	SMST_HIP(hipMemcpyAsync(dTileInfo, tileInfo, needInfo*sizeof(int), hipMemcpyHostToDevice, stGate));
 	if (anyPass) SMST_HIP(hipMemcpyAsync(dFlags, passFlags, S*sizeof(int), hipMemcpyHostToDevice, stGate));
+	if (anyPendAnalysis) SMST_HIP(hipMemcpyAsync(cs.pendHops, cs.hPendHops, S*sizeof(HopDesc), hipMemcpyHostToDevice, stGate));
 	// the kernels below are ordered after the uploads by an event, not by the host
 	SMST_HIP(hipEventRecord(cs.tables, stGate));
 	SMST_HIP(hipStreamWaitEvent(st, cs.tables, 0));
@@ -884,109 +1201,19 @@ void Batch::process(const float *in, long long inSS, long long inCS, const int *
 	d.hopStride = hopStride;
 	d.emitStride = nTiles;
 
-	const int carryBase = d.carryCur;
-	// Three HIP streams: `st` runs the feed-forward kernels of tile q, `stChain` the recurrence of tile q (a few
-	// hundred waves, instruction-issue bound), `stSynth` synthesis + emission.  Two workspaces alternate, so the bulk
-	// kernels of the next tile fill the machine while the recurrence of the current one is in flight.
-	const bool serial = profiling || !overlap;
-	const bool singleHop = singleHopSupported(d) && !noSingleHop;
-	hipStream_t sF = st, sC = serial ? st : stChain, sS = serial ? st : stSynth;
-	if (!serial) {
-		SMST_HIP(hipEventRecord(evStart, st));
-		SMST_HIP(hipStreamWaitEvent(sC, evStart, 0));
-		SMST_HIP(hipStreamWaitEvent(sS, evStart, 0));
-	}
-	int q = 0;
-	for (int sub = 0; sub < nSub; ++sub) {
-		const int sBase = sub*subS;
-		const int ns = std::min(subS, S - sBase);
-		for (int t = 0; t < nTiles; ++t, ++q) {
-			const unsigned char *th = tileHasV.data() + (size_t)(sub*nTiles + t)*8;
-			const int hopBase = t*T;
-			const int tileHops = std::min(T, std::max(1, maxHops - hopBase));
-			const int slot = q & 1;
-			const bool plain = !(th[1] || th[2]);
-			const bool fused = fusedSupported(d) && !noFuse; // mono/stereo: records stay in LDS (kVocoder)
-			const TileBuffers &w = slots[slot];
-			DevBatch dd = d;
-			dd.Xcur = w.Xcur; dd.Xprev = w.Xprev; dd.PE = w.PE; dd.OUT = w.OUT; dd.REC = w.REC; dd.dump = w.dump;
-			dd.map = w.map; dd.ratio = w.ratio; dd.energyT = w.energyT; dd.smoothT = w.smoothT; dd.peaksT = w.peaksT; dd.est = w.est; dd.freqEst = w.freqEst; dd.frames = w.frames;
-			dd.carryCur = (carryBase + t) & 1;
-			dd.nHops = dTileInfo + ((size_t)(sub*nTiles + t)*2)*subS;
-			dd.lastNewHop = dd.nHops + subS;
-			if (!serial && q >= 2) { // this workspace was last used by tile q-2
-				SMST_HIP(hipStreamWaitEvent(sF, evChain[slot], 0));
-				SMST_HIP(hipStreamWaitEvent(sF, evSynth[slot], 0));
-			}
-			if (!serial && fused && !plain && q >= 1) SMST_HIP(hipStreamWaitEvent(sF, evChain[slot ^ 1], 0)); // pass A reads the carried state
-			if (th[0]) {
-				if (th[3]) timed(timings.analyseMs, [&] { launchAnalyse(dd, io, sBase, ns, hopBase, tileHops, th[5] != 0, th[6] != 0, sF); if (profiling) ++timings.analyseLaunches; });
-				bool passADone = false;
-				if (th[1] || th[2]) timed(timings.feedMs, [&] { passADone = launchFeed(dd, sBase, ns, hopBase, tileHops, th[2] != 0, sF); });
-				timed(timings.predictMs, [&] {
-					if (fused) launchPredictFused(dd, sBase, ns, hopBase, tileHops, plain, passADone, sF);
-					else launchPredict(dd, sBase, ns, hopBase, tileHops, plain, passADone, sF);
-					if (profiling) ++timings.predictLaunches;
-				});
-				// the carried feed-forward state (Band.input/.prevInput, Prediction.energy) may only move on once every
-				// reader of the OLD state has run: in the fused path the producers inside kVocoder still read it
-				if (!fused) timed(timings.otherMs, [&] { launchCarryFeed(dd, sBase, ns, hopBase, th[2] != 0, sF); });
-			}
-			checkLaunch("analysis / feed-forward kernels");
-			if (!serial) {
-				SMST_HIP(hipEventRecord(evFeed[slot], sF));
-				SMST_HIP(hipStreamWaitEvent(sC, evFeed[slot], 0));
-			}
-			if (th[0]) {
-				hipEvent_t liveA = nullptr, liveB = nullptr;
-				if (liveTiming && !serial) {
-					if (liveEvents.size() == livePool.size()) growLivePool(livePool.size() + 64); // only if a run outgrows what enableProfiling() made
-					liveA = livePool[liveEvents.size()].first;
-					liveB = livePool[liveEvents.size()].second;
-					SMST_HIP(hipEventRecord(liveA, sC));
-				}
-				timed(timings.chainMs, [&] {
-					if (fused && tileHops == 1 && singleHop && !noAcross && acrossSupported(dd)) launchVocoderAcross(dd, sBase, ns, hopBase, plain, sC);
-					else if (fused && tileHops == 1 && singleHop) launchVocoderOne(dd, sBase, ns, hopBase, plain, sC);
-					else if (fused) launchVocoder(dd, sBase, ns, hopBase, plain, !th[4], sC);
-					else launchChain(dd, sBase, ns, hopBase, sC);
-					if (profiling) ++timings.chainLaunches;
-				});
-				if (liveA) {
-					SMST_HIP(hipEventRecord(liveB, sC));
-					liveEvents.emplace_back(liveA, liveB);
-				}
-				timed(timings.otherMs, [&] {
-					if (fused) launchCarryFeed(dd, sBase, ns, hopBase, th[2] != 0, sC);
-					launchCarryOut(dd, sBase, ns, sC);
-				});
-			}
-			checkLaunch("bin recurrence");
-			// synthesis + overlap-add + emission in one kernel where the geometry and the batch allow it; its window products depend on
-			// nothing the recurrence writes: queued in front of the wait for it
-			const bool emitted = th[0] && synthEmitApplies(dd, ns, tileHops);
-			if (emitted) timed(timings.otherMs, [&] { launchEmitProducts(dd, sBase, ns, t, sS); });
-			if (!serial) {
-				SMST_HIP(hipEventRecord(evChain[slot], sC));
-				SMST_HIP(hipStreamWaitEvent(sS, evChain[slot], 0));
-			}
-			if (th[0]) timed(timings.synthMs, [&] {
-				if (emitted) launchSynthEmit(dd, io, sBase, ns, t, sS);
-				else launchSynth(dd, sBase, ns, hopBase, tileHops, sS);
-				if (profiling) ++timings.synthLaunches;
-			});
-			if (!emitted) timed(timings.emitMs, [&] { launchEmit(dd, io, sBase, ns, t, maxSpanV[(size_t)sub*nTiles + t], sS); if (profiling) ++timings.emitLaunches; });
-			checkLaunch("synthesis / emission");
-			if (!serial) SMST_HIP(hipEventRecord(evSynth[slot], sS));
-		}
-	}
-	if (!serial) { // everything the caller can observe is ordered on `st` again
-		for (int i = 0; i < 2 && i < q; ++i) {
-			SMST_HIP(hipStreamWaitEvent(st, evChain[i], 0));
-			SMST_HIP(hipStreamWaitEvent(st, evSynth[i], 0));
-		}
-	}
-	d.carryCur = (carryBase + nTiles) & 1;
+	runTiles(TileRun{&io, nTiles, maxHops, tileHasV.data(), maxSpanV.data(), dTileInfo, false, nullptr});
+	if (anyPendAnalysis) timed(timings.analyseMs, [&] {
+		// the blocks left in flight: their spectra (Band.input and, where :303 asks for it, the re-analysed Band.prevInput) into the pending
+		// buffers, laid out as a one-hop tile over ALL streams
+		DevBatch dp = d;
+		dp.hops = cs.pendHops;
+		dp.hopStride = 1;
+		dp.T = 1;
+		dp.Xcur = dPendIn;
+		dp.Xprev = dPendPrev;
+		launchAnalyse(dp, io, 0, S, 0, 1, pendInCall, pendLate, st);
+		if (profiling) ++timings.analyseLaunches;
+	});
 	timed(timings.otherMs, [&] {
 		if (anyPass) launchPassThrough(d, io, dFlags, maxOut, st);
 		launchHistory(d, io, st);
@@ -1077,6 +1304,37 @@ void Batch::flush(float *out, long long outSS, long long outCS, const int *outSa
 		}
 		process(dZeros, 0, 0, blockIn.data(), out, outSS, outCS, blockOut.data(), runBlock.data());
 	}
+	// Split computation, between two interval boundaries: how far has the block in flight come?  (:321-325 spread its steps over the
+	// interval; flush() reads the REAL ring, one interval ahead of the stashed one that process() emits from, then stft.reset(0.1) and
+	// prevInput = output = 0, :442-463 -- and the block's remaining steps run afterwards, on what the flush left.  Pinned step by step by
+	// tests/golden/split_events.)
+	std::vector<int> synthChannels;
+	pendList.clear();
+	for (int s = 0; s < S; ++s) {
+		if (!on[s] || !split || !pend[s].valid) continue;
+		PendingBlock &pb = pend[s];
+		const StepLayout l = stepLayout(pb.flags);
+		const size_t e = stepsExecuted(size_t(l.steps), sched[s].samplesSinceLast);
+		if (e > size_t(l.synth0)) {
+			// the spectrum is complete and e - synth0 channels have been synthesised into the ring (all of them: the block is finished): run
+			// the block now; the other channels' frames never come -- stft.reset() clears the spectrum they would be made from
+			if (synthChannels.empty()) synthChannels.assign(S, -1);
+			synthChannels[s] = (e >= size_t(l.steps)) ? -1 : int(e) - l.synth0;
+			pendList.push_back(s);
+		} else if (e >= size_t(l.spectrum)) {
+			// output (and, after `.input -> .prevInput`, prevInput) were complete and are zeroed; what remains is a silent frame: its window product
+			pb.startBin = M;
+			pb.zeroPrevAfter = true;
+		} else if (e > size_t(l.main0)) {
+			// e - main0 chunks of the main prediction ran: those bins are zero now, the later chunks start from zeros (:725-726)
+			pb.startBin = std::max(pb.startBin, int(size_t(M)*(e - size_t(l.main0))/8));
+		} else if (l.copyIn >= 0 && e > size_t(l.analyse0) && e <= size_t(l.copyIn)) {
+			// e - analyse0 channels were analysed, not yet copied into Band.input: stft.reset() cleared their spectra (:356-373)
+			const int n = std::min(C, int(e) - l.analyse0);
+			SMST_HIP(hipMemsetAsync(dPendIn + (size_t)s*C*d.Mp, 0, (size_t)n*d.Mp*sizeof(float2), st));
+		}
+	}
+	if (!pendList.empty()) runPendingBlocks(synthChannels.data());
 	for (int s = 0; s < S; ++s) {
 		if (!on[s]) continue;
 		const StreamSched &sc = sched[s];
@@ -1089,9 +1347,10 @@ void Batch::flush(float *out, long long outSS, long long outCS, const int *outSa
 	SMST_HIP(hipStreamSynchronize(st));
 	IoArgs io{nullptr, out, 0, 0, outSS, outCS, dInSamples, dOutSamples};
 	launchFlushTail(d, io, dAux0, dAux1, st);
-	// stft.reset(0.1) + zero prevInput/output (:456-463)
-	for (int s = 0; s < S; ++s) { resetBitsV[s] = on[s] ? (1 | 4 | 8) : 0; if (on[s]) lastHop[s] = LastHop(); }
-	resetStreams(resetBitsV.data(), 0);
+	// stft.reset(0.1) + zero prevInput/output (:456-463).  Split computation: the samples up to the end of the interval still come from
+	// the stashed ring (:407-415), which the reset does not touch -- the fresh ring begins behind them
+	for (int s = 0; s < S; ++s) { resetBitsV[s] = on[s] ? (1 | 4 | 8) : 0; keepV[s] = on[s] ? tailOff[s] : 0; if (on[s]) lastHop[s] = LastHop(); }
+	resetStreams(resetBitsV.data(), 0, split ? keepV.data() : nullptr);
 	SMST_HIP(hipGetLastError());
 }
 
@@ -1164,6 +1423,11 @@ void Batch::copyStateFrom(Batch &o) {
 	sched = o.sched;
 	params = o.params;
 	paramsDirty = true;
+	pend = o.pend;
+	if (split) {
+		copy(dPendIn, o.dPendIn, (size_t)S*C*d.Mp*sizeof(float2));
+		copy(dPendPrev, o.dPendPrev, (size_t)S*C*d.Mp*sizeof(float2));
+	}
 	if (o.d.mapTableLen > 0) {
 		if (dMapTable) devFree(dMapTable);
 		dMapTable = devAlloc<float>((size_t)S*o.d.mapTableLen);

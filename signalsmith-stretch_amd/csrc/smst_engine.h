@@ -20,6 +20,25 @@ struct StreamSched { // reference members: signalsmith-stretch.h:494-529
 	unsigned seed = 0;                  // randomEngine, :616 -- the state of libstdc++'s minstd_rand0 (smst_kernels_common.h: engineDraw)
 };
 
+// Split computation (signalsmith-stretch.h:292-296,321-325): a block's steps are spread over its interval, so between two interval
+// boundaries one block is IN FLIGHT -- analysed from the input as it stood at the block's start (:293), everything else still to come,
+// and the steps that come read the live parameters and the live Band state.  The engine analyses such a block when it starts, keeps its
+// spectra, and runs the rest when the interval is complete (or when a flush() needs part of it); what happened in between is recorded here.
+struct PendingBlock {
+	bool valid = false;
+	unsigned flags = 0;      // HopDesc.flags as latched at the block's start (:299-310)
+	float timeFactor = 1;    // :312
+	unsigned seed = 0;       // the random engine's state before this block's draws
+	int startBin = 0;        // a flush() between two chunks of the main prediction (:722-803): the bins below were computed, then zeroed (:458-463)
+	bool zeroPrevAfter = false; // a flush() after `.input -> .prevInput` (:806-811): Band.prevInput stays zero
+	// the parameters as findPeaks (:874), updateFormants step 0 (:982) and step 2 (:1020) saw them, once each has run (frozen*)
+	bool frozenPeaks = false, frozenForm0 = false, frozenForm2 = false;
+	StreamParams peaks{}, form0{}, form2{};
+};
+struct StepLayout { // index of each step of a block in the reference's order (:304-318, :620-632); -1: the block has no such step
+	int reanalyse0 = -1, analyse0 = -1, copyIn = -1, peaks = -1, form0 = -1, form2 = -1, main0 = 0, prevCopy = -1, spectrum = 0, synth0 = 0, steps = 0;
+};
+
 struct BatchTimings { // filled when profiling is enabled (hipEvent pairs around each kernel class)
 	double analyseMs = 0, feedMs = 0, predictMs = 0, chainMs = 0, synthMs = 0, emitMs = 0, otherMs = 0;
 	long analyseLaunches = 0, synthLaunches = 0, chainLaunches = 0, predictLaunches = 0, emitLaunches = 0;
@@ -113,6 +132,7 @@ private:
 	struct CallSet {
 		int *inSamples, *outSamples, *flags, *tileInfo, *resetBits; HopDesc *hops; EmitDesc *emit;
 		int *hInSamples, *hOutSamples, *hFlags, *hTileInfo, *hResetBits; HopDesc *hHops; EmitDesc *hEmit; float *hEnergy;
+		HopDesc *pendHops = nullptr, *hPendHops = nullptr; // split computation: the block each stream leaves in flight at the end of the call ([S], analysis only)
 		size_t hopsCap, emitCap, tileInfoCap;
 		hipEvent_t done, tables; bool used;
 		std::vector<void *> retiredDevice, retiredPinned; // outgrown tables that the previous call may still read
@@ -124,7 +144,7 @@ private:
 	int subS = 0;
 	// per-call host scratch, kept between calls (no heap traffic in steady state); growth events are counted
 	std::vector<int> hopFirst, hopCount, maxSpanV;
-	std::vector<unsigned char> tileHasV, passV;
+	std::vector<unsigned char> tileHasV, passV, leavesPendingV;
 	long allocEvents = 0; // device allocations + pinned allocations + host table growth since construction
 	size_t wsBytes = 0;
 	DevBatch d{};
@@ -134,6 +154,25 @@ private:
 	std::vector<LastHop> lastHop; // where each stream's newest hop sits in the tile workspaces (debugGetMap)
 	std::vector<StreamParams> params;
 	bool paramsDirty = true;
+	// ---- split computation: the block in flight (see PendingBlock) ----
+	std::vector<PendingBlock> pend;
+	float2 *dPendIn = nullptr, *dPendPrev = nullptr; // its spectra, [S][C][Mp]: Band.input and (re-analysed) Band.prevInput
+	struct PendSet { // tables of one run of blocks in flight (double-buffered like CallSet: pinned staging, asynchronous uploads)
+		HopDesc *hops, *hHops; EmitDesc *emit, *hEmit; int *tileInfo, *hTileInfo, *bits, *hBits, *synthChannels, *hSynthChannels;
+		StreamParams *prm[3], *hPrm[3];
+		hipEvent_t done; bool used;
+	} pendSets[2]{};
+	int pendCur = 0;
+	int *dZeroCounts = nullptr; // [S] zeros: the sample counts of a run that consumes and emits nothing
+	std::vector<int> pendList;  // streams of the run being prepared
+	std::vector<unsigned char> pendTileHas;
+	std::vector<int> pendMaxSpan, keepV;
+	StepLayout stepLayout(unsigned flags) const;
+	size_t stepsExecuted(size_t steps, size_t samplesIntoInterval) const;
+	void freezePendingParams(int s);   // before a setter changes params[s]
+	void runPendingBlocks(const int *synthChannels); // runs the blocks of `pendList` (a tile of one hop per stream; no input, no output samples)
+	struct TileRun { const IoArgs *io; int nTiles, maxHops; const unsigned char *tileHas; const int *maxSpan; const int *dTileInfo; bool pendingRun; const int *dSynthChannels; };
+	void runTiles(const TileRun &run);
 	bool profiling = false, liveTiming = false;
 	std::vector<std::pair<hipEvent_t, hipEvent_t>> liveEvents; // pairs recorded since the last takeTimings()
 	std::vector<std::pair<hipEvent_t, hipEvent_t>> livePool;   // every pair ever created; [0, liveEvents.size()) are in use
@@ -153,10 +192,10 @@ private:
 	template <typename T> T *pinnedAlloc(size_t count);
 	void pinnedFree(void *p);
 	void releaseAll();
-	void resetStreams(const int *bitsHost, int allBits); // per-stream bit masks (kResetStreams) or null = allBits for all; synchronous upload (reset / flush)
+	void resetStreams(const int *bitsHost, int allBits, const int *keepHost = nullptr); // per-stream bit masks (kResetStreams) or null = allBits for all; keepHost: see launchResetStreams; synchronous upload (reset / flush)
 	bool checkLaunches = false; // SMST_CHECK_LAUNCHES=1: hipGetLastError() after every launch group of process(), not only at its end
 	void checkLaunch(const char *what);
-	int *dResetBits = nullptr;
+	int *dResetBits = nullptr, *dKeep = nullptr;
 	std::vector<int> resetBitsV;
 	float *dZeros = nullptr;
 	size_t zerosCapacity = 0;

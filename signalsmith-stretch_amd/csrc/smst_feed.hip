@@ -82,7 +82,7 @@ __global__ __launch_bounds__(64) void kFeedSerial(DevBatch d, int sBase, int hop
 	const HopDesc hd = d.hops[(size_t)sg*d.hopStride + hopBase + (k < nh ? k : 0)];
 	const bool active = k < nh;
 	const bool mapped = active && (hd.flags & HOP_MAPPED), formants = active && (hd.flags & HOP_FORMANTS);
-	const StreamParams prm = d.params[sg];
+	const StreamParams prm = d.paramsPeaks[sg], prmF0 = d.paramsForm0[sg], prmF2 = d.paramsForm2[sg]; // findPeaks / updateFormants(0) / (2) may see different live values (smst_device.h)
 	const float *eT = d.energyT + (size_t)s*M*64 + k;
 	float *sT = d.smoothT + (size_t)s*M*64 + k;
 	float2 *pk = d.peaksT + (size_t)s*(M/2 + 2)*64 + k;
@@ -170,7 +170,7 @@ __global__ __launch_bounds__(64) void kFeedSerial(DevBatch d, int sBase, int hop
 
 	if (__any(formants)) {
 		// updateFormants, :972-1036.  The metric is the channel-summed energy (:974-980).
-		const bool autoBase = formants && prm.formantBaseFreq <= 0;
+		const bool autoBase = formants && prmF0.formantBaseFreq <= 0;
 		float pw = 0, ww = 0;
 		if (__any(autoBase)) { // estimateFrequency() raw part, :929-960
 			int p0 = 0, p1 = 0, p2 = 0;
@@ -208,7 +208,7 @@ __global__ __launch_bounds__(64) void kFeedSerial(DevBatch d, int sBase, int hop
 				d.est[((size_t)s*d.T + k)*2 + 1] = ww;
 			}
 		}
-		float freqEstimate = prm.formantBaseFreq*Nf - 0.5f; // freqToBand, :982
+		float freqEstimate = prmF0.formantBaseFreq*Nf - 0.5f; // freqToBand, :982
 		if (__any(autoBase)) { // :962-965 -- the estimate is smoothed from hop to hop: replay the hops of the tile in order
 			float w = d.stFreq[2*sg], wt = d.stFreq[2*sg + 1];
 			float mine = 0;
@@ -247,10 +247,10 @@ __global__ __launch_bounds__(64) void kFeedSerial(DevBatch d, int sBase, int hop
 			float *ratio = d.ratio + ((size_t)s*d.T + k)*M;
 			for (int b = 0; b < M; ++b) {
 				float inputF = (b + 0.5f)/Nf;
-				float outputF = prm.formantCompensation ? mapFreqDev(d, prm, sg, inputF) : inputF;
+				float outputF = prmF2.formantCompensation ? mapFreqDev(d, prmF2, sg, inputF) : inputF;
 				// invMapFormant, :920-925
-				if (outputF*prm.invFormantMultiplier > prm.freqTonalityLimit) outputF = outputF + (1 - prm.formantMultiplier)*prm.freqTonalityLimit;
-				else outputF = outputF*prm.invFormantMultiplier;
+				if (outputF*prmF2.invFormantMultiplier > prmF2.freqTonalityLimit) outputF = outputF + (1 - prmF2.formantMultiplier)*prmF2.freqTonalityLimit;
+				else outputF = outputF*prmF2.invFormantMultiplier;
 				const float inputE = sT[(size_t)b*64];
 				float band = outputF*Nf - 0.5f;
 				float targetE = 0;
@@ -432,7 +432,7 @@ __global__ __launch_bounds__(256) void kFeedScanA(DevBatch d, int sBase, int hop
 	float2 *pk = reinterpret_cast<float2 *>(sm + M);          // [M/2 + 2] peaks
 	ScanMap *maps = reinterpret_cast<ScanMap *>(pk + M/2 + 2); // [264]
 	int *counts = reinterpret_cast<int *>(maps + 264);         // [264]
-	const StreamParams prm = d.params[sg];
+	const StreamParams prm = d.paramsPeaks[sg];
 	feedEnergyToLds(d, hd, s, sg, en);
 	__syncthreads();
 	if (mapped) {
@@ -600,7 +600,7 @@ __global__ __launch_bounds__(256) void kFeedScanA(DevBatch d, int sBase, int hop
 			}
 		}
 	}
-	if (formants && prm.formantBaseFreq <= 0) {
+	if (formants && d.paramsForm0[sg].formantBaseFreq <= 0) {
 		// estimateFrequency() raw part, :929-960: the three highest local maxima of the metric (= the channel-summed
 		// energy), ties to the earlier bin, three copies of bin 0 as the initial entries -- a serial walk by one thread
 		// (compares only, no arithmetic: 3 k steps)
@@ -641,7 +641,7 @@ __global__ __launch_bounds__(64) void kFeedFreq(DevBatch d, int sBase, int nStre
 	const int s = blockIdx.x*blockDim.x + threadIdx.x;
 	if (s >= nStreams) return;
 	const int sg = sBase + s, nh = d.nHops[s];
-	const StreamParams prm = d.params[sg];
+	const StreamParams prm = d.paramsForm0[sg];
 	const float Nf = float(d.N);
 	float w = d.stFreq[2*sg], wt = d.stFreq[2*sg + 1];
 	for (int j = 0; j < nh; ++j) {
@@ -675,7 +675,7 @@ __global__ __launch_bounds__(256) void kFeedScanC(DevBatch d, int sBase, int hop
 	float *en = reinterpret_cast<float *>(smemRaw);
 	float *sm = en + M;
 	ScanMap *maps = reinterpret_cast<ScanMap *>(sm + M);
-	const StreamParams prm = d.params[sg];
+	const StreamParams prm = d.paramsForm2[sg];
 	feedEnergyToLds(d, hd, s, sg, en);
 	__syncthreads();
 	const float freqEstimate = d.freqEst[(size_t)s*d.T + k];

@@ -28,7 +28,7 @@ __global__ __launch_bounds__(256) void kCarryFeed(DevBatch d, int sBase, int hop
 		bool any = false;
 		for (int j = 0; j < nh; ++j) {
 			const HopDesc hj = d.hops[(size_t)sg*d.hopStride + hopBase + j];
-			if (!(hj.flags & HOP_FORMANTS) || d.params[sg].formantBaseFreq > 0) continue;
+			if (!(hj.flags & HOP_FORMANTS) || d.paramsForm0[sg].formantBaseFreq > 0) continue;
 			w += (d.est[((size_t)s*d.T + j)*2] - w)*0.25f;
 			wt += (d.est[((size_t)s*d.T + j)*2 + 1] - wt)*0.25f;
 			any = true;
@@ -76,22 +76,26 @@ __global__ __launch_bounds__(256) void kPassThrough(DevBatch d, IoArgs io, const
 // reset() / flush() / first silent block (signalsmith-stretch.h:49-60, :456-463, :244-251) for the selected streams in ONE
 // launch.  Per-stream bit mask: 1 = stft.reset(0.1) (overlap-add sums and input history cleared, window products re-seeded,
 // both halves of the double buffers), 2 / 4 / 8 = clear Band.input / .prevInput / .output.
-__global__ __launch_bounds__(256) void kResetStreams(DevBatch d, const int *__restrict__ flags, int allBits, const float *__restrict__ seedWp) {
+__global__ __launch_bounds__(256) void kResetStreams(DevBatch d, const int *__restrict__ flags, int allBits, const float *__restrict__ seedWp, const int *__restrict__ keep) {
 	const int sg = blockIdx.y;
 	const int bits = flags ? flags[sg] : allBits;
 	if (!bits) return;
 	const int i = blockIdx.x*blockDim.x + threadIdx.x;
 	const int CL = d.carryLen, HL = d.histLen, M = d.M, C = d.C;
 	if (bits & 1) {
+		// split computation, between two interval boundaries: the samples up to the end of the interval are read from the stashed ring, which
+		// stft.reset() does not touch (:407-415); the real ring -- re-seeded -- begins behind them
+		const int kp = keep ? keep[sg] : 0, cur = d.carryCur;
 		if (i < CL) {
-			const float w = seedWp[i];
+			const float w = (i < kp) ? d.carryWp[cur][(size_t)sg*CL + i] : seedWp[i - kp];
 			d.carryWp[0][(size_t)sg*CL + i] = w;
 			d.carryWp[1][(size_t)sg*CL + i] = w;
 		}
 		for (int c = 0; c < C; ++c) {
 			if (i < CL) {
-				storeCarrySum(d, 0, ((size_t)sg*C + c)*CL + i, 0.0f);
-				storeCarrySum(d, 1, ((size_t)sg*C + c)*CL + i, 0.0f);
+				const float v = (i < kp) ? loadCarrySum(d, cur, ((size_t)sg*C + c)*CL + i) : 0.0f;
+				storeCarrySum(d, 0, ((size_t)sg*C + c)*CL + i, v);
+				storeCarrySum(d, 1, ((size_t)sg*C + c)*CL + i, v);
 			}
 			if (i < HL) {
 				d.hist[0][((size_t)sg*C + c)*HL + i] = 0.0f;
@@ -108,6 +112,26 @@ __global__ __launch_bounds__(256) void kResetStreams(DevBatch d, const int *__re
 			if (bits & 8) storeCarriedOutput(d, o, zero);
 		}
 	}
+}
+
+// split computation: the block in flight was analysed when it started (:293, :332-373); its spectra wait in [S][C][Mp] buffers and enter the
+// tile that finally runs the block as row 0 (Xcur: Band.input, Xprev: the re-analysed Band.prevInput)
+__global__ __launch_bounds__(256) void kPendingToTile(DevBatch d, int sBase, const float2 *__restrict__ pendIn, const float2 *__restrict__ pendPrev) {
+	const int s = blockIdx.z, sg = sBase + s, c = blockIdx.y;
+	const int b = blockIdx.x*blockDim.x + threadIdx.x;
+	if (d.nHops[s] == 0 || b >= d.M) return;
+	const size_t src = ((size_t)sg*d.C + c)*(size_t)d.Mp + b, dst = rowOf(d, s, 0, c) + b;
+	d.Xcur[dst] = pendIn[src];
+	d.Xprev[dst] = pendPrev[src];
+}
+// ... and a flush() between two of its synthesis steps (:397-399): the channels that had not been synthesised add nothing afterwards
+// (stft.reset() cleared the spectrum they would have been made from)
+__global__ __launch_bounds__(256) void kMaskOutRows(DevBatch d, int sBase, const int *__restrict__ synthChannels) {
+	const int s = blockIdx.z, sg = sBase + s, c = blockIdx.y;
+	const int b = blockIdx.x*blockDim.x + threadIdx.x;
+	const int from = synthChannels[sg];
+	if (d.nHops[s] == 0 || b >= d.M || from < 0 || c < from) return;
+	d.OUT[rowOf(d, s, 0, c) + b] = make_float2(0.f, 0.f);
 }
 
 // seek(): history = the last B+I samples of the (zero-padded) pre-roll  (signalsmith-stretch.h:140-158)
@@ -214,9 +238,15 @@ void launchPassThrough(const DevBatch &d, const IoArgs &io, const int *passFlags
 	if (bx < 1) bx = 1;
 	hipLaunchKernelGGL(kPassThrough, dim3(bx, d.C, d.S), dim3(256), 0, st, d, io, passFlags);
 }
-void launchResetStreams(const DevBatch &d, const int *flags, int allBits, const float *seedWp, hipStream_t st) {
+void launchResetStreams(const DevBatch &d, const int *flags, int allBits, const float *seedWp, hipStream_t st, const int *keep) {
 	const int span = d.carryLen > d.M ? (d.carryLen > d.histLen ? d.carryLen : d.histLen) : (d.M > d.histLen ? d.M : d.histLen);
-	hipLaunchKernelGGL(kResetStreams, dim3(divUp(span, 256), d.S), dim3(256), 0, st, d, flags, allBits, seedWp);
+	hipLaunchKernelGGL(kResetStreams, dim3(divUp(span, 256), d.S), dim3(256), 0, st, d, flags, allBits, seedWp, keep);
+}
+void launchPendingToTile(const DevBatch &d, int sBase, int nStreams, const float2 *pendIn, const float2 *pendPrev, hipStream_t st) {
+	hipLaunchKernelGGL(kPendingToTile, dim3(divUp(d.M, 256), d.C, nStreams), dim3(256), 0, st, d, sBase, pendIn, pendPrev);
+}
+void launchMaskOutRows(const DevBatch &d, int sBase, int nStreams, const int *synthChannels, hipStream_t st) {
+	hipLaunchKernelGGL(kMaskOutRows, dim3(divUp(d.M, 256), d.C, nStreams), dim3(256), 0, st, d, sBase, synthChannels);
 }
 void launchSeekHistory(const DevBatch &d, const IoArgs &io, const int *seekFlags, hipStream_t st) {
 	hipLaunchKernelGGL(kSeekHistory, dim3(divUp(d.histLen, 256), d.C, d.S), dim3(256), 0, st, d, io, seekFlags);

@@ -32,7 +32,8 @@ struct HopDesc {
 	float timeFactor; // already clamped to >= 1/maxCleanStretch (:638)
 	int outPos;       // output index (within the call) at which this hop fires (:280-285)
 	unsigned seed;    // counter-based RNG stream for timeFactor > 2 (:639-640)
-	int pad;
+	int startBin;     // 0, except for a split-computation block that a flush() interrupted between two chunks of the main prediction
+	                  // (:722-803 ran for the bins below, then :458-463 zeroed them): outputs below this bin stay zero (kVocoderOne only)
 };
 
 // Per-stream emission window of a tile (K4 overlap-add gather)

@@ -457,6 +457,9 @@ __global__ __launch_bounds__(128) void kVocoderOne(DevBatch d, int sBase, int ho
 
 	// ---------------- consumer (wave 0): every lane runs the chain of hop 0; lane 0 publishes ----------------
 	__builtin_amdgcn_s_setprio(3);
+	// split computation: a flush() that fell between two chunks of this block's main prediction zeroed the bins that had been computed
+	// (:458-463); the chunks that ran afterwards began on zeros (HopDesc.startBin; 0 otherwise)
+	const int startBin = hopLds[0].startBin;
 	float2 pf[CH];
 	float2 h[8][CH];
 #pragma unroll
@@ -526,6 +529,7 @@ __global__ __launch_bounds__(128) void kVocoderOne(DevBatch d, int sBase, int ho
 						oc = makeOutput(cmul(om, cmulc(pc, pm)), pc, f[11 + 3*c]); // channel lock, :791-800
 					}
 					if (c == mc) oc = om;
+					if (b < startBin) oc = make_float2(0.f, 0.f);
 					h[i][c] = oc; // bins past the last one have all-zero records, which give exactly zero
 					if (k == 0) blockOut[c*BS + step] = oc;
 				}

@@ -146,13 +146,13 @@ def only(names):
     case = real
 
 
-def split_event_scenarios(interval, n_in, pre_intervals, post_intervals, offsets, rate=1.0, pre_mapped=None):
+def split_event_scenarios(interval, n_in, pre_intervals, post_intervals, offsets, rate=1.0, pre_mapped=None, events=None):
     """Op lists of the split-computation fixtures: process() up to `off` samples into an interval, an event, more process().
     Events: flush of one interval / of a third of it, setTransposeSemitones 3 -> 7 (the block in flight is already mapped: findPeaks
     reads the live parameters, signalsmith-stretch.h:850-856), 0 -> 4 (`mappedFrequencies` was latched at the block's start, :300),
     reset(), seek()."""
     out = []
-    for event in ("flush", "flush_short", "param", "param_unmapped", "reset", "seek"):
+    for event in (events or ("flush", "flush_short", "param", "param_unmapped", "reset", "seek")):
         for off in offsets:
             nout = (pre_mapped if (event == "param" and pre_mapped) else pre_intervals)*interval + off  # (a transposed run of the small geometry drifts from the WASM by 2e-3 within ten hops: keep it short)
             nin = int(round(nout*rate))
@@ -194,6 +194,10 @@ def split_event_fixtures():
         # the small geometry of tests/parity_cases.py (SMALL_SPLIT): 24 steps per stereo block, one step per ~5 samples
         "small_stereo": dict(cfg=dict(preset="configure", block=512, interval=128, split=True), channels=2, interval=128, n=6000,
                              pre=10, pre_mapped=3, post=4, offsets=(1, 5, 8, 12, 16, 32, 46, 47, 54, 55, 64, 80, 100, 110, 115, 116, 121, 122, 124, 127)),  # 46|47: findPeaks of a mapped stereo block (step 8 of 24); 54|55: first main-prediction chunk of an unmapped one (step 8 of 20); 115|116, 121|122: its two synthesis steps
+        # a playback rate of 1.25: every block re-analyses its previous spectrum (:303), channels + 1 more steps in front (26 stereo, 30 mapped)
+        "small_stereo_rate": dict(cfg=dict(preset="configure", block=512, interval=128, split=True), channels=2, interval=128, n=6000,
+                                  pre=10, pre_mapped=3, post=4, rate=1.25, events=("flush", "param"),
+                                  offsets=(3, 9, 14, 20, 40, 49, 50, 56, 57, 90, 104, 105, 109, 110, 120, 127)),  # 49|50: findPeaks (step 11 of 30); 56|57: first main-prediction chunk (step 11 of 26); 104|105, 109|110: the synthesis steps
         # presetCheaper at 48 kHz (always split in the WASM ABI, web/emscripten/main.cpp:46-48), mono
         "cheaper_48k_mono": dict(cfg=dict(preset="cheaper"), channels=1, interval=1920, n=26000,
                                  pre=4, post=3, offsets=(5, 700, 1500, 1850, 1919)),
@@ -201,7 +205,7 @@ def split_event_fixtures():
     for name, g in geoms.items():
         C = g["channels"]
         x = (synth_input(0, C, g["n"], sr) + 0.3*synth_input(3, C, g["n"], sr)).astype(np.float32)  # tonal: the fixtures must resolve single steps, not chaos
-        scen = split_event_scenarios(g["interval"], g["n"], g["pre"], g["post"], g["offsets"], pre_mapped=g.get("pre_mapped"))
+        scen = split_event_scenarios(g["interval"], g["n"], g["pre"], g["post"], g["offsets"], pre_mapped=g.get("pre_mapped"), rate=g.get("rate", 1.0), events=g.get("events"))
         blob = dict(x=x, cfg=json.dumps(g["cfg"]), names=json.dumps([s[0] for s in scen]))
         for key, ops in scen:
             y, info = wasm_oracle.run(x, ops, **g["cfg"])

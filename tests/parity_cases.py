@@ -165,19 +165,8 @@ def case_random_call_sequences(lib, ref, seeds=range(6), cfg=SMALL, calls=14):
             rng = np.random.default_rng(1000 + seed)
             pos, outs = 0, []
             ratio = 1.0
-            # split computation: the reference spreads a block's steps over the interval, the product completes the block at the
-            # interval's first sample -- parameter changes, seeks, flushes and resets BETWEEN interval boundaries
-            # are a documented deviation there, so a split-mode walk sets its parameters once and then only processes
-            split = bool(cfg.get("split", False))
-            if split:
-                o.setTransposeSemitones(float(rng.integers(-7, 8)), float(rng.choice([0.0, 0.15])))
-                if formants:
-                    o.setFormantFactor(float(rng.choice([0.9, 1.15])), bool(rng.integers(0, 2)))
-                ratio = float(rng.choice([0.75, 1.0, 1.3, 1.6]))
             for call in range(calls):
                 kind = rng.choice(["process", "process", "process", "param", "flush", "seek", "reset", "empty"], p=[0.3, 0.2, 0.15, 0.15, 0.06, 0.05, 0.04, 0.05])
-                if split and kind in ("param", "flush", "seek", "reset"):
-                    kind = "process"
                 if kind == "param":
                     which = int(rng.integers(0, 4 if formants else 2))
                     if which == 0:
@@ -1099,33 +1088,120 @@ def case_debug_map_is_of_the_last_call(lib):
 
 
 def case_split_mid_interval_flush(lib, ref):
-    """Pins the documented deviation of split computation (signalsmith-stretch.h:294-297,321-325,442-455): the
-    reference spreads a block's steps over the interval and adds the synthesised frame to its output ring only when the last steps
-    have run, the product completes the block at the interval's first sample.  flush() reads that ring, so a flush in the first
-    middle of an interval returns the newest frame here and not there (rel-RMS 0.5 .. 0.9 of the tail); on an interval boundary,
-    one sample before it, and whenever the flush is longer than an interval (it then runs the block to its end first) the two
-    agree.  (The step at which the L1 layer finishes a frame is internal to signalsmith-linear, which is not in the reference
-    tree: the deviation is pinned, not removed.)"""
+    """Split computation (signalsmith-stretch.h:294-297,321-325,442-455): the reference spreads a block's steps over the interval and
+    flush() reads the real output ring, one interval ahead of the stashed copy that process() emits from -- so a flush between two
+    interval boundaries returns the newest frame only as far as its synthesis steps have run, resets the real ring, and leaves the
+    rest of the interval to the stashed ring.  The product analyses the block in flight when it starts and runs the rest when the
+    interval is complete, or as far as a flush() needs it (smst_engine.h: PendingBlock): every offset agrees with the reference,
+    in the flushed tail AND in what process() returns afterwards.  (Rounds 1-4 completed the block at the interval's first sample
+    and pinned the resulting deviation here: 0.05 .. 1.0 of the tail at interior offsets.)"""
     C, sr = 2, 48000
     x = synth_input(0, C, 12000, sr)
     I = 128
     figures = {}
-    for offset in (0, 1, 5, 32, 64, 100, 127):
+    for offset in (0, 1, 5, 32, 54, 55, 64, 100, 115, 116, 121, 122, 127):
         g, r = make("product", lib, ref, C, SMALL_SPLIT), make("ref", lib, ref, C, SMALL_SPLIT)
         nout = 55*I + offset
         a, b = g.process(x[:, :6000], nout), r.process(x[:, :6000], nout)
         assert rel_rms(a, b) < 1e-5, (offset, "process", rel_rms(a, b))
         fa, fb = g.flush(I), r.flush(I)
-        figures[offset] = rel_rms(fa, fb)
-    assert all(figures[o] < 1e-5 for o in (0, 127)), figures
-    assert all(0.05 < figures[o] < 1.0 for o in (1, 5, 32, 64, 100)), figures  # the pinned deviation: if this starts to agree, update DESIGN.md section 8
-    # a flush longer than one interval finishes the block first: its first interval agrees again, from any offset
+        pa, pb = g.process(x[:, 6000:6700], 700), r.process(x[:, 6000:6700], 700)
+        level = float(np.sqrt(np.mean(np.square(b, dtype=np.float64))))
+        figures[offset] = (rel_rms(fa, fb), float(np.sqrt(np.mean(np.square(np.asarray(pa, np.float64) - pb))))/level)
+    assert all(f < 1e-4 and after < 1e-4 for f, after in figures.values()), figures
+    # a flush longer than one interval finishes the block first (it runs process() on silence, :439-440), from any offset
     g, r = make("product", lib, ref, C, SMALL_SPLIT), make("ref", lib, ref, C, SMALL_SPLIT)
     g.process(x[:, :6000], 55*I + 40), r.process(x[:, :6000], 55*I + 40)
     fa, fb = g.flush(300), r.flush(300)
-    figures["long flush, first interval"] = rel_rms(fa[:, :I], fb[:, :I])
-    assert figures["long flush, first interval"] < 1e-4, figures  # one more block of the phase vocoder ran: its own sensitivity (GPU: 2e-5)
-    return figures
+    figures["long flush"] = (rel_rms(fa[:, :I], fb[:, :I]), rel_rms(fa, fb))
+    assert figures["long flush"][0] < 1e-4 and figures["long flush"][1] < 1e-3, figures  # (its later intervals ran blocks at a huge time factor: their own sensitivity)
+    return {k: ("%.1e" % v[0], "%.1e" % v[1]) for k, v in figures.items()}
+
+
+def case_split_events_golden(lib, ref, geometry):
+    """The product against what the reference's shipped WASM build does when a flush / parameter change / reset / seek falls BETWEEN
+    two interval boundaries in split-computation mode (tests/golden/split_events, make_golden.py split): every offset of the
+    fixtures, among them the single samples at which a step of the block in flight moves to the other side of the event."""
+    x, cfg, scen = scenarios.load_split_events(geometry)
+    worst = {}
+    for name, ops, y in scen:
+        g = make("product", lib, ref, x.shape[0], cfg)
+        out = np.asarray(scenarios.replay(g, x, ops))
+        assert out.shape == y.shape
+        e = scenarios.split_event_errors(out, y, ops, g.intervalSamples())
+        tol_seg, tol_after = scenarios.split_event_tolerance(name)
+        if max(v for _, v in e["segments"]) > tol_seg or max(e["after"]) > tol_after:
+            # a transposed scenario drifts from the WASM within a few hops (so does the checker): the checker's own distance decides
+            r = make("ref", lib, ref, x.shape[0], cfg)
+            er = scenarios.split_event_errors(scenarios.replay(r, x, ops), y, ops, r.intervalSamples())
+            assert all(v <= max(tol_seg, 2*w + FLOOR) for (_, v), (_, w) in zip(e["segments"], er["segments"])), (geometry, name, e, er)
+            assert all(v <= max(tol_after, 2*w + 1e-5) for v, w in zip(e["after"], er["after"])), (geometry, name, e, er)
+        kind = name.rsplit("_", 1)[0]
+        worst[kind] = max(worst.get(kind, 0.0), max(e["after"]))
+    return {k: "%.1e" % v for k, v in worst.items()}
+
+
+def case_split_events_vs_checker(lib, ref, channels=3, cfg=SMALL_SPLIT):
+    """What the WASM ABI cannot do (formant parameters: its updateFormants is another revision) and what the
+    fixtures do not hold (3 channels, several events inside ONE interval, a flush longer than the interval from an interior offset,
+    ragged call sizes) -- against oracle/_ref, whose step partition the fixtures pin.  Formant steps of a mapped 3-channel block:
+    29 + 3 steps, updateFormants(0) reads formantBaseFreq (:982), updateFormants(2) the multiplier and the compensation flag (:1020)."""
+    sr = 48000
+    I = cfg["interval"]
+    x = synth_input(0, channels, 9000, sr) + 0.3*synth_input(3, channels, 9000, sr)
+    figures = {}
+
+    def run(label, play, cap=CAP_FORMANT, tol=None):
+        g, r = make("product", lib, ref, channels, cfg), make("ref", lib, ref, channels, cfg)
+        y, o = np.asarray(play(g)), play(r)
+        o2 = [play(make("ref", lib, ref, channels, cfg), xx=perturbed(x, k)) for k in SELF_SEEDS]
+        assert_parity(y, o, o2, I, label, cap=cap)
+        figures[label] = rel_rms(y, o)
+        if tol is not None:
+            assert figures[label] < tol, (label, figures[label])
+
+    for off in (3, 40, 47, 52, 53, 56, 57, 61, 70, 100, 127):  # 52|53: updateFormants(0) = step 12 of 31 runs with sample 53; 56|57 (+ 4): updateFormants(2) = step 14 with sample 61
+        def formant_change(o, xx=x, off=off):
+            o.setTransposeSemitones(3, 0)
+            o.setFormantFactor(1.1, True)
+            outs = [o.process(xx[:, :1500], 8*I + off)]
+            o.setFormantBase(180.0/sr)       # updateFormants(0) of the block in flight sees it only if it has not run yet
+            outs.append(o.process(xx[:, 1500:1510], 4))
+            o.setFormantFactor(0.9, False)   # ... updateFormants(2) likewise, four samples later
+            outs.append(o.process(xx[:, 1510:2400], 3*I))
+            return np.concatenate(outs, axis=1)
+        run("formant parameters at %d" % off, formant_change)
+
+    def two_events(o, xx=x):  # a parameter change, a short flush and another parameter change inside one interval; then a flush of 2.5 intervals from an interior offset
+        o.setTransposeSemitones(-2, 0)
+        outs = [o.process(xx[:, :2000], 10*I + 20)]
+        o.setTransposeSemitones(2, 0)
+        outs.append(o.process(xx[:, 2000:2030], 30))
+        outs.append(o.flush(25))
+        o.setTransposeSemitones(5, 0)
+        outs.append(o.process(xx[:, 2030:2800], 6*I + 77))
+        outs.append(o.flush(int(2.5*I)))
+        outs.append(o.process(xx[:, 2800:4000], 1200))
+        return np.concatenate(outs, axis=1)
+    run("two events in one interval", two_events, cap=CAP_TONAL)
+
+    def flush_twice(o, xx=x):  # two flushes inside the same interval: the second finds a block that the first one already interrupted
+        outs = [o.process(xx[:, :2000], 12*I + 60)]
+        outs.append(o.flush(10))
+        outs.append(o.process(xx[:, 2000:2030], 30))
+        outs.append(o.flush(40))
+        outs.append(o.process(xx[:, 2030:3200], 1170))
+        return np.concatenate(outs, axis=1)
+    run("two flushes in one interval", flush_twice, cap=CAP_TONAL, tol=1e-4)
+
+    def quanta(o, xx=x):  # the real-time pattern with a parameter automation: one setter per 37-sample call
+        outs = []
+        for k in range(60):
+            o.setTransposeSemitones(-3 + 0.1*k, 0)
+            outs.append(o.process(xx[:, 37*k:37*(k + 1)], 37))
+        return np.concatenate(outs, axis=1)
+    run("a setter in every 37-sample call", quanta, cap=CAP_TONAL)
+    return {k: "%.1e" % v for k, v in figures.items()}
 
 
 def case_across_equals_single_hop(lib, monkeypatch, streams=21, channel_counts=(1, 2), setup=None):

@@ -159,6 +159,20 @@ def test_random_call_sequences_emu(emu, ref):
     pc.case_random_call_sequences(emu, ref, seeds=range(6))
 
 
+def test_random_call_sequences_split_emu(emu, ref):
+    """the same walks in split-computation mode: parameter changes, flushes, seeks and resets fall between interval boundaries"""
+    print(pc.case_random_call_sequences(emu, ref, seeds=range(100, 108), cfg=pc.SMALL_SPLIT))
+
+
+@pytest.mark.parametrize("geometry", scenarios.split_event_geometries())
+def test_split_events_golden_emu(emu, ref, geometry):
+    print(pc.case_split_events_golden(emu, ref, geometry))
+
+
+def test_split_events_vs_checker_emu(emu, ref):
+    print(pc.case_split_events_vs_checker(emu, ref))
+
+
 def test_random_time_factor_parity_emu(emu, ref):
     print(pc.case_random_time_factor_parity(emu, ref))
 

@@ -582,7 +582,18 @@ def test_debug_map_is_of_the_last_call(hip):
 
 
 def test_split_mid_interval_flush(hip, ref):
-    print(pc.case_split_mid_interval_flush(hip, ref))
+    _report("split_mid_interval_flush", pc.case_split_mid_interval_flush(hip, ref))
+
+
+@pytest.mark.parametrize("geometry", scenarios.split_event_geometries())
+def test_split_events_golden(hip, ref, geometry):
+    """the reference's shipped WASM build on flush / parameter change / reset / seek between interval boundaries (split computation)"""
+    _report("split_events_golden/" + geometry, pc.case_split_events_golden(hip, ref, geometry))
+
+
+def test_split_events_vs_checker(hip, ref):
+    _report("split_events_vs_checker", pc.case_split_events_vs_checker(hip, ref))
+    _report("split_events_vs_checker/cheaper48k", pc.case_split_events_vs_checker(hip, ref, channels=2, cfg=dict(preset="cheaper", sample_rate=48000.0)))
 
 
 def test_across_equals_single_hop(hip, monkeypatch):
@@ -593,7 +604,8 @@ def test_across_equals_single_hop(hip, monkeypatch):
 def test_random_call_sequences(hip, ref):
     """API fuzz against the checker: seeded random walks over process / parameter setters / seek / flush / reset."""
     pc.case_random_call_sequences(hip, ref, seeds=range(12))
-    pc.case_random_call_sequences(hip, ref, seeds=range(100, 104), cfg=pc.SMALL_SPLIT)
+    # split computation: the same walks -- parameter changes, flushes, seeks and resets between interval boundaries included (round 5)
+    _report("random_call_sequences_split", pc.case_random_call_sequences(hip, ref, seeds=range(100, 112), cfg=pc.SMALL_SPLIT))
 
 
 def test_random_time_factor_parity(hip, ref):
