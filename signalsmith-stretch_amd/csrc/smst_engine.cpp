@@ -353,6 +353,7 @@ void Batch::construct(const FftPlan &plan, long seed) {
 	hopFirst.assign(S, 0);
 	hopCount.assign(S, 0);
 	leavesPendingV.assign(S, 0);
+	ridesV.assign(S, 0);
 	passV.assign(S, 0);
 	dInSamples = callSets[0].inSamples;
 	dOutSamples = callSets[0].outSamples;
@@ -401,7 +402,7 @@ void Batch::construct(const FftPlan &plan, long seed) {
 		dZeroCounts = devAlloc<int>(S);
 		SMST_HIP(hipMemset(dZeroCounts, 0, S*sizeof(int)));
 		pendList.reserve(S);
-		pendTileHas.assign((size_t)nSub*8, 0);
+		pendTileHas.assign((size_t)nSub*kTileHasStride, 0);
 		pendMaxSpan.assign(nSub, 0);
 	}
 	reset();
@@ -759,7 +760,7 @@ void Batch::runPendingBlocks(const int *synthChannels) {
 	for (int s : pendList) {
 		const PendingBlock &pb = pend[s];
 		HopDesc &hd = ps.hHops[s];
-		hd.flags = pb.flags;
+		hd.flags = pb.flags | HOP_PREANALYSED;
 		hd.timeFactor = pb.timeFactor;
 		hd.seed = pb.seed;
 		hd.startBin = pb.startBin;
@@ -774,12 +775,13 @@ void Batch::runPendingBlocks(const int *synthChannels) {
 		int *info = ps.hTileInfo + (size_t)sub*2*subS;
 		info[sl] = 1;
 		info[subS + sl] = nw ? 0 : -1;
-		unsigned char *th = pendTileHas.data() + (size_t)sub*8;
+		unsigned char *th = pendTileHas.data() + (size_t)sub*kTileHasStride;
 		th[0] = 1;
 		if (pb.flags & HOP_MAPPED) th[1] = 1;
 		if (pb.flags & HOP_FORMANTS) th[2] = 1;
 		if (pb.flags & HOP_RANDOM_TF) th[4] = 1;
 		if (pb.startBin > 0) th[7] = 1;
+		th[8] = 1;
 		anyFrozen = anyFrozen || pb.frozenPeaks || pb.frozenForm0 || pb.frozenForm2;
 		anyZeroPrev = anyZeroPrev || pb.zeroPrevAfter;
 		LastHop &lh = lastHop[s];
@@ -849,7 +851,7 @@ void Batch::runTiles(const TileRun &run) {
 		const int sBase = sub*subS;
 		const int ns = std::min(subS, S - sBase);
 		for (int t = 0; t < nTiles; ++t, ++q) {
-			const unsigned char *th = run.tileHas + (size_t)(sub*nTiles + t)*8;
+			const unsigned char *th = run.tileHas + (size_t)(sub*nTiles + t)*kTileHasStride;
 			const int hopBase = t*T;
 			const int tileHops = std::min(T, std::max(1, maxHops - hopBase));
 			const int slot = q & 1;
@@ -862,15 +864,14 @@ void Batch::runTiles(const TileRun &run) {
 			dd.carryCur = (carryBase + t) & 1;
 			dd.nHops = run.dTileInfo + ((size_t)(sub*nTiles + t)*2)*subS;
 			dd.lastNewHop = dd.nHops + subS;
-			if (run.pendingRun) dd.synthEmit = 0; // (a one-hop tile whose hop began before the call: kSynthTeams + kEmit place it)
 			if (!serial && q >= 2) { // this workspace was last used by tile q-2
 				SMST_HIP(hipStreamWaitEvent(sF, evChain[slot], 0));
 				SMST_HIP(hipStreamWaitEvent(sF, evSynth[slot], 0));
 			}
 			if (!serial && fused && !plain && q >= 1) SMST_HIP(hipStreamWaitEvent(sF, evChain[slot ^ 1], 0)); // pass A reads the carried state
 			if (th[0]) {
-				if (run.pendingRun) timed(timings.otherMs, [&] { launchPendingToTile(dd, sBase, ns, dPendIn, dPendPrev, sF); });
-				else if (th[3]) timed(timings.analyseMs, [&] { launchAnalyse(dd, io, sBase, ns, hopBase, tileHops, th[5] != 0, th[6] != 0, sF); if (profiling) ++timings.analyseLaunches; });
+				if (th[8]) timed(timings.otherMs, [&] { launchPendingToTile(dd, sBase, ns, dPendIn, dPendPrev, sF); }); // blocks that began in an earlier call: their spectra are waiting
+				if (th[3]) timed(timings.analyseMs, [&] { launchAnalyse(dd, io, sBase, ns, hopBase, tileHops, th[5] != 0, th[6] != 0, sF); if (profiling) ++timings.analyseLaunches; });
 				bool passADone = false;
 				if (th[1] || th[2]) timed(timings.feedMs, [&] { passADone = launchFeed(dd, sBase, ns, hopBase, tileHops, th[2] != 0, sF); });
 				timed(timings.predictMs, [&] {
@@ -916,7 +917,7 @@ void Batch::runTiles(const TileRun &run) {
 			checkLaunch("bin recurrence");
 			// synthesis + overlap-add + emission in one kernel where the geometry and the batch allow it; its window products depend on
 			// nothing the recurrence writes: queued in front of the wait for it
-			const bool emitted = th[0] && synthEmitApplies(dd, ns, tileHops);
+			const bool emitted = th[0] && !th[8] && synthEmitApplies(dd, ns, tileHops); // (th[8]: a hop that began before the call's first sample -- kSynthTeams + kEmit place its frame)
 			if (emitted) timed(timings.otherMs, [&] { launchEmitProducts(dd, sBase, ns, t, sS); });
 			if (!serial) {
 				SMST_HIP(hipEventRecord(evChain[slot], sC));
@@ -983,6 +984,7 @@ void Batch::process(const float *in, long long inSS, long long inCS, const int *
 		hopFirst[s] = 0;
 		hopCount[s] = 0;
 		leavesPendingV[s] = 0;
+		ridesV[s] = 0;
 		clearBits[s] = 0;
 		if (active && !active[s]) continue;
 		lastHop[s].slot = -1; // smst_batch_debug_get_map reports the newest hop of THIS call only
@@ -1014,9 +1016,16 @@ void Batch::process(const float *in, long long inSS, long long inCS, const int *
 		if (split) {
 			// split computation: a block is finished when its interval is (:321-325).  The block in flight from earlier calls runs now if
 			// this call reaches the end of its interval; the last block that begins here stays in flight unless its interval ends here too
-			if (pend[s].valid && nOut[s] >= first) pendList.push_back(s);
-			hopCount[s] = (nOut[s] > first) ? (nOut[s] - first)/I : 0;
-			leavesPendingV[s] = starts > hopCount[s];
+			// (a plain one becomes the stream's first hop of this call; one that a flush() interrupted or whose steps saw different parameters runs by itself first)
+			ridesV[s] = 0;
+			if (pend[s].valid && nOut[s] >= first) {
+				const PendingBlock &pb = pend[s];
+				if (pb.startBin > 0 || pb.zeroPrevAfter || pb.frozenPeaks || pb.frozenForm0 || pb.frozenForm2) pendList.push_back(s);
+				else ridesV[s] = 1;
+			}
+			const int complete = (nOut[s] > first) ? (nOut[s] - first)/I : 0;
+			leavesPendingV[s] = starts > complete;
+			hopCount[s] = complete + ridesV[s];
 		} else {
 			hopCount[s] = starts;
 		}
@@ -1072,7 +1081,7 @@ void Batch::process(const float *in, long long inSS, long long inCS, const int *
 	std::memset(hopsAll, 0, needHops*sizeof(HopDesc));
 	std::memset(tileInfo, 0, needInfo*sizeof(int));
 	ensureSize(maxSpanV, (size_t)nSub*nTiles, allocEvents);
-	ensureSize(tileHasV, (size_t)nSub*nTiles*8, allocEvents); // any hops / any mapped / any formants / any new spectrum / any random time factor
+	ensureSize(tileHasV, (size_t)nSub*nTiles*kTileHasStride, allocEvents); // (smst_types.h: kTileHasStride)
 	std::fill(maxSpanV.begin(), maxSpanV.end(), 0);
 	std::fill(tileHasV.begin(), tileHasV.end(), 0);
 
@@ -1082,16 +1091,30 @@ void Batch::process(const float *in, long long inSS, long long inCS, const int *
 		const int sub = s/subS, sl = s%subS;
 		HopDesc *list = hopsAll + (size_t)s*hopStride;
 		const int nh = hopCount[s];
-		const int nStart = nh + (leavesPendingV[s] ? 1 : 0); // split computation: the last block that begins here may stay in flight
+		const int rides = ridesV[s]; // split computation: the block in flight from an earlier call is this call's hop 0 ...
+		const int nStart = nh + (leavesPendingV[s] ? 1 : 0); // ... and the last block that begins here may stay in flight
 		if (split) cs.hPendHops[s] = HopDesc{};
-		if (nStart > 0) {
+		int lastNew = -1;
+		if (rides) {
+			const PendingBlock &pb = pend[s];
+			HopDesc &hd = list[0];
+			hd.flags = pb.flags | HOP_PREANALYSED;
+			hd.timeFactor = pb.timeFactor;
+			hd.seed = pb.seed;
+			hd.outPos = -int(sched[s].samplesSinceLast); // it began that many samples ago: its frame lands where its interval ends (:292-296)
+			const bool nw = (pb.flags & HOP_NEW_SPECTRUM) != 0;
+			hd.inSrc = nw ? 0 : SRC_STATE;
+			hd.prevSrc = (nw && (pb.flags & HOP_REANALYSE_PREV)) ? SRC_REANALYSED : SRC_STATE;
+			if (nw) lastNew = 0;
+			pend[s] = PendingBlock();
+		}
+		if (nStart > rides) {
 			StreamSched &sc = sched[s];
 			const StreamParams &prm = params[s];
 			const bool mapped = prm.hasCustomMap || prm.freqMultiplier != 1; // :300
 			const bool formants = prm.formantMultiplier != 1 || (prm.formantCompensation && mapped); // :310
-			int lastNew = -1;
 			int o = hopFirst[s];
-			for (int j = 0; j < nStart; ++j, o += I) {
+			for (int j = rides; j < nStart; ++j, o += I) {
 				HopDesc inFlight{};
 				HopDesc &hd = (j < nh) ? list[j] : inFlight;
 				int inputOffset = int(std::round(o*float(nIn[s])/nOut[s])); // :288 (fp32 on purpose)
@@ -1162,10 +1185,12 @@ void Batch::process(const float *in, long long inSS, long long inCS, const int *
 			int *info = tileInfo + ((size_t)(sub*nTiles + t)*2)*subS;
 			info[sl] = cnt;
 			int lastNewLocal = -1;
-			unsigned char *th = tileHasV.data() + (size_t)(sub*nTiles + t)*8;
+			unsigned char *th = tileHasV.data() + (size_t)(sub*nTiles + t)*kTileHasStride;
 			for (int h = h0; h < h1; ++h) {
 				const unsigned f = list[h].flags;
-				if (f & HOP_NEW_SPECTRUM) {
+				if (f & HOP_PREANALYSED) th[8] = 1;
+				if ((f & HOP_NEW_SPECTRUM) && (f & HOP_PREANALYSED)) lastNewLocal = h - h0;
+				if ((f & HOP_NEW_SPECTRUM) && !(f & HOP_PREANALYSED)) {
 					lastNewLocal = h - h0; th[3] = 1;
 					// analysis frames whose window lies in this call's input ([5], taken by kAnalyseTeams) / reaches into the history ([6])
 					for (int which = 0; which < ((f & HOP_REANALYSE_PREV) ? 2 : 1); ++which) th[analysisWindowInCall(d.B, d.M, d.I, list[h].inputOffset, which, nIn[s]) ? 5 : 6] = 1;

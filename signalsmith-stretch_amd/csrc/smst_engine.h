@@ -144,7 +144,7 @@ private:
 	int subS = 0;
 	// per-call host scratch, kept between calls (no heap traffic in steady state); growth events are counted
 	std::vector<int> hopFirst, hopCount, maxSpanV;
-	std::vector<unsigned char> tileHasV, passV, leavesPendingV;
+	std::vector<unsigned char> tileHasV, passV, leavesPendingV, ridesV;
 	long allocEvents = 0; // device allocations + pinned allocations + host table growth since construction
 	size_t wsBytes = 0;
 	DevBatch d{};

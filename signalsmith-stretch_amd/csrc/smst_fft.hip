@@ -351,7 +351,7 @@ __global__ __launch_bounds__(16*R3 > 256 ? 16*R3 : 256) __attribute__((amdgpu_wa
 	const int which = bc.y & 1;
 	const int s = bc.s;
 	const HopDesc hd = d.hops[(size_t)(sBase + s)*d.hopStride + hopBase + k];
-	if (!(hd.flags & HOP_ACTIVE) || !(hd.flags & HOP_NEW_SPECTRUM)) return;
+	if (!(hd.flags & HOP_ACTIVE) || !(hd.flags & HOP_NEW_SPECTRUM) || (hd.flags & HOP_PREANALYSED)) return;
 	if (which == 1 && !(hd.flags & HOP_REANALYSE_PREV)) return;
 	if (lateOnly && analysisWindowInCall(d.B, d.M, d.I, hd.inputOffset, which, io.inSamples[sBase + s])) return; // kAnalyseTeams has taken this frame
 	const int B = d.B, H = d.M, halfB = B/2, N = d.N;
@@ -471,7 +471,7 @@ __global__ __launch_bounds__(256*TEAMS) void kAnalyseTeams(DevBatch d, IoArgs io
 		const BlockCoord bc = xcdAwareCoord(lin, tileHops, 2*d.C, nStreams);
 		const HopDesc hd = hopTable[(size_t)(sBase + bc.s)*d.hopStride + hopBase + bc.x];
 		const int c = bc.y >> 1, which = bc.y & 1;
-		if (!(hd.flags & HOP_ACTIVE) || !(hd.flags & HOP_NEW_SPECTRUM) || (which && !(hd.flags & HOP_REANALYSE_PREV)) || !analysisWindowInCall(B, H, d.I, hd.inputOffset, which, io.inSamples[sBase + bc.s])) continue;
+		if (!(hd.flags & HOP_ACTIVE) || !(hd.flags & HOP_NEW_SPECTRUM) || (hd.flags & HOP_PREANALYSED) || (which && !(hd.flags & HOP_REANALYSE_PREV)) || !analysisWindowInCall(B, H, d.I, hd.inputOffset, which, io.inSamples[sBase + bc.s])) continue;
 		const int base = hd.inputOffset - (which ? d.I : 0) - B;
 		const float *x = io.in + (size_t)(sBase + bc.s)*io.inStreamStride + (size_t)c*io.inChannelStride;
 		const float *x0 = x + base + halfB, *x1 = x + base - H + halfB;
@@ -809,7 +809,11 @@ __global__ __launch_bounds__(512) void kSynthEmitTeams(DevBatch d, IoArgs io, in
 		overlapAdd();
 		sync();
 		emitInterval(cnt - 1);
-		const int n0 = ed.firstHopPos + cnt*I; // what the ring still holds: the start of the next tile's sums
+		// split computation: only blocks whose interval is complete are in the tile (the one in flight runs with a later call), so a call's
+		// last tile may end up to an interval behind its last hop's interval: those samples leave like any other interval
+		const bool trailing = SPLIT && ed.firstHopPos + cnt*I < ed.nHi;
+		if (trailing) emitInterval(cnt);
+		const int n0 = ed.firstHopPos + (cnt + (trailing ? 1 : 0))*I; // what the ring still holds: the start of the next tile's sums
 #pragma unroll
 		for (int u = 0; u < NI; ++u) {
 #pragma unroll
@@ -866,7 +870,7 @@ __global__ __launch_bounds__(256) void kAnalyse(DevBatch d, IoArgs io, int sBase
 	const int which = bc.y & 1; // 0: current window, 1: window one interval earlier
 	const int s = bc.s;
 	const HopDesc hd = d.hops[(size_t)(sBase + s)*d.hopStride + hopBase + k];
-	if (!(hd.flags & HOP_ACTIVE) || !(hd.flags & HOP_NEW_SPECTRUM)) return;
+	if (!(hd.flags & HOP_ACTIVE) || !(hd.flags & HOP_NEW_SPECTRUM) || (hd.flags & HOP_PREANALYSED)) return;
 	if (which == 1 && !(hd.flags & HOP_REANALYSE_PREV)) return;
 
 	const int B = d.B, H = d.M, halfB = B/2;

@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256) void kResetStreams(DevBatch d, const int *__re
 __global__ __launch_bounds__(256) void kPendingToTile(DevBatch d, int sBase, const float2 *__restrict__ pendIn, const float2 *__restrict__ pendPrev) {
 	const int s = blockIdx.z, sg = sBase + s, c = blockIdx.y;
 	const int b = blockIdx.x*blockDim.x + threadIdx.x;
-	if (d.nHops[s] == 0 || b >= d.M) return;
+	if (d.nHops[s] == 0 || b >= d.M || !(d.hops[(size_t)sg*d.hopStride].flags & HOP_PREANALYSED)) return; // (such a block is always its stream's first hop of the call)
 	const size_t src = ((size_t)sg*d.C + c)*(size_t)d.Mp + b, dst = rowOf(d, s, 0, c) + b;
 	d.Xcur[dst] = pendIn[src];
 	d.Xprev[dst] = pendPrev[src];

@@ -7,6 +7,7 @@ namespace smst {
 constexpr int kTileHops = 64;   // hops per tile = lanes of the wave that runs the bin recurrence
 constexpr int kMaxChannels = 8; // compile-time bound of the chain kernel's per-lane channel arrays
 constexpr int kMaxFftPasses = 12;
+constexpr int kTileHasStride = 12; // per-tile summary bytes of the host scheduler: any hop / mapped / formants / new spectrum / random time factor / analysis window in the call / reaching into the history / a start bin / a pre-analysed hop
 constexpr int kEnergyParts = 16; // partial sums per stream in the silence-gate reduction
 
 // Hop flags (reference: signalsmith-stretch.h:299-313)
@@ -17,6 +18,7 @@ enum : unsigned {
 	HOP_MAPPED = 8u,         // :300
 	HOP_FORMANTS = 16u,      // :310
 	HOP_RANDOM_TF = 32u,     // :639
+	HOP_PREANALYSED = 64u,   // split computation: the block began in an earlier call and was analysed then (:293, :332-373); its spectra come from the pending buffers
 };
 
 // Source codes for the per-hop spectra (which row holds Band.input / Band.prevInput for this hop)

@@ -1008,7 +1008,8 @@ def case_synth_emit_equals_two_kernels(lib, monkeypatch, presets=(("cheaper", 48
                 b.close()
                 outs.append(np.concatenate([y1, y2, y3, tail], axis=2))
                 grew = [pkg.launch_count(k, lib) - c for k, c in zip(names, counts)]
-                assert (grew[0] > 0 and grew[1] == 0) if fusedKernel else (grew[0] == 0 and grew[1] > 0), (fusedKernel, grew)
+                # (split computation: a call's first tile, which begins with the block the call before left in flight, goes through kSynthTeams + kEmit)
+                assert (grew[0] > 0 and (grew[1] == 0 or split)) if fusedKernel else (grew[0] == 0 and grew[1] > 0), (fusedKernel, split, grew)
             monkeypatch.delenv("SMST_FFT_TEAMS", raising=False)
             monkeypatch.delenv("SMST_SYNTH_EMIT", raising=False)
             assert np.abs(outs[0]).max() > 0.05
@@ -1147,8 +1148,9 @@ def case_split_events_vs_checker(lib, ref, channels=3, cfg=SMALL_SPLIT):
     ragged call sizes) -- against oracle/_ref, whose step partition the fixtures pin.  Formant steps of a mapped 3-channel block:
     29 + 3 steps, updateFormants(0) reads formantBaseFreq (:982), updateFormants(2) the multiplier and the compensation flag (:1020)."""
     sr = 48000
-    I = cfg["interval"]
-    x = synth_input(0, channels, 9000, sr) + 0.3*synth_input(3, channels, 9000, sr)
+    I = make("ref", lib, ref, channels, cfg).intervalSamples()
+    q = I/128.0  # the sample counts below are written for the small geometry (interval 128) and scale with the interval
+    x = synth_input(0, channels, int(9000*q), sr) + 0.3*synth_input(3, channels, int(9000*q), sr)
     figures = {}
 
     def run(label, play, cap=CAP_FORMANT, tol=None):
@@ -1164,41 +1166,45 @@ def case_split_events_vs_checker(lib, ref, channels=3, cfg=SMALL_SPLIT):
         def formant_change(o, xx=x, off=off):
             o.setTransposeSemitones(3, 0)
             o.setFormantFactor(1.1, True)
-            outs = [o.process(xx[:, :1500], 8*I + off)]
+            n0, off2 = int(1500*q), int(off*q)
+            outs = [o.process(xx[:, :n0], 8*I + off2)]
             o.setFormantBase(180.0/sr)       # updateFormants(0) of the block in flight sees it only if it has not run yet
-            outs.append(o.process(xx[:, 1500:1510], 4))
+            outs.append(o.process(xx[:, n0:n0 + 10], 4))
             o.setFormantFactor(0.9, False)   # ... updateFormants(2) likewise, four samples later
-            outs.append(o.process(xx[:, 1510:2400], 3*I))
+            outs.append(o.process(xx[:, n0 + 10:n0 + 10 + 3*I], 3*I))
             return np.concatenate(outs, axis=1)
         run("formant parameters at %d" % off, formant_change)
 
     def two_events(o, xx=x):  # a parameter change, a short flush and another parameter change inside one interval; then a flush of 2.5 intervals from an interior offset
         o.setTransposeSemitones(-2, 0)
-        outs = [o.process(xx[:, :2000], 10*I + 20)]
+        a, b, c, e = int(2000*q), int(2030*q), int(2800*q), int(4000*q)
+        outs = [o.process(xx[:, :a], 10*I + int(20*q))]
         o.setTransposeSemitones(2, 0)
-        outs.append(o.process(xx[:, 2000:2030], 30))
-        outs.append(o.flush(25))
+        outs.append(o.process(xx[:, a:b], b - a))
+        outs.append(o.flush(int(25*q)))
         o.setTransposeSemitones(5, 0)
-        outs.append(o.process(xx[:, 2030:2800], 6*I + 77))
+        outs.append(o.process(xx[:, b:c], 6*I + int(77*q)))
         outs.append(o.flush(int(2.5*I)))
-        outs.append(o.process(xx[:, 2800:4000], 1200))
+        outs.append(o.process(xx[:, c:e], e - c))
         return np.concatenate(outs, axis=1)
     run("two events in one interval", two_events, cap=CAP_TONAL)
 
     def flush_twice(o, xx=x):  # two flushes inside the same interval: the second finds a block that the first one already interrupted
-        outs = [o.process(xx[:, :2000], 12*I + 60)]
-        outs.append(o.flush(10))
-        outs.append(o.process(xx[:, 2000:2030], 30))
-        outs.append(o.flush(40))
-        outs.append(o.process(xx[:, 2030:3200], 1170))
+        a, b, c = int(2000*q), int(2030*q), int(3200*q)
+        outs = [o.process(xx[:, :a], 12*I + int(60*q))]
+        outs.append(o.flush(int(10*q)))
+        outs.append(o.process(xx[:, a:b], b - a))
+        outs.append(o.flush(int(40*q)))
+        outs.append(o.process(xx[:, b:c], c - b))
         return np.concatenate(outs, axis=1)
-    run("two flushes in one interval", flush_twice, cap=CAP_TONAL, tol=1e-4)
+    run("two flushes in one interval", flush_twice, cap=CAP_TONAL, tol=1e-4 if q == 1 else None)
 
     def quanta(o, xx=x):  # the real-time pattern with a parameter automation: one setter per 37-sample call
         outs = []
+        n = int(37*q)
         for k in range(60):
             o.setTransposeSemitones(-3 + 0.1*k, 0)
-            outs.append(o.process(xx[:, 37*k:37*(k + 1)], 37))
+            outs.append(o.process(xx[:, n*k:n*(k + 1)], n))
         return np.concatenate(outs, axis=1)
     run("a setter in every 37-sample call", quanta, cap=CAP_TONAL)
     return {k: "%.1e" % v for k, v in figures.items()}

@@ -396,7 +396,14 @@ def _report(name, figures):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
     with open(os.path.join(root, "gpurun_out", "parity_instruments.jsonl"), "a") as f:
-        f.write(json.dumps(dict(test=name, **{k: float(v) for k, v in figures.items()})) + "\n")
+        def plain(v):
+            if isinstance(v, (list, tuple)):
+                return [plain(u) for u in v]
+            try:
+                return float(v)
+            except (TypeError, ValueError):
+                return str(v)
+        f.write(json.dumps(dict(test=name, **{str(k): plain(v) for k, v in figures.items()})) + "\n")
 
 
 @pytest.mark.parametrize("label,cfg,C,stretch,setup", [

@@ -14,14 +14,16 @@ def main():
     ap.add_argument("--quanta", type=int, default=600)
     ap.add_argument("--streams", type=int, nargs="*", default=[1, 64, 256, 1024, 4096])
     ap.add_argument("--stretch", type=float, default=1.0)
+    ap.add_argument("--preset", default="default", choices=["default", "cheaper"], help="cheaper = split computation, the preset real-time hosts use (signalsmith-stretch.h:66-68)")
+    ap.add_argument("--channels", type=int, default=2)
     args = ap.parse_args()
     import torch
     pkg = importlib.import_module("signalsmith-stretch_amd")
-    sr, C, Q = 48000, 2, args.quantum
+    sr, C, Q = 48000, args.channels, args.quantum
     n_in = int(round(Q/args.stretch))
     rows = []
     for S in args.streams:
-        b = pkg.StretchBatch(S, C, preset="default", sample_rate=sr)
+        b = pkg.StretchBatch(S, C, preset=args.preset, sample_rate=sr)
         t = torch.arange(n_in*(args.quanta + 50), device="cuda", dtype=torch.float32)/sr
         x = (0.4*torch.sin(2*torch.pi*220.0*t)).expand(S, C, -1).contiguous()
         y = torch.empty((S, C, Q), dtype=torch.float32, device="cuda")
@@ -40,7 +42,7 @@ def main():
         rows.append({"streams": S, "median_ms": round(med*1e3, 4), "p99_ms": round(p99*1e3, 4), "mean_ms": round(sum(times)/len(times)*1e3, 4),
                      "realtime_budget_ms": round(budget*1e3, 4), "realtime_headroom_x": round(budget/p99, 2),
                      "Msamples_per_s": round(S*C*(n_in + Q)/(sum(times)/len(times))/1e6, 2)})
-    print(json.dumps({"pattern": "process(%d, %d) per quantum, stereo 48 kHz presetDefault, device-resident, 1 sync per quantum" % (n_in, Q),
+    print(json.dumps({"pattern": "process(%d, %d) per quantum, %d ch 48 kHz preset %s, device-resident, 1 sync per quantum" % (n_in, Q, C, args.preset),
                       "stretch": args.stretch, "quanta_timed": args.quanta, "rows": rows}))
 
 
