@@ -72,6 +72,7 @@ def _batch_vs_ref(hip, ref, S, C, sr, n, nout, cfg, preset, label, setup=None, p
             per_stream_setup(b, s, s)
     y = b.process(xs, nouts)
     b.close()
+    informative = []
     for s in range(S):
         def one(o, s=s):
             if setup:
@@ -81,10 +82,17 @@ def _batch_vs_ref(hip, ref, S, C, sr, n, nout, cfg, preset, label, setup=None, p
         r = pc.make("ref", hip, ref, C, cfg, one, seed=s)  # stream s of a batch = the instance seeded seed + s
         o = r.process(xs[s], nouts[s])
         o2 = [pc.make("ref", hip, ref, C, cfg, one, seed=s).process(pc.perturbed(xs[s], seed), nouts[s]) for seed in pc.SELF_SEEDS]
-        pc.assert_parity(y[s][:, :nouts[s]], o, o2, r.intervalSamples(), "%s stream %d" % (label, s), cap=cap, require_informative=False)
+        informative.append(pc.assert_parity(y[s][:, :nouts[s]], o, o2, r.intervalSamples(), "%s stream %d" % (label, s), cap=cap, require_informative=False))
         # phase-free check that survives decorrelation (SURVEY App. D.2 iv): output energy within 1 %
         ra, rb = np.sqrt(np.mean(y[s][:, :nouts[s]]**2)), np.sqrt(np.mean(o**2))
         assert abs(ra/rb - 1) < 0.01, (label, s, ra, rb)
+    # how far the sample-domain comparison really went, per stream (hops up to which a bound was ASSERTED; beyond that the checker's own
+    # response to a 1e-6 perturbation exceeds the cap and only the phase-free instruments speak): reported, and bounded from below --
+    # the sine streams (s % 3 == 0) must be informative over at least the first 12 hops, and no more than a third of the streams may
+    # be chaos-dominated from the first horizon on (the noise streams through a frequency map are)
+    _report("free_running_horizons/" + label.replace(" ", "_"), dict(hops_asserted=informative, streams=S))
+    assert all(h >= 12 for s, h in enumerate(informative) if s % 3 == 0), (label, informative)
+    assert sum(1 for h in informative if h == 0) <= S//3, (label, informative)
 
 
 def test_config2_subset(hip, ref):
@@ -406,28 +414,31 @@ def _report(name, figures):
         f.write(json.dumps(dict(test=name, **{str(k): plain(v) for k, v in figures.items()})) + "\n")
 
 
+@pytest.mark.parametrize("gain_offsets", [False, True], ids=["equal-gains", "gain-offsets"])
 @pytest.mark.parametrize("label,cfg,C,stretch,setup", [
     ("config2", D48, 2, 1.5, None),
     ("config3", D48, 2, 1.0, _cfg3),
     ("config4b", D48, 2, 0.75, _cfg4b),
     ("config5-8ch-cheaper", CHEAPER96, 8, 1.2, lambda o: o.setTransposeSemitones(-5, 0)),
 ])
-def test_teacher_forced(hip, ref, label, cfg, C, stretch, setup):
-    """D.2 (i): product state := checker state, one hop, Band.output and the emitted interval <= 1e-5 rel-RMS; for the
-    sine / chirp / noise streams of the bench (0, 1, 2).  Also the committed measurement behind PERTURBATION: the
-    analysis spectra of the two implementations differ by `analysis` rel-RMS, which an input perturbation of
-    sqrt(3)*analysis would produce."""
-    w = pc.case_teacher_forced(hip, ref, cfg, C, stretch, "forced " + label, setup=setup, warm_hops=10, forced_hops=8)
+def test_teacher_forced(hip, ref, label, cfg, C, stretch, setup, gain_offsets):
+    """D.2 (i): product state := checker state, one hop, Band.output and the emitted interval; for the sine / chirp / noise streams of
+    the bench (0, 1, 2).  Every hop is bounded (parity_cases.case_teacher_forced): a FIXED ceiling on Band.output outside the
+    arg-max near-tie regions (per bin, decided from the checker's data), 1e-4 on |Band.output| inside them, the smooth
+    5 x self-sensitivity bound on the hops without any discrete event.  Twice: with the bench's equal-amplitude channels (near-ties
+    endemic) and with channel gains 1 - 0.07 c, where at most one hop in ten may have an excused bin at all.  Also the committed
+    measurement behind PERTURBATION: the analysis spectra of the two implementations differ by `analysis` rel-RMS, which an input
+    perturbation of sqrt(3)*analysis would produce."""
+    cap = pc.CAP_FORMANT if label == "config4b" else pc.CAP_TONAL
+    w = pc.case_teacher_forced(hip, ref, cfg, C, stretch, "forced " + label, setup=setup, warm_hops=10, forced_hops=8, cap=cap,
+                               gains=[1 - 0.07*c for c in range(C)] if gain_offsets else None)
     w["equivalent_perturbation"] = 3**0.5*w["analysis"]
-    _report("teacher_forced/" + label, w)
-    # a FIXED ceiling beside the bounds that follow the checker's own one-hop sensitivity (which reaches 1.75 on the chirp stream
-    # under formant compensation: 5 x that bounds nothing): Band.output without the 1 % of bins with the largest error, against
-    # the caps of SURVEY App. D.2 iii -- 5e-3 stretch / pitch only, 5e-2 with formant processing
-    assert w["spectrum_trimmed"] <= (pc.CAP_FORMANT if label == "config4b" else pc.CAP_TONAL), w
-    # ... and on the UNTRIMMED distance of every hop in which no discrete decision flipped (no arg-max channel near-tie, no peak-run
-    # near-tie): the same ceilings, fixed -- not a multiple of the checker's own sensitivity
-    assert w["spectrum_unflipped"] <= (pc.CAP_FORMANT if label == "config4b" else pc.CAP_TONAL) or w["flips"] > w["argmax_ties"], w
-    assert w["ring"] > 0 and (w["ring"] <= max(pc.TOL_FORCED_SAMPLES, pc.SELF_FACTOR*w["ring_self"]) or w["flips"] > 0), w
+    _report("teacher_forced/" + label + ("/gain-offsets" if gain_offsets else ""), w)
+    if gain_offsets:  # at most one hop in ten with an excused region that carries energy (1e-4 of the spectrum)
+        assert w["excused_hops"] <= 0.1*w["hops"] + (1 if C > 2 else 0), w  # (8 channels of independent noise: two to three near-tie bins per hop whatever the gains -- one more hop of 24)
+    assert w["spectrum_outside_ties"] <= cap and w["magnitude_inside_ties"] <= pc.TOL_EXCUSED_MAGNITUDE, w  # (asserted per hop inside the case as well)
+    if gain_offsets:
+        assert w["clean_hops"] >= 0.75*w["hops"], w  # the smooth bound really covers most hops
     assert w["equivalent_perturbation"] <= pc.PERTURBATION, w
     assert w["equivalent_perturbation"] >= pc.PERTURBATION/8, w  # ... and PERTURBATION is not much larger than it needs to be
 
