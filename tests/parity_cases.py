@@ -698,12 +698,16 @@ def _argmax_mask(e_other, e_r, e_twin=None):
     return mask, ties, unexplained
 
 
-def _masked_distances(out_o, out_r, mask):
+def _masked_distances(out_o, out_r, mask, trim=0.0):
     """(distance of the complex spectra over the bins OUTSIDE the mask, distance of the magnitudes INSIDE it), both relative to the
-    checker's whole spectrum."""
+    checker's whole spectrum.  trim: drop that fraction of the outside bins with the largest error first (formant processing: a few
+    near-silent bins are amplified by the envelope ratio and dominate an untrimmed distance, see _crel_trimmed)."""
     o, r = np.asarray(out_o, np.complex128), np.asarray(out_r, np.complex128)
     total = max(float(np.sum(np.abs(r)**2)), 1e-300)
-    outside = float(np.sqrt(np.sum(np.abs(o[:, ~mask] - r[:, ~mask])**2)/total))
+    d = np.sum(np.abs(o[:, ~mask] - r[:, ~mask])**2, axis=0)
+    if trim > 0 and len(d):
+        d = np.sort(d)[:max(1, int(round(len(d)*(1 - trim))))]
+    outside = float(np.sqrt(np.sum(d)/total))
     inside = float(np.sqrt(np.sum((np.abs(o[:, mask]) - np.abs(r[:, mask]))**2)/total))
     return outside, inside
 
@@ -731,7 +735,7 @@ def _inject(batch, stream, r):
 
 
 def case_teacher_forced(lib, ref, cfg, channels, stretch, label, setup=None, warm_hops=9, forced_hops=3, streams=(0, 1, 2), gains=None,
-                        cap=CAP_TONAL, max_excused_share=None):
+                        cap=CAP_TONAL, trim=0.0):
     """D.2 (i): run `warm_hops` hops on both sides, then `forced_hops` times: overwrite the product's carried state with
     the checker's, run ONE hop on both, compare the emitted interval and Band.output.  Every compared hop starts from
     identical state, so nothing is amplified over time -- but one hop still has a condition number: with a frequency
@@ -739,17 +743,20 @@ def case_teacher_forced(lib, ref, cfg, channels, stretch, label, setup=None, war
     regions and with them the phase advance of whole groups of bins.  Bounds, per stream and hop:
 
       * EVERY hop: Band.output OUTSIDE the arg-max near-tie regions (_argmax_mask: per bin, decided from the checker's data) within the
-        FIXED ceiling `cap` (5e-3 stretch / pitch only, 5e-2 with formant processing: SURVEY App. D.2 iii); |Band.output| INSIDE them
-        within TOL_EXCUSED_MAGNITUDE; no arg-max call that differs without being a near-tie -- unless the hop is an explained
-        peak-run flip (_flip_margin: the checker's own energy > smoothedEnergy comparison was a near-tie and the output maps
-        differ), of which at most one in eight hops may occur.
-      * hops without any near-tie region or flip: the smooth bound max(TOL_FORCED_*, SELF_FACTOR * the CHECKER'S OWN one-hop
-        sensitivity) on spectrum, emitted samples and the overlap-add ring, where the sensitivity is measured with a second checker
-        instance that has seen the input perturbed by PERTURBATION throughout and is forced to the first one's state before each
-        compared hop.
+        FIXED ceiling `cap` (5e-3 stretch / pitch only, 5e-2 with formant processing: SURVEY App. D.2 iii; with formant processing
+        without the `trim` share of bins with the largest error -- near-silent bins amplified by the envelope ratio); |Band.output|
+        INSIDE them within TOL_EXCUSED_MAGNITUDE; no arg-max call that differs without being a near-tie -- unless the hop is an
+        explained peak-run flip (_flip_margin: the checker's own energy > smoothedEnergy comparison was a near-tie and the output
+        maps differ), of which at most one in eight hops may occur.
+      * EVERY hop without such a flip, again OUTSIDE the near-tie regions (the product's and the perturbed checker's together): the
+        smooth bound max(TOL_FORCED_SPECTRUM, SELF_FACTOR * the CHECKER'S OWN one-hop sensitivity over the same bins), per stream,
+        worst hop against worst hop and typical against typical -- the sensitivity measured with a second checker instance that has
+        seen the input perturbed by PERTURBATION throughout and is forced to the first one's state before each compared hop.
+      * hops whose near-tie regions hold less than EXCUSED_SHARE of the spectrum's energy ("clean"): the same smooth bound on the
+        emitted samples and on the overlap-add ring (a sample domain has no bins to leave out).
       * `gains`: per-channel input gains.  The bench's inputs give every channel the same amplitude (conftest.synth_input), so
-        near-ties are endemic there (a quarter of the bins of a sine stream); with gains 1 - 0.07 c they are rare, and
-        `max_excused_share` bounds the share of hops that have any excused bin at all.
+        near-ties are endemic there (a quarter of the bins of a sine stream); with gains 1 - 0.07 c they are rare: the caller bounds
+        `excused_hops` and `excused_bin_fraction`.
     Returns the worst figures."""
     pkg = package()
     sr = int(cfg.get("sample_rate", 48000))
@@ -763,6 +770,7 @@ def case_teacher_forced(lib, ref, cfg, channels, stretch, label, setup=None, war
     if setup:
         setup(b)
     I = b.intervalSamples()
+    b_bands = b.bands()
     total_hops = warm_hops + forced_hops
     n_in = _hop_io(I, stretch, total_hops)[1] + 8
     xs = np.stack([synth_input(s, channels, n_in, sr) for s in streams])
@@ -771,7 +779,8 @@ def case_teacher_forced(lib, ref, cfg, channels, stretch, label, setup=None, war
     xp = np.stack([perturbed(x, 1 + i) for i, x in enumerate(xs)])
     worst = dict(spectrum=0.0, spectrum_self=0.0, spectrum_trimmed=0.0, samples=0.0, samples_self=0.0, analysis=0.0, analysis_self=0.0,
                  ring=0.0, ring_self=0.0, spectrum_outside_ties=0.0, magnitude_inside_ties=0.0, spectrum_clean_hops=0.0, spectrum_self_clean_hops=0.0,
-                 ring_clean_hops=0.0, ring_self_clean_hops=0.0, excused_hops=0, excused_bins_max=0, excused_share_max=0.0, argmax_ties=0, hops=S*forced_hops)
+                 ring_clean_hops=0.0, ring_self_clean_hops=0.0, spectrum_outside_all_ties=0.0, spectrum_self_outside_all_ties=0.0, excused_hops=0, excused_bins_max=0, excused_bins_total=0,
+                 excused_share_max=0.0, excused_energy_fraction=0.0, argmax_ties=0, hops=S*forced_hops)
     per = [[] for _ in streams]
     flips = 0
     for k in range(total_hops):
@@ -805,7 +814,12 @@ def case_teacher_forced(lib, ref, cfg, channels, stretch, label, setup=None, war
             e_t = twins[i].bands_real(4)
             mask, ties, unexplained = _argmax_mask(b.debug_state(i, 3), e_r, e_t)
             mask_t, ties_t, _ = _argmax_mask(e_t, e_r, e_t)  # the perturbed checker flips the same kind of call: its hop is no measure of a smooth response either
-            outside, inside = _masked_distances(po, ro, mask)
+            outside, inside = _masked_distances(po, ro, mask, trim)
+            union = mask | mask_t
+            out_p, _ = _masked_distances(po, ro, union)
+            out_t, _ = _masked_distances(twins[i].bands_complex(2), ro, union)
+            share_t = float(np.sum(np.abs(np.asarray(ro, np.complex128)[:, mask_t])**2)/max(np.sum(np.abs(np.asarray(ro, np.complex128))**2), 1e-300))
+            worst["excused_bins_total"] += int(mask.sum())
             share = float(np.sum(np.abs(np.asarray(ro, np.complex128)[:, mask])**2)/max(np.sum(np.abs(np.asarray(ro, np.complex128))**2), 1e-300))
             margin = _flip_margin(b, i, r)
             flipped = margin is not None and margin < MARGIN_FLIP  # the output maps differ and the checker's run boundary there was a near-tie
@@ -813,6 +827,7 @@ def case_teacher_forced(lib, ref, cfg, channels, stretch, label, setup=None, war
             worst["argmax_ties"] += ties
             worst["excused_hops"] += int(share > EXCUSED_SHARE)  # (near-ties among bins at the noise floor excuse nothing that carries energy)
             worst["excused_share_max"] = max(worst["excused_share_max"], share)
+            worst["excused_energy_fraction"] += share/(S*forced_hops)  # (mean over the hops of the energy share inside excused regions)
             worst["excused_bins_max"] = max(worst["excused_bins_max"], int(mask.sum()))
             where = "%s: stream %d, forced hop %d" % (label, streams[i], k - warm_hops)
             if not flipped:
@@ -821,30 +836,33 @@ def case_teacher_forced(lib, ref, cfg, channels, stretch, label, setup=None, war
                 worst["spectrum_outside_ties"] = max(worst["spectrum_outside_ties"], outside)
             assert inside <= TOL_EXCUSED_MAGNITUDE or flipped, "%s: |Band.output| inside the near-tie regions %.3e > %.1e" % (where, inside, TOL_EXCUSED_MAGNITUDE)
             worst["magnitude_inside_ties"] = max(worst["magnitude_inside_ties"], 0.0 if flipped else inside)
-            clean = share <= EXCUSED_SHARE and ties_t == 0 and not flipped
+            clean = share <= EXCUSED_SHARE and share_t <= EXCUSED_SHARE and not flipped
             if clean:
                 for key, v in (("spectrum_clean_hops", e_spec), ("spectrum_self_clean_hops", s_spec), ("ring_clean_hops", e_ring), ("ring_self_clean_hops", s_ring)):
                     worst[key] = max(worst[key], v)
-            per[i].append((e_samp, s_samp, e_spec, s_spec, e_ring, s_ring, float(clean)))
+            if not flipped:
+                per[i].append((e_samp, s_samp, out_p, out_t, e_ring, s_ring, float(clean)))
+                worst["spectrum_outside_all_ties"] = max(worst["spectrum_outside_all_ties"], out_p)
+                worst["spectrum_self_outside_all_ties"] = max(worst["spectrum_self_outside_all_ties"], out_t)
     b.close()
     assert flips <= max(1, (S*forced_hops)//8), (label, "too many flipped peak-run decisions", flips)
     worst["flips"] = flips
-    if max_excused_share is not None:
-        assert worst["excused_hops"] <= max_excused_share*S*forced_hops, (label, "too many hops with an excused arg-max region", worst["excused_hops"], S*forced_hops)
-    # per stream, the hops without any discrete event against SELF_FACTOR x the checker's own one-hop sensitivity -- typical hop against
-    # typical hop as well (one pathological hop of the checker must not widen everything: the chirp stream under formant compensation has
-    # one-hop sensitivities from 4e-3 to 1.7, amplified near-silent bins)
+    worst["excused_bin_fraction"] = worst["excused_bins_total"]/float(S*forced_hops*b_bands)
+    # per stream: every un-flipped hop's spectrum outside the near-tie regions, and the clean hops' samples and ring, against SELF_FACTOR x
+    # the checker's own one-hop sensitivity -- typical hop against typical hop as well (one pathological hop of the checker must not widen
+    # everything: the chirp stream under formant compensation has one-hop sensitivities from 4e-3 to 1.7, amplified near-silent bins)
     clean_total = 0
     for i in range(S):
-        a = np.array(per[i])
-        a = a[a[:, 6] > 0]
-        clean_total += len(a)
-        if len(a) == 0:
-            continue
-        for col, name, tol in ((0, "samples", TOL_FORCED_SAMPLES), (2, "spectrum", TOL_FORCED_SPECTRUM), (4, "ring", TOL_FORCED_SAMPLES)):
-            assert np.median(a[:, col]) <= max(tol, SELF_FACTOR*np.median(a[:, col + 1])), (label, streams[i], "median " + name, np.median(a[:, col]), np.median(a[:, col + 1]))
-            bound = max(tol, SELF_FACTOR*a[:, col + 1].max())
-            assert a[:, col].max() <= bound, "%s: stream %d: %s rel-RMS %.3e > %.1e (checker's one-hop sensitivity %.1e)" % (label, streams[i], name, a[:, col].max(), bound, a[:, col + 1].max())
+        a = np.array(per[i]).reshape(-1, 7)
+        for rows, cols in ((a, ((2, "spectrum outside the near-tie regions", TOL_FORCED_SPECTRUM),)),
+                           (a[a[:, 6] > 0], ((0, "samples", TOL_FORCED_SAMPLES), (4, "ring", TOL_FORCED_SAMPLES)))):
+            if len(rows) == 0:
+                continue
+            for col, name, tol in cols:
+                assert np.median(rows[:, col]) <= max(tol, SELF_FACTOR*np.median(rows[:, col + 1])), (label, streams[i], "median " + name, np.median(rows[:, col]), np.median(rows[:, col + 1]))
+                bound = max(tol, SELF_FACTOR*rows[:, col + 1].max())
+                assert rows[:, col].max() <= bound, "%s: stream %d: %s rel-RMS %.3e > %.1e (checker's one-hop sensitivity %.1e)" % (label, streams[i], name, rows[:, col].max(), bound, rows[:, col + 1].max())
+        clean_total += int((a[:, 6] > 0).sum())
     worst["clean_hops"] = clean_total
     assert worst["ring"] > 0, (label, "the ring comparison is empty")
     return worst
