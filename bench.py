@@ -118,9 +118,15 @@ def cpu_baseline(budget_s=5.0):
 
 
 def cmd_binary_baseline(physical_cpus, seconds=30.0, stretch=1.5):
-    """The reference's OWN cmd/ binary (oracle/_ref/ref_cli = /root/reference/cmd/main.cpp compiled unmodified) on the same
-    kind of input, WAV file in -> WAV file out (so its 16-bit file I/O is inside the time): once alone on an idle core, then one
-    pinned process per physical core at the same time.  Samples counted as the GPU line counts them (in + out, per channel)."""
+    """The reference's OWN cmd/ binary (oracle/_ref/ref_cli = /root/reference/cmd/main.cpp compiled unmodified) on the same kind of
+    input, WAV file in -> WAV file out: alone on an idle core, then one pinned process per physical core for a quarter of the cores and
+    for all of them.  Every process works in a directory of its own on tmpfs with its own copy of the input (round 4 had all of them
+    read one file and write into one directory).  The binary decodes and encodes 16-bit WAV and starts a process per file: that is
+    INSIDE its time by construction (the reference has no other entry point for files), so per process the wall time is reported next
+    to the CPU time the kernel charged it (user + system, os.wait4): where the two part, the processes are waiting for each other in
+    the file system, not computing.  Samples counted as the GPU line counts them (in + out, per channel).  The figure to compare a GPU
+    number with is `cpu_baseline.value` -- the same reference code timed around process() only."""
+    import shutil
     import struct
     import tempfile
     import numpy as np
@@ -132,36 +138,56 @@ def cmd_binary_baseline(physical_cpus, seconds=30.0, stretch=1.5):
     n = int(seconds*SR)
     x = 0.8*synth_input(0, 2, n, SR)
     tmp = tempfile.mkdtemp(prefix="smst_cmd_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
-    src = os.path.join(tmp, "in.wav")
     data = np.clip(np.round(x.T*32768.0), -32768, 32767).astype("<i2").tobytes()
-    with open(src, "wb") as f:
-        f.write(b"RIFF" + struct.pack("<I", 36 + len(data)) + b"WAVEfmt " + struct.pack("<IHHIIHH", 16, 1, 2, SR, SR*4, 4, 16))
-        f.write(b"data" + struct.pack("<I", len(data)) + data)
+    wav = b"RIFF" + struct.pack("<I", 36 + len(data)) + b"WAVEfmt " + struct.pack("<IHHIIHH", 16, 1, 2, SR, SR*4, 4, 16) + b"data" + struct.pack("<I", len(data)) + data
     samples = 2*(n + int(round(n*stretch)))
 
-    def launch(cpu, i):
+    def prepare(i):
+        d = os.path.join(tmp, "p%d" % i)
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, "in.wav"), "wb") as f:
+            f.write(wav)
+        return d
+
+    def launch(cpu, d):
         def pin():
             try:
                 os.sched_setaffinity(0, {cpu})
             except OSError:
                 pass
-        return subprocess.Popen([exe, src, os.path.join(tmp, "out%d.wav" % i), "--time=%g" % stretch], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, preexec_fn=pin)
-    try:
+        return subprocess.Popen([exe, os.path.join(d, "in.wav"), os.path.join(d, "out.wav"), "--time=%g" % stretch], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, preexec_fn=pin)
+
+    def run(cpus):
+        dirs = [prepare(i) for i in range(len(cpus))]  # (the input copies are written before the clock starts)
         t0 = time.perf_counter()
-        rc = launch(physical_cpus[0], 0).wait()
-        single = time.perf_counter() - t0
-        if rc != 0:
-            return dict(error="ref_cli exited with %d" % rc)
-        t0 = time.perf_counter()
-        procs = [launch(cpu, i) for i, cpu in enumerate(physical_cpus)]
-        ok = all(p.wait() == 0 for p in procs)
+        procs = [launch(cpu, d) for cpu, d in zip(cpus, dirs)]
+        cpu_s, ok = [], True
+        for p in procs:
+            _, status, ru = os.wait4(p.pid, 0)
+            p.returncode = os.waitstatus_to_exitcode(status) if hasattr(os, "waitstatus_to_exitcode") else (status >> 8)
+            ok = ok and p.returncode == 0
+            cpu_s.append(ru.ru_utime + ru.ru_stime)
         wall = time.perf_counter() - t0
+        for d in dirs:
+            shutil.rmtree(d, ignore_errors=True)
+        return dict(processes=len(cpus), wall_s=wall, aggregate_Msamples_s=(samples*len(cpus)/wall/1e6 if ok else None),
+                    mean_cpu_s_per_process=sum(cpu_s)/len(cpu_s), Msamples_s_per_process_cpu_time=samples/(sum(cpu_s)/len(cpu_s))/1e6, ok=ok)
+    try:
+        single = run(physical_cpus[:1])
+        if not single["ok"]:
+            return dict(error="ref_cli failed")
+        quarter = run(physical_cpus[:max(1, len(physical_cpus)//4)])
+        full = run(physical_cpus)
     finally:
-        import shutil
         shutil.rmtree(tmp, ignore_errors=True)
     return dict(binary="oracle/_ref/ref_cli (cmd/main.cpp, unmodified; g++ -O3; L1 restated)", what="%.0f s stereo 48 kHz 16-bit WAV -> WAV at %.2fx, presetDefault; "
-                "whole process incl. file I/O in /dev/shm" % (seconds, stretch), single_process_s=single, single_process_Msamples_s=samples/single/1e6,
-                processes=len(physical_cpus), all_processes_wall_s=wall, aggregate_Msamples_s=(samples*len(physical_cpus)/wall/1e6 if ok else None))
+                "whole process incl. start-up and file I/O, a tmpfs directory and input copy per process" % (seconds, stretch),
+                single_process_s=single["wall_s"], single_process_Msamples_s=single["aggregate_Msamples_s"],
+                processes=full["processes"], all_processes_wall_s=full["wall_s"], aggregate_Msamples_s=full["aggregate_Msamples_s"],
+                runs=[single, quarter, full],
+                authoritative="cpu_baseline.value (the same reference code as a library, timed around process() only) is the CPU figure to hold a GPU "
+                              "number against; this binary's aggregate is bounded by process start-up and WAV file I/O once many run at the same time "
+                              "(compare wall_s with mean_cpu_s_per_process in `runs`)")
 
 
 # rel-RMS of stream 0's first second against oracle/_ref as measured on the MI355X (profiles/r4_bench_*.json; stream 0 is the tonal stream):
@@ -193,32 +219,81 @@ def self_check(batch_first_output, x0, n_out0, C, sr_cfg, preset, setup, seconds
                 bound="rel-RMS < %.1e over the first second (10 x the value measured for this config on the MI355X), level within 0.1 %%" % bound)
 
 
-def pin_rank_to_numa_node(local_rank, world):
-    """Multi-GPU runs: keep each rank's host scheduler (the block scheduler of process() is single-threaded host code) on
-    the CPUs of the NUMA node its GPU hangs off; ranks that share a node split its CPUs.  Best effort, silent when sysfs
-    has no answer."""
+def cpu_ranges(cpus):
+    """[0, 1, 2, 3, 8, 9] -> "0-3,8-9" """
+    out, cpus = [], sorted(cpus)
+    i = 0
+    while i < len(cpus):
+        j = i
+        while j + 1 < len(cpus) and cpus[j + 1] == cpus[j] + 1:
+            j += 1
+        out.append(str(cpus[i]) if i == j else "%d-%d" % (cpus[i], cpus[j]))
+        i = j + 1
+    return ",".join(out)
+
+
+def device_pci_address(index):
+    """"dddd:bb:dd.f" of HIP device `index`: from the HIP runtime itself (hipDeviceGetPCIBusId through the library torch has loaded),
+    else from torch's device properties; None if neither answers."""
+    import ctypes
     try:
         import torch
-        bus = torch.cuda.get_device_properties(local_rank).pci_bus_id if hasattr(torch.cuda.get_device_properties(local_rank), "pci_bus_id") else None
-        node = None
-        if bus is not None:
-            for cand in ("/sys/bus/pci/devices/0000:%02x:00.0/numa_node" % bus,):
-                if os.path.exists(cand):
-                    node = int(open(cand).read().strip())
-        cpus = sorted(os.sched_getaffinity(0))
-        if node is not None and node >= 0:
-            spec = open("/sys/devices/system/node/node%d/cpulist" % node).read().strip()
-            node_cpus = []
-            for part in spec.split(","):
-                a, _, b = part.partition("-")
-                node_cpus += list(range(int(a), int(b or a) + 1))
-            cpus = [c for c in cpus if c in set(node_cpus)] or cpus
-        share = max(1, len(cpus)//max(world, 1))
-        mine = cpus[(local_rank*share) % len(cpus):][:share] or cpus
-        os.sched_setaffinity(0, set(mine))
-        return mine
+        libdir = os.path.join(os.path.dirname(torch.__file__), "lib")
+        for name in ("libamdhip64.so", "libamdhip64.so.6", "libamdhip64.so.7"):
+            path = os.path.join(libdir, name)
+            if not os.path.exists(path):
+                continue
+            hip = ctypes.CDLL(path)
+            buf = ctypes.create_string_buffer(64)
+            if hip.hipDeviceGetPCIBusId(buf, 64, int(index)) == 0 and buf.value:
+                return buf.value.decode().lower()
     except Exception:
-        return None
+        pass
+    try:
+        import torch
+        p = torch.cuda.get_device_properties(index)
+        if hasattr(p, "pci_bus_id"):
+            return "%04x:%02x:%02x.0" % (getattr(p, "pci_domain_id", 0), p.pci_bus_id, getattr(p, "pci_device_id", 0))
+    except Exception:
+        pass
+    return None
+
+
+def pin_rank_to_numa_node(local_rank, world, share_index=None, strict=True):
+    """Multi-GPU runs: keep each rank's host scheduler (the block scheduler of process() is single-threaded host code) on the CPUs of
+    the NUMA node its GPU hangs off; ranks whose GPUs share a node split its CPUs (share_index of `world` shares).  LOUD: returns what
+    it did -- PCI address, NUMA node, the CPU set it chose -- for the JSON line of EVERY rank, and with strict=True (--gpus > 1 on real
+    devices) it raises when the device's PCI address or NUMA node cannot be read: eight ranks silently sharing rank 0's CPUs would
+    look like bad scaling of the engine."""
+    report = dict(device=local_rank, pci=None, numa_node=None, cpus=None, pinned=False)
+    pci = device_pci_address(local_rank)
+    report["pci"] = pci
+    node = None
+    if pci is not None:
+        path = "/sys/bus/pci/devices/%s/numa_node" % pci
+        if os.path.exists(path):
+            node = int(open(path).read().strip())
+    report["numa_node"] = node
+    if pci is None or node is None:
+        if strict:
+            raise SystemExit("bench: cannot read the PCI address / NUMA node of device %d (pci %r): refusing to run %d ranks unpinned "
+                             "(--no-numa-pinning to run them where the launcher put them)" % (local_rank, pci, world))
+        report["cpus"] = cpu_ranges(os.sched_getaffinity(0))
+        return report
+    cpus = sorted(os.sched_getaffinity(0))
+    if node >= 0:  # (-1: the platform has a single node / does not say: the whole affinity mask)
+        node_cpus = set()
+        for part in open("/sys/devices/system/node/node%d/cpulist" % node).read().strip().split(","):
+            a, _, b = part.partition("-")
+            node_cpus.update(range(int(a), int(b or a) + 1))
+        cpus = [c for c in cpus if c in node_cpus] or cpus
+    share = max(1, len(cpus)//max(world, 1))
+    k = local_rank if share_index is None else share_index
+    mine = cpus[(k*share) % len(cpus):][:share] or cpus
+    os.sched_setaffinity(0, set(mine))
+    report["cpus"] = cpu_ranges(mine)
+    report["pinned"] = True
+    return report
 
 
 def own_algorithmic_bytes(B, I, M, r):
@@ -284,6 +359,7 @@ def main():
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"], help="nccl = RCCL (the multi-GPU default); gloo only for --oversubscribe if RCCL refuses two ranks on one device")
     ap.add_argument("--as-rank", type=int, default=None, help="single-process run with the stream indices and seed of this rank (cross-check of an --oversubscribe run)")
     ap.add_argument("--dump-output", default=None, help="write rank-local output of the first streams to this .npy prefix (oversubscribe cross-check)")
+    ap.add_argument("--no-numa-pinning", action="store_true", help="with --gpus > 1: leave every rank's CPU affinity as the launcher set it (default: pin each rank's host scheduler to the CPUs of its GPU's NUMA node, and FAIL if that node cannot be read)")
     ap.add_argument("--half-state", action="store_true", help="BASELINE config 5 'fp16 internal': carried state and overlap-add sums stored in fp16 (SMST_FLAG_HALF_STATE)")
     ap.add_argument("--config", default="2", choices=["2", "3", "4", "4b", "5"],
                     help="BASELINE.json config (default 2 = the one the headline metric is quoted on; the others are "
@@ -342,15 +418,20 @@ def main():
     if use_dist and dist_world != args.gpus:
         raise SystemExit("bench: the process group has %d ranks, --gpus says %d" % (dist_world, args.gpus))
 
-    affinity = pin_rank_to_numa_node(dev_index if args.oversubscribe else local_rank, world) if world > 1 else None
-    if args.oversubscribe and affinity and world > 1:  # ranks share the device's NUMA node: split its CPUs by RANK, not by device index
-        try:
-            cpus = sorted(os.sched_getaffinity(0))
-            share = max(1, len(cpus)//world)
-            os.sched_setaffinity(0, set(cpus[rank*share:(rank + 1)*share] or cpus))
-            affinity = sorted(os.sched_getaffinity(0))
-        except OSError:
-            pass
+    # one line per rank about where its host scheduler runs: PCI address and NUMA node of its GPU, the CPU set it was pinned to.  With
+    # more than one rank a device whose NUMA node cannot be read is an error (--no-numa-pinning: run where the launcher put the ranks)
+    if world > 1 and not args.no_numa_pinning:
+        placement = pin_rank_to_numa_node(dev_index, world, share_index=rank if args.oversubscribe else local_rank, strict=not args.oversubscribe)
+    else:
+        placement = dict(device=dev_index, pci=device_pci_address(dev_index), numa_node=None, cpus=cpu_ranges(os.sched_getaffinity(0)), pinned=False)
+    placement["rank"] = rank
+    placements = [placement]
+    if use_dist:
+        placements = [None]*dist_world
+        dist.all_gather_object(placements, placement)
+    if world > 1:
+        print("bench: rank %d -> device %d (pci %s, NUMA node %s), host scheduler on CPUs %s%s" % (
+            rank, dev_index, placement["pci"], placement["numa_node"], placement["cpus"], "" if placement["pinned"] else " (NOT pinned)"), file=sys.stderr)
     pkg = importlib.import_module("signalsmith-stretch_amd")
     S = args.streams
     n_in = int(args.seconds*sr_cfg)
@@ -541,7 +622,7 @@ def main():
                        % (args.config, S, C, sr_cfg, preset, args.seconds),
                        "streams_total": world*S, "channels": C, "block": B, "interval": I, "fft": batch.fftSamples(),
                        "hops_per_stream_per_step": hops_per_stream, "sharding": sharding,
-                       "rank0_cpu_affinity": ("%d CPUs from %d" % (len(affinity), affinity[0])) if affinity else None},
+                       "ranks": placements},
             "realtime_x": world*S*args.seconds*args.steps/elapsed,
             "channels": C,
             "output_finite_nonzero": ok, "self_check": check,

@@ -85,7 +85,10 @@ void smst_destroy(smst_stretch *h);
  * here, independently of each other.  An unconfigured `src` gives an unconfigured copy. */
 int smst_clone(smst_stretch **out, const smst_stretch *src);
 /* The device new single-stream objects of the C++ drop-in header are created on (the reference has no such notion): the
- * environment variable SMST_DEVICE at first use, 0 if unset, or whatever smst_set_default_device() was given last. */
+ * environment variable SMST_DEVICE at first use, 0 if unset, or whatever smst_set_default_device() was given last.
+ * An SMST_DEVICE that is not an ordinal this process can see (not a number, or >= smst_device_count()) is an ERROR, not device 0: the
+ * function reports it on stderr once and returns -1 from then on, and smst_create(..., -1) fails with SMST_ERR_INVALID and a message
+ * that names the value and the device count (one rank per GPU: a silent fall-back would put every rank on GPU 0). */
 int smst_default_device(void);
 int smst_set_default_device(int device);
 

@@ -15,9 +15,9 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# The engine's three pipeline streams must not share a hardware queue with each other ("Hardware queues"): effective
-# only if the HIP runtime has not started yet -- import this package (or set the variable) before the first torch.cuda / HIP call.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# (The engine's three pipeline streams should not share a hardware queue: INTEGRATION.md "Hardware queues" asks the HOST APPLICATION to
+# export GPU_MAX_HW_QUEUES=8 before the HIP runtime starts.  Importing this package does not touch the environment -- bench.py and tools/
+# set the variable themselves; load_library() warns once when it finds the runtime already started with fewer queues.)
 # SMST_LIBRARY: measurement hook of bench.py / tools/ -- another BUILD of the same library (an A/B variant, an instrumented trace
 # build under variants/), never another implementation; unset in every product use, and announced on stderr when set.  A build that
 # lacks entry points of include/smst.h is refused at load unless SMST_LIBRARY_ALLOW_MISSING=1 (A/B against an older revision).
@@ -149,8 +149,16 @@ def load_library():
             import torch  # noqa: F401
         except ImportError:
             pass
+        import sys
+        try:  # advisory only: with 4 hardware queues (HIP's default) a step of the pipelined engine takes ~12 % longer next to an RCCL communicator
+            queues = int(os.environ.get("GPU_MAX_HW_QUEUES", "4"))
+        except ValueError:
+            queues = 4
+        torch_mod = sys.modules.get("torch")
+        if queues < 8 and torch_mod is not None and torch_mod.cuda.is_available() and torch_mod.cuda.is_initialized():
+            print("signalsmith-stretch_amd: the HIP runtime is already running with GPU_MAX_HW_QUEUES=%d; export GPU_MAX_HW_QUEUES=8 before the "
+                  "first HIP call so that the engine's pipeline streams get hardware queues of their own (INTEGRATION.md)" % queues, file=sys.stderr)
         if os.environ.get("SMST_LIBRARY"):
-            import sys
             print("signalsmith-stretch_amd: SMST_LIBRARY is set -- loading %s instead of the in-tree library (measurement hook)" % LIBRARY_PATH, file=sys.stderr)
         _lib = bind(C.CDLL(LIBRARY_PATH))
     return _lib

@@ -2,6 +2,8 @@
 // handle; device-memory calls go straight to the engine.
 #include "../../include/smst.h"
 #include "smst_engine.h"
+#include <cstdio>
+#include <mutex>
 
 #include <algorithm>
 #include <atomic>
@@ -270,12 +272,13 @@ int smst_batch_output_seek(smst_batch *b, const float *in, long long ss, long lo
 // ---------------------------------------------------------------------------------------------------------
 // single-stream handle API (web/emscripten/main.cpp:15-77 with a handle instead of the global singleton)
 // ---------------------------------------------------------------------------------------------------------
+static std::string g_defaultDeviceError; // set once by smst_default_device() when SMST_DEVICE names no device of this process
 int smst_create(smst_stretch **out, long seed, int device) {
 	if (!out) return fail("null output pointer");
 	SMST_TRY
 	int n = 0;
 	if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) throw smst::Error("hipGetDeviceCount: no HIP device available (the gfx950 path has no CPU fallback)", true);
-	if (device < 0 || device >= n) throw smst::Error("device ordinal out of range");
+	if (device < 0 || device >= n) throw smst::Error(g_defaultDeviceError.empty() ? std::string("device ordinal out of range") : g_defaultDeviceError);
 	smst_stretch *h = new smst_stretch();
 	h->seed = seed;
 	h->device = device;
@@ -287,19 +290,32 @@ void smst_destroy(smst_stretch *h) { delete h; }
 
 // the device new single-stream handles are created on: SMST_DEVICE (validated against the device count, once) or the setter
 static std::atomic<int> g_defaultDevice{-1};
+// SMST_DEVICE that is no ordinal this process can see is an ERROR (one rank per GPU: a wrong ordinal or a mismatch with HIP_VISIBLE_DEVICES
+// would put every rank on GPU 0 without a word): smst_default_device() reports it on stderr once and returns -1, and smst_create() on the
+// default device fails with SMST_ERR_INVALID naming the value and the device count.
 int smst_default_device(void) {
 	int v = g_defaultDevice.load(std::memory_order_acquire);
-	if (v < 0) {
+	if (v == -1) {
 		v = 0;
 		if (const char *env = std::getenv("SMST_DEVICE")) {
 			char *end = nullptr;
 			const long asked = std::strtol(env, &end, 10);
 			const int n = smst_device_count();
-			if (end != env && *end == '\0' && asked >= 0 && (n <= 0 || asked < n)) v = int(asked); // an ordinal this process cannot see falls back to 0
+			if (end != env && *end == '\0' && asked >= 0 && (n <= 0 || asked < n)) {
+				v = int(asked);
+			} else {
+				static std::once_flag once;
+				std::call_once(once, [&] {
+					g_defaultDeviceError = std::string("SMST_DEVICE=\"") + env + "\" is not a device ordinal of this process (" + std::to_string(n) + " device(s) visible)";
+					std::fprintf(stderr, "libsmst_hip: %s\n", g_defaultDeviceError.c_str());
+				});
+				v = -2; // latched: invalid
+			}
 		}
 		int expected = -1;
 		if (!g_defaultDevice.compare_exchange_strong(expected, v, std::memory_order_acq_rel)) v = expected; // another thread (or the setter) was first
 	}
+	if (v == -2) { fail(g_defaultDeviceError.c_str()); return -1; }
 	return v;
 }
 int smst_set_default_device(int device) {

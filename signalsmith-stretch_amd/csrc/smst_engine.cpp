@@ -1,5 +1,6 @@
 // Host-side engine implementation.  See smst_engine.h.
 #include "smst_engine.h"
+#include "smst_switches.h"
 
 #include <algorithm>
 #include <cmath>
@@ -150,12 +151,10 @@ void Batch::construct(const FftPlan &plan, long seed) {
 		SMST_HIP(hipEventCreateWithFlags(&evChain[i], hipEventDisableTiming));
 		SMST_HIP(hipEventCreateWithFlags(&evSynth[i], hipEventDisableTiming));
 	}
-	// environment switches are read once, here
-	if (const char *env = std::getenv("SMST_NO_OVERLAP")) overlap = atoi(env) == 0;
-	noFuse = std::getenv("SMST_NO_FUSE") != nullptr;
-	noSingleHop = std::getenv("SMST_NO_SINGLE_HOP") != nullptr;
-	noAcross = std::getenv("SMST_NO_ACROSS") != nullptr;
-	if (const char *env = std::getenv("SMST_CHECK_LAUNCHES")) checkLaunches = atoi(env) != 0;
+	// the cross-check switches: one struct, one table, read once (smst_switches.h)
+	const Switches sw = Switches::fromEnvironment();
+	overlap = sw.overlap; noFuse = sw.noFuse; noSingleHop = sw.noSingleHop; noAcross = sw.noAcross; checkLaunches = sw.checkLaunches;
+	workspaceGiB = sw.workspaceGiB;
 
 	d.S = S; d.C = C; d.B = B; d.I = I; d.M = M; d.N = N; d.L = L; d.T = kTileHops;
 	d.histLen = B + I;
@@ -168,26 +167,19 @@ void Batch::construct(const FftPlan &plan, long seed) {
 	d.plan = plan;
 	d.mapTableLen = 0;
 	d.halfState = halfState ? 1 : 0;
-	d.debugMode = 0;
-#ifdef SMST_EXPERIMENTS
-	if (const char *env = std::getenv("SMST_DEBUG_MODE")) d.debugMode = atoi(env);
-#endif
-	d.noFeedFusion = 0;
-	if (const char *env = std::getenv("SMST_NO_FEED_FUSION")) d.noFeedFusion = atoi(env);
-	d.noStage = std::getenv("SMST_NO_STAGE") != nullptr;
-	d.noAlign = std::getenv("SMST_NO_ALIGN") != nullptr;
-	d.alignAll = std::getenv("SMST_ALIGN_ALL") != nullptr;
-	d.noFastFft = std::getenv("SMST_NO_FAST_FFT") != nullptr;
+	d.debugMode = sw.debugMode;
+	d.noFeedFusion = sw.noFeedFusion;
+	d.noStage = sw.noStage;
+	d.noAlign = sw.noAlign;
+	d.alignAll = sw.alignAll;
+	d.noFastFft = sw.noFastFft;
 	// lean FFT tables (8-byte window entries + generated modulation, six stage twiddles instead of fifteen) are OPT-IN: they take 0.2 ms
 	// off a 16.3-ms step, and their one extra rounding per element (spectra 1.2e-7 away from the full tables') flipped a peak decision
 	// of a noise stream in tests/test_parity_gpu.py::test_batch_ragged -- parity first
-	d.fftLean = 0;
-	if (const char *env = std::getenv("SMST_FFT_TABLES")) d.fftLean = std::string(env) == "lean";
-	d.feedSerial = std::getenv("SMST_FEED_SERIAL") != nullptr;
-	d.fftTeams = 1;
-	if (const char *env = std::getenv("SMST_FFT_TEAMS")) d.fftTeams = atoi(env);
-	d.synthEmit = 1;
-	if (const char *env = std::getenv("SMST_SYNTH_EMIT")) d.synthEmit = atoi(env);
+	d.fftLean = sw.fftLean ? 1 : 0;
+	d.feedSerial = sw.feedSerial;
+	d.fftTeams = sw.fftTeams;
+	d.synthEmit = sw.synthEmit;
 	{
 		int cus = 0;
 		SMST_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
@@ -461,7 +453,7 @@ void Batch::allocateWorkspace() {
 			budgetGiB = std::min(std::min(96.0, std::max(8.0, freeGiB/3.0)), 0.4*freeGiB);
 		}
 	}
-	if (const char *env = std::getenv("SMST_WORKSPACE_GIB")) budgetGiB = std::max(0.0005, atof(env));
+	if (workspaceGiB > 0) budgetGiB = std::max(0.0005, workspaceGiB); // SMST_WORKSPACE_GIB (smst_switches.h)
 	const bool needRecords = !fusedSupported(d) || noFuse; // the fused recurrence keeps its records in LDS
 	const size_t recChunks = (9 + 3*(size_t)C + 3)/4;
 	d.recSteps = ((M + d.lag*(d.T - 1) + 63)/64)*64 + 8;

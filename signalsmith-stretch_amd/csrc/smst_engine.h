@@ -140,7 +140,8 @@ private:
 	int callCur = 0;
 	hipEvent_t evStart = nullptr, evFeed[2] = {nullptr, nullptr}, evChain[2] = {nullptr, nullptr}, evSynth[2] = {nullptr, nullptr};
 	struct TileBuffers { float2 *Xcur, *Xprev, *OUT, *dump, *map, *peaksT; float4 *REC; PredEntry *PE; float *ratio, *energyT, *smoothT, *est, *freqEst, *frames; } slots[2]{};
-	bool overlap = true, noFuse = false, noSingleHop = false, noAcross = false;
+	bool overlap = true, noFuse = false, noSingleHop = false, noAcross = false; // (smst_switches.h)
+	double workspaceGiB = 0;
 	int subS = 0;
 	// per-call host scratch, kept between calls (no heap traffic in steady state); growth events are counted
 	std::vector<int> hopFirst, hopCount, maxSpanV;

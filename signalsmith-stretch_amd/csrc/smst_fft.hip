@@ -1100,6 +1100,9 @@ bool synthEmitApplies(const DevBatch &d, int nStreams, int tileHops) {
 	if (!(d.delta == 0 || d.delta == d.I)) return false;
 	const int QN = d.M == 256*10 ? 3 : 4, SLOTS = d.M == 256*10 ? 8 : 6; // the presets' block / interval ratios (2.5 and 4)
 	if (QN*d.I < d.B || d.I > 256*SLOTS || d.B > d.N) return false;
+	// the teams read wpHead[off + q*I + r] for q <= QN, r < I, with off = the samples in front of a tile's first hop (< I: a block begins at
+	// the latest I - 1 samples into a call, smst_engine.cpp): inside the (ceil(B/I) + 2)*I floats per stream only if QN >= ceil(B/I) -- stated, not assumed
+	if ((QN + 2)*d.I > d.wpHeadLen) return false;
 	// one (stream, channel) per team, its hops in sequence.  Measured on 256 CUs (profiles/r4_synth_emit_sweep.txt): ahead of the two
 	// kernels from 32 stereo streams on, at every batch size up to 1024 -- also where the last round of teams is mostly empty
 	return d.synthEmit == 2 || (tileHops >= 8 && nStreams*d.C >= 64);

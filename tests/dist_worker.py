@@ -20,12 +20,17 @@ def main():
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     emu = pkg.bind(ctypes.CDLL(os.path.join(ROOT, "tests", "emu", "libsmst_emu.so")))
-    total, C, n, nout = 5, 2, 3000, 3600
+    # argv: <output file> [total streams] [n in] [n out]; beyond 2x the hops draw random time factors, so the per-rank seed matters:
+    # global stream g carries the reference engine seeded g = the rank's first stream + i (bench.py: seed = rank * streams per GPU)
+    total = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+    n = int(sys.argv[3]) if len(sys.argv) > 3 else 3000
+    nout = int(sys.argv[4]) if len(sys.argv) > 4 else 3600
+    C = 2
     lo, hi = sharding.shard_range(total, rank, world)
     xs = np.stack([synth_input(s, C, n, 48000) for s in range(lo, hi)])
-    b = pkg.StretchBatch(hi - lo, C, block=512, interval=128, lib=emu)
+    b = pkg.StretchBatch(hi - lo, C, block=512, interval=128, lib=emu, seed=lo)
     for i, s in enumerate(range(lo, hi)):
-        b.setTransposeSemitones(float(s - 2), 0.0, stream=i)
+        b.setTransposeSemitones(float(s % 5 - 2), 0.0, stream=i)
     dist.barrier()
     y = b.process(xs, nout)
     dist.barrier()

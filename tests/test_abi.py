@@ -74,3 +74,34 @@ def test_error_codes_distinguish_device_from_argument_errors(emu):
     assert emu.smst_batch_create(ctypes.byref(h), 1, 2, 512, 128, 0, 0, 0) == 0
     assert emu.smst_batch_set_transpose_factor(h, 5, 1.0, 0.0) == -1               # stream index out of range
     emu.smst_batch_destroy(h)
+
+
+def test_process_does_not_allocate_in_steady_state_split(emu):
+    """... nor in split-computation mode, where every call leaves a block in flight (its tables were sized at construction)"""
+    _steady_state_allocations(emu, dict(block=512, interval=128, split=True))
+
+
+def test_invalid_default_device_is_an_error(emu):
+    """SMST_DEVICE that names no device of the process: smst_default_device() says so and returns -1, a handle on the default device is
+    refused with the value and the device count in the message -- not silently created on device 0."""
+    import subprocess
+    import sys
+    code = (
+        "import ctypes, sys\n"
+        "sys.path.insert(0, %r)\n"
+        "import importlib\n"
+        "pkg = importlib.import_module('signalsmith-stretch_amd')\n"
+        "lib = pkg.bind(ctypes.CDLL(%r))\n"
+        "d = lib.smst_default_device()\n"
+        "h = ctypes.c_void_p()\n"
+        "rc = lib.smst_create(ctypes.byref(h), 0, d)\n"
+        "print(d, rc, lib.smst_last_error().decode())\n"
+    ) % (ROOT, os.path.join(ROOT, "tests", "emu", "libsmst_emu.so"))
+    for value, ok in (("7", False), ("gpu1", False), ("0", True)):
+        res = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, SMST_DEVICE=value), capture_output=True, text=True, check=True)
+        d, rc, msg = res.stdout.strip().split(" ", 2) if res.stdout.strip().count(" ") >= 2 else (res.stdout.strip().split(" ") + [""])[:3]
+        if ok:
+            assert (int(d), int(rc)) == (0, 0), res.stdout
+        else:
+            assert int(d) == -1 and int(rc) != 0 and "SMST_DEVICE" in msg and value in msg and "1 device" in msg, (res.stdout, res.stderr)
+            assert "SMST_DEVICE" in res.stderr

@@ -52,3 +52,13 @@ def test_in_flight_across_a_back_edge(tmp_path):
     text = (HEAD + "\ts_waitcnt vmcnt(0)\n.LBB0_1:\n\tv_mov_b32_e32 v20, v10\n" + ASM_LOAD + "\ts_cbranch_scc1 .LBB0_1\n\ts_waitcnt vmcnt(0)\n" + TAIL)
     found = run(text, tmp_path)
     assert len(found) == 2 and "v_mov_b32_e32 v20, v10" in found[0] and "global_load_dwordx2 v[10:11]" in found[1]  # (the copy; the re-request into a register still in flight)
+
+
+def test_functions_are_picked_by_content(tmp_path):
+    """No name list: every function with an inline-assembly load is checked, whatever it is called -- and only those."""
+    p = tmp_path / "k.s"
+    p.write_text("_Z6kPlainv:\n\tglobal_load_dword v30, v[2:3], off\n\ts_waitcnt vmcnt(0)\n\ts_endpgm\n.Lfunc_end0:\n"
+                 + "_Z9kNewAsyncILi3EEvv:\n" + ASM_LOAD + "\tv_mov_b32_e32 v20, v10\n\ts_waitcnt vmcnt(0)\n\ts_endpgm\n.Lfunc_end1:\n")
+    picked = list(chk.functions(str(p)))
+    assert [name for name, _ in picked] == ["_Z9kNewAsyncILi3EEvv"]
+    assert len(chk.check_function(picked[0][0], picked[0][1], str(p))) == 1

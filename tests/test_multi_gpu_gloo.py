@@ -35,10 +35,38 @@ def test_world_size_2_gloo_matches_single_process(emu, tmp_path):
     xs = np.stack([synth_input(s, C, n, 48000) for s in range(total)])
     b = pkg.StretchBatch(total, C, block=512, interval=128, lib=emu)
     for s in range(total):
-        b.setTransposeSemitones(float(s - 2), 0.0, stream=s)
+        b.setTransposeSemitones(float(s % 5 - 2), 0.0, stream=s)
     whole = b.process(xs, nout)
     assert sharded.shape == whole.shape
     assert np.array_equal(sharded, whole)
+
+
+def test_world_size_8_gloo_per_rank_seeds_match_single_process(emu, tmp_path):
+    """Eight ranks, as BASELINE config 4 shards its 4096 streams (8 x 512, seed of rank r = 512 r: bench.py), here with 3 streams per
+    rank so that the CPU stand-in finishes: every hop runs beyond 2x (1200 -> 3000 samples), where the per-bin time factors come from
+    the stream's random engine -- the gathered shards equal ONE batch of all 24 streams seeded 0 only if every rank seeded its shard
+    with its first global stream index."""
+    sharding = importlib.import_module("signalsmith-stretch_amd.sharding")
+    assert sharding.shard_sizes(4096, 8) == [512]*8 and [sharding.shard_range(4096, r, 8)[0] for r in range(8)] == [512*r for r in range(8)]
+    pkg = package()
+    out = str(tmp_path/"gathered8.npy")
+    total, C, n, nout = 24, 2, 1200, 3000
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1",
+           "--master-port", "29518", os.path.join(ROOT, "tests", "dist_worker.py"), out, str(total), str(n), str(nout)]
+    res = subprocess.run(cmd, env=dict(os.environ, MASTER_ADDR="127.0.0.1", OMP_NUM_THREADS="1"), capture_output=True, text=True, timeout=600)
+    assert res.returncode == 0, res.stderr[-2000:]
+    sharded = np.load(out)
+    xs = np.stack([synth_input(s, C, n, 48000) for s in range(total)])
+    b = pkg.StretchBatch(total, C, block=512, interval=128, lib=emu, seed=0)
+    for s in range(total):
+        b.setTransposeSemitones(float(s % 5 - 2), 0.0, stream=s)
+    whole = b.process(xs, nout)
+    assert sharded.shape == whole.shape and np.array_equal(sharded, whole)
+    # ... and the seeds do matter: the same shard seeded 0 on every rank would not reproduce streams 3..23
+    wrong = pkg.StretchBatch(3, C, block=512, interval=128, lib=emu, seed=0)
+    for i in range(3):
+        wrong.setTransposeSemitones(float((3 + i) % 5 - 2), 0.0, stream=i)
+    assert not np.array_equal(wrong.process(xs[3:6], nout), whole[3:6])
 
 
 def _bench_module():
