@@ -122,8 +122,8 @@ struct SignalsmithStretch {
 	int outputSeekLength(Sample playbackRate) const { return smst_output_seek_length(h(), playbackRate); }
 
 	// The reference's profiling hooks (:211-213, :329-331, :402-404, :420-422): START and END bracket the call as they do there.  The
-	// per-step hooks have no counterpart -- the spectral steps of a call run as kernels over the whole call, not interleaved with
-	// the output samples on the host -- so STEP is reported once (step 0 of 1) and ENDSTEP once, after the device work.
+	// per-step hooks: the spectral steps of a call run as kernels over the whole call, not interleaved with the output samples on the
+	// host -- see process() for what STEP / ENDSTEP report.
 	template <class Inputs, class Outputs>
 	void process(Inputs &&inputs, int inputSamples, Outputs &&outputs, int outputSamples) {
 #ifdef SIGNALSMITH_STRETCH_PROFILE_PROCESS_START
@@ -131,12 +131,25 @@ struct SignalsmithStretch {
 #endif
 		gather(inputs, inputSamples, 0);
 		prepareOut(outputSamples);
+		// The reference announces every step of a block (STEP(step, steps)) and closes it (ENDSTEP), :327-404.  Here a call's device work
+		// is ONE asynchronous submission: it is attributed to step 0, and the block's remaining steps -- counted exactly as the reference
+		// counts them for this block (smst_block_steps) -- are announced after it, so that a harness that sizes its per-step tables from
+		// `steps` (cmd/main-dev.cpp:44-52) sees the reference's step count.
 #ifdef SIGNALSMITH_STRETCH_PROFILE_PROCESS_STEP
-		SIGNALSMITH_STRETCH_PROFILE_PROCESS_STEP(size_t(0), size_t(1));
+		{
+			const int before = smst_block_steps(h());
+			SIGNALSMITH_STRETCH_PROFILE_PROCESS_STEP(size_t(0), size_t(before > 0 ? before : 1));
+		}
 #endif
 		check(smst_process(h(), inPtrs.data(), inputSamples, outPtrs.data(), outputSamples));
 #ifdef SIGNALSMITH_STRETCH_PROFILE_PROCESS_ENDSTEP
 		SIGNALSMITH_STRETCH_PROFILE_PROCESS_ENDSTEP();
+#endif
+#if defined(SIGNALSMITH_STRETCH_PROFILE_PROCESS_STEP) && defined(SIGNALSMITH_STRETCH_PROFILE_PROCESS_ENDSTEP)
+		for (int step = 1, steps = smst_block_steps(h()); step < steps; ++step) {
+			SIGNALSMITH_STRETCH_PROFILE_PROCESS_STEP(size_t(step), size_t(steps));
+			SIGNALSMITH_STRETCH_PROFILE_PROCESS_ENDSTEP();
+		}
 #endif
 		scatter(outputs, outputSamples);
 #ifdef SIGNALSMITH_STRETCH_PROFILE_PROCESS_END

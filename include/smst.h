@@ -104,6 +104,10 @@ int smst_interval_samples(const smst_stretch *h);
 int smst_input_latency(const smst_stretch *h);
 int smst_output_latency(const smst_stretch *h);
 int smst_split_computation(const smst_stretch *h);
+/* Number of processing steps of the newest block (blockProcess.steps, signalsmith-stretch.h:284-318: analysis, spectral processing and
+ * synthesis steps as the reference counts them for this block's flags and channel count); 0 before the first block.  The C++ drop-in
+ * header reports it through the reference's SIGNALSMITH_STRETCH_PROFILE_PROCESS_STEP(step, steps) hook (:329-331). */
+int smst_block_steps(const smst_stretch *h);
 int smst_seek_length(const smst_stretch *h);
 int smst_output_seek_length(const smst_stretch *h, float playbackRate);
 

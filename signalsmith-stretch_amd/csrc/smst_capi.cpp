@@ -374,6 +374,7 @@ STRETCH_Q(smst_interval_samples, e.intervalSamples())
 STRETCH_Q(smst_input_latency, e.inputLatency())
 STRETCH_Q(smst_output_latency, e.outputLatency())
 STRETCH_Q(smst_split_computation, e.splitComputation() ? 1 : 0)
+STRETCH_Q(smst_block_steps, e.lastBlockSteps(0))
 STRETCH_Q(smst_seek_length, e.seekLength())
 int smst_output_seek_length(const smst_stretch *h, float rate) { if (!h || !h->batch) return fail("unconfigured handle"); return h->batch->engine->outputSeekLength(rate); }
 

@@ -155,6 +155,7 @@ void Batch::construct(const FftPlan &plan, long seed) {
 	const Switches sw = Switches::fromEnvironment();
 	overlap = sw.overlap; noFuse = sw.noFuse; noSingleHop = sw.noSingleHop; noAcross = sw.noAcross; checkLaunches = sw.checkLaunches;
 	workspaceGiB = sw.workspaceGiB;
+	subStreamsAsked = sw.subStreams;
 
 	d.S = S; d.C = C; d.B = B; d.I = I; d.M = M; d.N = N; d.L = L; d.T = kTileHops;
 	d.histLen = B + I;
@@ -170,6 +171,7 @@ void Batch::construct(const FftPlan &plan, long seed) {
 	d.debugMode = sw.debugMode;
 	d.noFeedFusion = sw.noFeedFusion;
 	d.noStage = sw.noStage;
+	d.vocNWide = sw.vocNWide;
 	d.noAlign = sw.noAlign;
 	d.alignAll = sw.alignAll;
 	d.noFastFft = sw.noFastFft;
@@ -372,6 +374,7 @@ void Batch::construct(const FftPlan &plan, long seed) {
 
 	allocateWorkspace();
 	pend.assign(S, PendingBlock());
+	lastSteps.assign(S, 0);
 	keepV.assign(S, 0);
 	if (split) { // the block in flight: its spectra, and the tables of the run that completes it (PendingBlock, smst_engine.h)
 		const size_t rows = (size_t)S*C*d.Mp;
@@ -467,6 +470,7 @@ void Batch::allocateWorkspace() {
 	size_t maxStreams = size_t(budgetGiB*1024.0*1024.0*1024.0/double(perStream));
 	if (maxStreams < 1) maxStreams = 1;
 	subS = int(std::min<size_t>(S, maxStreams));
+	if (subStreamsAsked > 0) subS = std::min(subS, subStreamsAsked);
 	for (;;) {
 		const size_t mark = allocations.size();
 		try {
@@ -529,6 +533,7 @@ void Batch::reset() { // signalsmith-stretch.h:49-60
 	resetStreams(nullptr, 1 | 2 | 4 | 8);
 	for (auto &lh : lastHop) lh = LastHop();
 	for (auto &pb : pend) pb = PendingBlock(); // blockProcess = {}
+	std::fill(lastSteps.begin(), lastSteps.end(), 0);
 	d.histCur = 0;
 	d.carryCur = 0;
 	for (auto &sc : sched) {
@@ -1130,6 +1135,7 @@ void Batch::process(const float *in, long long inSS, long long inCS, const int *
 				if (tf > kMaxCleanStretch) flags |= HOP_RANDOM_TF; // :639
 				hd.timeFactor = tf;
 				hd.flags = flags;
+				lastSteps[s] = stepLayout(flags).steps;
 				hd.seed = sc.seed; // the engine's state before this hop's draws
 				if (flags & HOP_RANDOM_TF) sc.seed = unsigned((unsigned long long)sc.seed*lcgHopJump % 2147483647ull); // 2M - 2 draws later
 				if (j == nh) {

@@ -99,6 +99,7 @@ public:
 	void waitForStream(hipStream_t other);
 	void signalStream(hipStream_t other);
 	int subBatchStreams() const { return subS; }
+	int lastBlockSteps(int stream) const { return (stream >= 0 && stream < S) ? lastSteps[stream] : 0; } // blockProcess.steps of the stream's newest block (:284-318)
 	// the object is copyable in the reference (a plain struct, signalsmith-stretch.h:34-35): same geometry required; every piece of
 	// carried state, the parameters and the scheduler state of `other` replace this batch's
 	void copyStateFrom(Batch &other);
@@ -142,6 +143,7 @@ private:
 	struct TileBuffers { float2 *Xcur, *Xprev, *OUT, *dump, *map, *peaksT; float4 *REC; PredEntry *PE; float *ratio, *energyT, *smoothT, *est, *freqEst, *frames; } slots[2]{};
 	bool overlap = true, noFuse = false, noSingleHop = false, noAcross = false; // (smst_switches.h)
 	double workspaceGiB = 0;
+	int subStreamsAsked = 0;
 	int subS = 0;
 	// per-call host scratch, kept between calls (no heap traffic in steady state); growth events are counted
 	std::vector<int> hopFirst, hopCount, maxSpanV;
@@ -156,6 +158,7 @@ private:
 	std::vector<StreamParams> params;
 	bool paramsDirty = true;
 	// ---- split computation: the block in flight (see PendingBlock) ----
+	std::vector<int> lastSteps;
 	std::vector<PendingBlock> pend;
 	float2 *dPendIn = nullptr, *dPendPrev = nullptr; // its spectra, [S][C][Mp]: Band.input and (re-analysed) Band.prevInput
 	struct PendSet { // tables of one run of blocks in flight (double-buffered like CallSet: pinned staging, asynchronous uploads)

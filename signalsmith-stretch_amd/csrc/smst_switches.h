@@ -19,8 +19,11 @@
 //   SMST_FEED_SERIAL       unset    set: bin-by-bin feed recurrences (kFeedSerial) instead of the scan form
 //   SMST_FFT_TEAMS         1        0: one frame per workgroup; 2: persistent teams even for tiles with few frames per team (tests)
 //   SMST_SYNTH_EMIT        1        0: kSynthTeams + kEmit; 2: kSynthEmitTeams also for small tiles (tests)
+//   SMST_VOCN_WIDE         1        0: kVocoderN's producer passes 16 rows x 4 steps (the first form) instead of 8 rows x 8 steps
 //   SMST_DEBUG_MODE        0        timing experiments; only in builds with -DSMST_EXPERIMENTS
 //   SMST_WORKSPACE_GIB     auto     tile workspace budget per workspace in GiB (a tuning knob, not a cross-check: always read)
+//   SMST_SUB_STREAMS       auto     streams per sub-batch, if smaller than what the budget allows (the same kind of knob: sub-batches alternate between the
+//                                   two tile workspaces, so the bulk kernels of one overlap the recurrence of the other)
 #pragma once
 #include <cstdlib>
 #include <string>
@@ -29,13 +32,15 @@ namespace smst {
 
 struct Switches {
 	bool overlap = true, noFuse = false, noSingleHop = false, noAcross = false, checkLaunches = false;
-	int noFeedFusion = 0, fftTeams = 1, synthEmit = 1, debugMode = 0;
+	int noFeedFusion = 0, fftTeams = 1, synthEmit = 1, debugMode = 0, vocNWide = 1;
 	bool noStage = false, noAlign = false, alignAll = false, noFastFft = false, fftLean = false, feedSerial = false;
 	double workspaceGiB = 0; // 0: automatic
+	int subStreams = 0;      // 0: automatic
 
 	static Switches fromEnvironment() {
 		Switches s;
 		if (const char *env = std::getenv("SMST_WORKSPACE_GIB")) s.workspaceGiB = atof(env);
+		if (const char *env = std::getenv("SMST_SUB_STREAMS")) s.subStreams = atoi(env);
 #ifndef SMST_NO_SWITCHES
 		auto set = [](const char *name) { return std::getenv(name) != nullptr; };
 		auto num = [](const char *name, int fallback) { const char *env = std::getenv(name); return env ? atoi(env) : fallback; };
@@ -53,6 +58,7 @@ struct Switches {
 		s.feedSerial = set("SMST_FEED_SERIAL");
 		s.fftTeams = num("SMST_FFT_TEAMS", 1);
 		s.synthEmit = num("SMST_SYNTH_EMIT", 1);
+		s.vocNWide = num("SMST_VOCN_WIDE", 1);
 #ifdef SMST_EXPERIMENTS
 		s.debugMode = num("SMST_DEBUG_MODE", 0);
 #endif

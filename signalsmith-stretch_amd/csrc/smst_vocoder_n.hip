@@ -219,6 +219,7 @@ __global__ __launch_bounds__(64*kVocWaves) __attribute__((amdgpu_waves_per_eu(4,
 	constexpr int NP = kVocWaves - 2;
 	constexpr int lag = L + 1;
 	static_assert(CH >= 3 && CH <= kMaxChannels && L >= 1 && L + BS < R, "ring depth: a slot is rewritten R bins later, the oldest tap is L bins back");
+	static_assert(NB == 2, "the wide producer passes fill both blocks of the ring");
 	extern __shared__ __attribute__((aligned(16))) unsigned char smemRaw[];
 	float4 *recs = reinterpret_cast<float4 *>(smemRaw);                  // [(slot*BS + st)*NCH + j][64 lanes]
 	float2 *ring = reinterpret_cast<float2 *>(recs + NB*BS*NCH*64);      // [CH][R bins][64 lanes]: Band.output of the last R bins of every hop
@@ -279,8 +280,39 @@ __global__ __launch_bounds__(64*kVocWaves) __attribute__((amdgpu_waves_per_eu(4,
 			}
 			return;
 		}
-		// ---------------- producers: 16 rows x 4 steps per wave-pass
+		// ---------------- producers: a wave-pass computes 64 records.  Two shapes: 16 rows x 4 steps (one block: the first form), or
+		// 8 rows x 8 steps (BOTH blocks of the ring).  A record's operands are row segments around its bin -- 8 channels x (P, E), the previous
+		// hop's energies, prevInput pairs, the maximum channel's vertical taps -- and the kernel lives on the rate at which a CU's L1 takes
+		// in the lines they lie on (EXPERIMENTS.md 4.12: ~1300 half-used lines per 4-step block): with 8 consecutive bins of a row in ONE
+		// load instruction a line is asked for once where two passes of 4 bins asked twice, a block apart.  Same records either way.
 		const int pIndex = wave - 1 - (wave > 4);
+		if (d.vocNWide) {
+			constexpr int PS = 2*BS, PR = 64/PS, PASSES = 64/PR; // 8 steps x 8 rows; 8 passes per pair of blocks
+			const int st8 = k & (PS - 1), r = k/PS;
+			const int half = st8/BS, st = st8 & (BS - 1);
+			for (int u = pIndex; u < (totalBlocks/2)*PASSES; u += NP) {
+				const int pair = u/PASSES, it = u - pair*PASSES;
+				const int row = PR*it + r;
+				const int b = PS*pair + st8 - lag*row;
+				float f[NCH*4];
+#pragma unroll
+				for (int j = 0; j < NCH*4; ++j) f[j] = 0.0f;
+				if (row < nh && b >= 0 && b < M && !SMST_SKIP_PRODUCER_MATH(d)) computeRecord<CH, PLAIN, false, false>(d, hopsLds[row], hopsLds[row > 0 ? row - 1 : 0], s, sg, row, b, f);
+#pragma unroll
+				for (int h = 0; h < 2; ++h) { // block 2*pair + h lives in slot h (NB == 2)
+					const int n = 2*pair + h;
+					while (n - ldsPeek(&sync[NB]) >= NB) __builtin_amdgcn_s_sleep(2); // slot still being read
+					asm volatile("" ::: "memory");
+					if (half == h) {
+#pragma unroll
+						for (int j = 0; j < NCH; ++j) recs[((h*BS + st)*NCH + j)*64 + ((row + st) & 63)] = make_float4(f[4*j], f[4*j + 1], f[4*j + 2], f[4*j + 3]);
+					}
+					asm volatile("" ::: "memory");
+					if (k == 0) ldsCount(&sync[h]); // LDS ops of a wave are in order: data first, then the count
+				}
+			}
+			return;
+		}
 		const int st = k & (BS - 1), r = k/BS;
 		constexpr int ROWS = 64/BS, UNITS = 64/ROWS; // passes per block
 		for (int u = pIndex; u < totalBlocks*UNITS; u += NP) {
@@ -312,7 +344,7 @@ __global__ __launch_bounds__(64*kVocWaves) __attribute__((amdgpu_waves_per_eu(4,
 	float2 pf[CH], own1[CH];
 #pragma unroll
 	for (int c = 0; c < CH; ++c) { pf[c] = make_float2(0.f, 0.f); own1[c] = make_float2(0.f, 0.f); }
-	constexpr int UNITS = BS;
+	const int UNITS = d.vocNWide ? 2*BS : BS; // producer passes that make up a block
 	for (int ch = 0; ch < chunks; ++ch) {
 		const int tb = ch << 6;
 		if (ch > 0) {
