@@ -177,6 +177,8 @@ int smst_batch_seek(smst_batch *b, const float *in, long long inStreamStride, lo
 int smst_batch_process(smst_batch *b, const float *in, long long inStreamStride, long long inChannelStride,
                        const int *inSamples, float *out, long long outStreamStride, long long outChannelStride,
                        const int *outSamples, int memory);
+/* flush(): per stream as signalsmith-stretch.h:427-464 (the stream's output ring is read out and the stream starts afresh).  A NEGATIVE
+ * outSamples[s] leaves stream s out of the call altogether -- a count of 0 still resets it, as flush(outputs, 0) of an instance does. */
 int smst_batch_flush(smst_batch *b, float *out, long long outStreamStride, long long outChannelStride,
                      const int *outSamples, const float *playbackRates, int memory);
 int smst_batch_output_seek(smst_batch *b, const float *in, long long inStreamStride, long long inChannelStride,

@@ -350,6 +350,7 @@ class StretchBatch:
         _check(self.lib, self.lib.smst_batch_seek(self.h, ptr, ss, cs, pin, r.ctypes.data_as(_dp), mem))
 
     def flush(self, out_samples, rates=0.0, like=None):
+        """flush() of every stream with a non-negative count; a negative count leaves that stream alone (include/smst.h)"""
         S, Cn = self.streams, self.channels
         nout, pout = _int_array(out_samples, S)
         r = np.ascontiguousarray(np.broadcast_to(np.asarray(rates, dtype=np.float32), (S,)))

@@ -244,14 +244,20 @@ int smst_batch_process(smst_batch *b, const float *in, long long iss, long long 
 int smst_batch_flush(smst_batch *b, float *out, long long oss, long long ocs, const int *outSamples, const float *rates, int memory) {
 	BATCH_CALL({
 		if (!outSamples) throw smst::Error("null sample counts");
+		Batch &e = *b->engine;
+		// a NEGATIVE count leaves that stream out of the flush (flush() of an instance also resets it, :456-463: a count of 0 would do that)
+		std::vector<unsigned char> active(e.streams(), 1);
+		std::vector<int> counts(outSamples, outSamples + e.streams());
+		bool all = true;
+		for (int s = 0; s < e.streams(); ++s) if (counts[s] < 0) { active[s] = 0; counts[s] = 0; all = false; }
+		const unsigned char *mask = all ? nullptr : active.data();
 		if (memory == SMST_MEM_DEVICE) {
-			b->engine->flush(out, oss, ocs, outSamples, rates);
+			e.flush(out, oss, ocs, counts.data(), rates, mask);
 		} else {
-			Batch &e = *b->engine;
-			const int maxOut = maxOf(outSamples, e.streams());
+			const int maxOut = maxOf(counts.data(), e.streams());
 			ensureStage(b->dOut, b->outCap, (size_t)e.streams()*e.channels()*maxOut, e.device(), b->stagingAllocs);
-			e.flush(b->dOut, (long long)e.channels()*maxOut, maxOut, outSamples, rates);
-			unstageOut(b, out, oss, ocs, outSamples, maxOut);
+			e.flush(b->dOut, (long long)e.channels()*maxOut, maxOut, counts.data(), rates, mask);
+			unstageOut(b, out, oss, ocs, counts.data(), maxOut);
 		}
 	})
 }

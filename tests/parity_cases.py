@@ -1284,6 +1284,99 @@ def case_split_events_vs_checker(lib, ref, channels=3, cfg=SMALL_SPLIT):
     return {k: "%.1e" % v for k, v in figures.items()}
 
 
+def case_split_batch_events(lib, monkeypatch=None, streams=5, channels=2, cfg=SMALL_SPLIT):
+    """Split computation in a BATCH: every stream sits at another offset inside its interval (ragged per-stream sample counts), parameter
+    changes hit single streams, a flush() takes some streams (negative counts leave the others alone) -- and every stream of the batch
+    stays bit-identical to the same stream driven alone through the single-stream handle; then a clone taken between two interval
+    boundaries (the block in flight and its spectra travel with it) continues exactly as the original."""
+    pkg = package()
+    sr = 48000
+    kw = dict(block=cfg["block"], interval=cfg["interval"], split=True)
+    I = cfg["interval"]
+    n_total = 40*I
+    xs = np.stack([synth_input(s, channels, n_total, sr) + 0.2*synth_input(s + 3, channels, n_total, sr) for s in range(streams)])
+    rng = np.random.default_rng(7)
+    # a script of calls: per stream (n_in, n_out) for process, or a flush length (negative: not part of it), or a setter
+    script = []
+    for call in range(9):
+        script.append(("process", [(int(rng.integers(40, 400)), int(rng.integers(40, 500))) for _ in range(streams)]))
+        if call == 2:
+            script.append(("transpose", 1, 5.0))
+        if call == 4:
+            script.append(("flush", [int(rng.integers(1, 200)) if s % 2 == 0 else -1 for s in range(streams)]))
+        if call == 5:
+            script.append(("formant", 3, 1.15))
+            script.append(("transpose", 0, -3.0))
+        if call == 7:
+            script.append(("flush", [int(rng.integers(100, 300)) if s % 2 == 1 else -1 for s in range(streams)]))
+
+    def run_batch():
+        b = pkg.StretchBatch(streams, channels, lib=lib, **kw)
+        pos = [0]*streams
+        outs = [[] for _ in range(streams)]
+        for step in script:
+            if step[0] == "process":
+                nin = np.array([c[0] for c in step[1]], np.int32)
+                nout = np.array([c[1] for c in step[1]], np.int32)
+                x = np.zeros((streams, channels, int(nin.max())), np.float32)
+                for s in range(streams):
+                    x[s, :, :nin[s]] = xs[s][:, pos[s]:pos[s] + nin[s]]
+                    pos[s] += int(nin[s])
+                y = np.array(b.process(x, nout, in_samples=nin), copy=True)
+                for s in range(streams):
+                    outs[s].append(y[s][:, :nout[s]])
+            elif step[0] == "flush":
+                y = np.array(b.flush(np.array(step[1], np.int32)), copy=True)
+                for s in range(streams):
+                    if step[1][s] >= 0:
+                        outs[s].append(y[s][:, :step[1][s]])
+            elif step[0] == "transpose":
+                b.setTransposeSemitones(step[2], 0.0, stream=step[1])
+            else:
+                b.setFormantFactor(step[2], True, stream=step[1])
+        b.close()
+        return [np.concatenate(o, axis=1) for o in outs]
+
+    def run_single(s):
+        g = pkg.SignalsmithStretch(seed=s, lib=lib)  # stream s of a batch carries the engine seeded seed + s
+        g.configure(channels, cfg["block"], cfg["interval"], True)
+        pos, outs = 0, []
+        for step in script:
+            if step[0] == "process":
+                nin, nout = step[1][s]
+                outs.append(np.asarray(g.process(xs[s][:, pos:pos + nin], nout)))
+                pos += nin
+            elif step[0] == "flush":
+                if step[1][s] >= 0:
+                    outs.append(np.asarray(g.flush(step[1][s])))
+            elif step[0] == "transpose":
+                if step[1] == s:
+                    g.setTransposeSemitones(step[2], 0.0)
+            elif step[1] == s:
+                g.setFormantFactor(step[2], True)
+        return np.concatenate(outs, axis=1)
+
+    batch = run_batch()
+    for s in range(streams):
+        single = run_single(s)
+        assert batch[s].shape == single.shape and np.abs(single).max() > 0.01
+        assert np.array_equal(batch[s], single), ("stream %d of the batch differs from the same stream alone" % s, float(np.abs(batch[s] - single).max()))
+    if monkeypatch is not None:  # two streams per sub-batch: the blocks in flight of a call run per sub-batch
+        monkeypatch.setenv("SMST_SUB_STREAMS", "2")
+        again = run_batch()
+        monkeypatch.delenv("SMST_SUB_STREAMS", raising=False)
+        assert all(np.array_equal(a, b) for a, b in zip(again, batch))
+    # clone between two interval boundaries
+    g = pkg.SignalsmithStretch(seed=0, lib=lib)
+    g.configure(channels, cfg["block"], cfg["interval"], True)
+    g.setTransposeSemitones(4.0, 0.0)
+    g.process(xs[0][:, :1500], 11*I + 37)
+    twin = g.clone()
+    a = np.concatenate([np.asarray(g.process(xs[0][:, 1500:1600], 50)), np.asarray(g.flush(60)), np.asarray(g.process(xs[0][:, 1600:2600], 1000))], axis=1)
+    b = np.concatenate([np.asarray(twin.process(xs[0][:, 1500:1600], 50)), np.asarray(twin.flush(60)), np.asarray(twin.process(xs[0][:, 1600:2600], 1000))], axis=1)
+    assert np.array_equal(a, b) and np.abs(a).max() > 0.01
+
+
 def case_across_equals_single_hop(lib, monkeypatch, streams=21, channel_counts=(1, 2), setup=None):
     """Single-hop tiles, mono / stereo: the recurrence runs with its lanes across STREAMS (kVocoder ACROSS); SMST_NO_ACROSS=1 runs
     one chain per stream (kVocoderOne).  Same records, same arithmetic: bit-identical, for a stream count that is no multiple of

@@ -197,3 +197,8 @@ def test_hop_magnitudes_per_stream_parameters_small(emu, ref):
 
 def test_reconfigure_keeps_random_engine(emu, ref):
     pc.case_reconfigure_keeps_random_engine(emu, ref)
+
+
+def test_split_batch_events_emu(emu, monkeypatch):
+    """split computation in a batch: streams at different offsets of their intervals, per-stream setters and flushes == every stream alone"""
+    pc.case_split_batch_events(emu, monkeypatch)

@@ -667,3 +667,8 @@ def test_fft_teams_equals_per_frame(hip, monkeypatch):
     """kAnalyseTeams (SMST_FFT_TEAMS=1) against kAnalyseFast: bit-identical."""
     pc.case_fft_teams_equals_per_frame(hip, monkeypatch, presets=(("cheaper", 48000), ("default", 48000), ("default", 44100)), streams=5)
     pc.case_fft_teams_equals_per_frame(hip, monkeypatch, presets=(("default", 48000),), streams=2, channels=1)
+
+
+def test_split_batch_events(hip, monkeypatch):
+    """split computation in a batch: streams at different offsets of their intervals, per-stream setters and flushes == every stream alone"""
+    pc.case_split_batch_events(hip, monkeypatch)

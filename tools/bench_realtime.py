@@ -4,6 +4,7 @@
 Prints one JSON object: per batch size the median / p99 time per quantum and how many streams that sustains in real time.
 This pattern is bound by kernel launches and the per-call host scheduling, not by the kernels."""
 import argparse, importlib, json, os, sys, time
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # the engine's pipeline streams get hardware queues of their own (INTEGRATION.md); before the HIP runtime starts
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 

@@ -8,6 +8,7 @@ import json
 import os
 import sys
 import time
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")  # the engine's pipeline streams get hardware queues of their own; before the HIP runtime starts
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
