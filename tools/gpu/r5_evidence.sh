@@ -52,8 +52,10 @@ timeout 400 python tools/bench_sweep.py > $OUT/stream_sweep.json 2> $OUT/stream_
 timeout 400 python tools/bench_presets.py > $OUT/presets.json 2> $OUT/presets.err
 timeout 400 python tools/bench_realtime.py > $OUT/realtime_quanta.json 2> $OUT/realtime.err
 timeout 400 python tools/bench_realtime.py --preset cheaper > $OUT/realtime_quanta_cheaper_split.json 2> $OUT/realtime_cheaper.err
-find $OUT -name "*_kernel_trace.csv" -size +8M -delete
-find $OUT -name "*_counter_collection.csv" -size +16M -delete
+# what travels back is bounded (64 MiB): counter files shrink to one row per (kernel, counter), kernel traces of the counter passes go
+for f in $(find $OUT -name "*_counter_collection.csv"); do python3 $ROOT/tools/prof/reduce_counters.py $f; done
+find $OUT -path "*prof_c*" -name "*_kernel_trace.csv" -delete
+find $OUT -name "*_agent_info.csv" -delete
 cat $OUT/prof_c5/outcomes.txt
 fi
 du -sh $OUT
