@@ -274,12 +274,15 @@ def pin_rank_to_numa_node(local_rank, world, share_index=None, strict=True):
         if os.path.exists(path):
             node = int(open(path).read().strip())
     report["numa_node"] = node
-    if pci is None or node is None:
+    if pci is None:
         if strict:
-            raise SystemExit("bench: cannot read the PCI address / NUMA node of device %d (pci %r): refusing to run %d ranks unpinned "
-                             "(--no-numa-pinning to run them where the launcher put them)" % (local_rank, pci, world))
+            raise SystemExit("bench: cannot read the PCI address of device %d: refusing to run %d ranks unpinned "
+                             "(--no-numa-pinning to run them where the launcher put them)" % (local_rank, world))
         report["cpus"] = cpu_ranges(os.sched_getaffinity(0))
         return report
+    if node is None:  # the address is known, sysfs does not say which node it hangs off (some containers hide it): say so, and still give every rank CPUs of its own
+        print("bench: /sys/bus/pci/devices/%s/numa_node is not readable: rank on device %d gets its share of ALL CPUs instead of its NUMA node's" % (pci, local_rank), file=sys.stderr)
+        node = -1
     cpus = sorted(os.sched_getaffinity(0))
     if node >= 0:  # (-1: the platform has a single node / does not say: the whole affinity mask)
         node_cpus = set()

@@ -108,3 +108,27 @@ def test_bench_refuses_world_size_mismatch():
     env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
     res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], capture_output=True, text=True, timeout=300, env=env)
     assert res.returncode != 0 and "WORLD_SIZE (1) != --gpus (2)" in res.stderr
+
+
+def test_numa_pinning_is_loud(monkeypatch):
+    """Every rank says where its host scheduler runs; a device whose PCI address cannot be read stops a multi-GPU run (eight ranks silently
+    on rank 0's CPUs would look like bad scaling); a readable address without a NUMA node in sysfs still gives every rank CPUs of its own."""
+    import pytest
+    bench = _bench_module()
+    assert bench.cpu_ranges([0, 1, 2, 3, 8, 9, 11]) == "0-3,8-9,11"
+    before = os.sched_getaffinity(0)
+    try:
+        monkeypatch.setattr(bench, "device_pci_address", lambda i: None)
+        with pytest.raises(SystemExit) as e:
+            bench.pin_rank_to_numa_node(1, 4, strict=True)
+        assert "PCI address" in str(e.value)
+        relaxed = bench.pin_rank_to_numa_node(1, 4, strict=False)
+        assert relaxed["pinned"] is False and relaxed["cpus"]
+        if len(before) >= 4:
+            monkeypatch.setattr(bench, "device_pci_address", lambda i: "0000:ff:1f.0")  # no such device in sysfs: the node is unknown
+            a = bench.pin_rank_to_numa_node(0, 4, strict=True)
+            os.sched_setaffinity(0, before)
+            b = bench.pin_rank_to_numa_node(1, 4, strict=True)
+            assert a["pinned"] and b["pinned"] and a["cpus"] != b["cpus"] and a["pci"] == "0000:ff:1f.0"
+    finally:
+        os.sched_setaffinity(0, before)
