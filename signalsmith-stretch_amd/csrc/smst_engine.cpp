@@ -532,14 +532,14 @@ void Batch::reset() { // signalsmith-stretch.h:49-60
 	SMST_HIP(hipMemsetAsync(d.stFreq, 0, (size_t)S*2*sizeof(float), st));
 	resetStreams(nullptr, 1 | 2 | 4 | 8);
 	for (auto &lh : lastHop) lh = LastHop();
-	for (auto &pb : pend) pb = PendingBlock(); // blockProcess = {}
 	std::fill(lastSteps.begin(), lastSteps.end(), 0);
 	d.histCur = 0;
 	d.carryCur = 0;
-	for (auto &sc : sched) {
-		const unsigned seed = sc.seed; // reset() leaves the reference's randomEngine alone
-		sc = StreamSched();
-		sc.seed = seed;
+	for (int s = 0; s < S; ++s) {
+		const unsigned seed = seedAfterDroppedBlock(s); // reset() leaves the reference's randomEngine alone; a block in flight is dropped with the draws it has made
+		pend[s] = PendingBlock(); // blockProcess = {}
+		sched[s] = StreamSched();
+		sched[s].seed = seed;
 	}
 }
 
@@ -725,6 +725,32 @@ size_t Batch::stepsExecuted(size_t steps, size_t k) const { // after k samples o
 	const float processRatio = float(k)/float(size_t(I));
 	return std::min<size_t>(steps, size_t((float(steps) + 0.999f)*processRatio));
 }
+// The random engine and the block in flight (:616, :749, :769): a block beyond 2x draws its 2M - 2 time factors inside the chunks of the main
+// prediction, in bin order, WHEN those chunks run.  So the stream's engine moves on by a whole block when the block in flight finally runs, and
+// -- if reset(), a silent call or configure() drops it (blockProcess = {}) -- by the draws of the chunks that had run by then only.
+static unsigned lcgPower(unsigned long long n) { // 16807^n mod (2^31 - 1)
+	unsigned long long r = 1, b = 16807;
+	const unsigned long long m = 2147483647ull;
+	while (n) {
+		if (n & 1) r = r*b % m;
+		b = b*b % m;
+		n >>= 1;
+	}
+	return unsigned(r);
+}
+unsigned Batch::seedAfterDroppedBlock(int s) const {
+	const PendingBlock &pb = pend[s];
+	const unsigned seed = sched[s].seed;
+	if (!split || !pb.valid || !(pb.flags & HOP_RANDOM_TF)) return seed;
+	const StepLayout l = stepLayout(pb.flags);
+	const size_t e = stepsExecuted(size_t(l.steps), sched[s].samplesSinceLast);
+	const size_t chunks = e > size_t(l.main0) ? std::min<size_t>(8, e - size_t(l.main0)) : 0;
+	const size_t b0 = size_t(M)*chunks/8; // bins [0, b0) have drawn: one draw per bin for b > 0, one for b < M - 1
+	if (b0 == 0) return seed;
+	const unsigned long long draws = (b0 >= size_t(M)) ? 2ull*M - 2 : 2ull*b0 - 1;
+	return unsigned((unsigned long long)seed*lcgPower(draws) % 2147483647ull);
+}
+
 // A setter is about to change params[s]: the steps of the block in flight that have already run saw the OLD values (:874, :982, :1020)
 void Batch::freezePendingParams(int s) {
 	if (!split) return;
@@ -821,7 +847,10 @@ void Batch::runPendingBlocks(const int *synthChannels) {
 	}
 	SMST_HIP(hipEventRecord(ps.done, st));
 	ps.used = true;
-	for (int s : pendList) pend[s] = PendingBlock();
+	for (int s : pendList) {
+		if (pend[s].flags & HOP_RANDOM_TF) sched[s].seed = unsigned((unsigned long long)sched[s].seed*lcgHopJump % 2147483647ull); // its draws happen now
+		pend[s] = PendingBlock();
+	}
 	pendList.clear();
 }
 
@@ -992,8 +1021,9 @@ void Batch::process(const float *in, long long inSS, long long inCS, const int *
 			if (sc.silenceCounter >= size_t(2*B)) {
 				if (sc.silenceFirst) {
 					sc.silenceFirst = false;
+					sc.seed = seedAfterDroppedBlock(s); // ... which drops the block in flight, with the draws it has made
 					sc.samplesSinceLast = SIZE_MAX; // blockProcess = {}
-					pend[s] = PendingBlock();       // ... which drops the block in flight
+					pend[s] = PendingBlock();
 					clearBits[s] = 2 | 4 | 8;       // Band.input / .prevInput / .output := 0
 					anyClear = true;
 				}
@@ -1103,6 +1133,7 @@ void Batch::process(const float *in, long long inSS, long long inCS, const int *
 			hd.inSrc = nw ? 0 : SRC_STATE;
 			hd.prevSrc = (nw && (pb.flags & HOP_REANALYSE_PREV)) ? SRC_REANALYSED : SRC_STATE;
 			if (nw) lastNew = 0;
+			if (pb.flags & HOP_RANDOM_TF) sched[s].seed = unsigned((unsigned long long)sched[s].seed*lcgHopJump % 2147483647ull); // its draws happen now
 			pend[s] = PendingBlock();
 		}
 		if (nStart > rides) {
@@ -1137,7 +1168,7 @@ void Batch::process(const float *in, long long inSS, long long inCS, const int *
 				hd.flags = flags;
 				lastSteps[s] = stepLayout(flags).steps;
 				hd.seed = sc.seed; // the engine's state before this hop's draws
-				if (flags & HOP_RANDOM_TF) sc.seed = unsigned((unsigned long long)sc.seed*lcgHopJump % 2147483647ull); // 2M - 2 draws later
+				if ((flags & HOP_RANDOM_TF) && j < nh) sc.seed = unsigned((unsigned long long)sc.seed*lcgHopJump % 2147483647ull); // 2M - 2 draws later (a block left in flight draws when it runs: seedAfterDroppedBlock)
 				if (j == nh) {
 					// in flight at the end of the call: analysed now, from the input as it stands (:293 stashes it), into the pending buffers;
 					// everything else when its interval is complete -- or when a flush() needs to know how far it has come
@@ -1474,7 +1505,7 @@ void Batch::inheritAcrossConfigure(Batch &o) {
 	for (int s = 0; s < S; ++s) {
 		const StreamSched &from = o.sched[s];
 		StreamSched &to = sched[s];
-		to.seed = from.seed;
+		to.seed = o.seedAfterDroppedBlock(s); // (configure() drops a block in flight: blockProcess = {}, :89)
 		to.prevInputOffset = from.prevInputOffset;
 		to.didSeek = from.didSeek;
 		to.seekTimeFactor = from.seekTimeFactor;

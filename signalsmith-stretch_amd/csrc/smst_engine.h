@@ -174,6 +174,7 @@ private:
 	StepLayout stepLayout(unsigned flags) const;
 	size_t stepsExecuted(size_t steps, size_t samplesIntoInterval) const;
 	void freezePendingParams(int s);   // before a setter changes params[s]
+	unsigned seedAfterDroppedBlock(int s) const; // the random engine once the block in flight is dropped (reset / silence / configure)
 	void runPendingBlocks(const int *synthChannels); // runs the blocks of `pendList` (a tile of one hop per stream; no input, no output samples)
 	struct TileRun { const IoArgs *io; int nTiles, maxHops; const unsigned char *tileHas; const int *maxSpan; const int *dTileInfo; bool pendingRun; const int *dSynthChannels; };
 	void runTiles(const TileRun &run);

@@ -1284,6 +1284,31 @@ def case_split_events_vs_checker(lib, ref, channels=3, cfg=SMALL_SPLIT):
     return {k: "%.1e" % v for k, v in figures.items()}
 
 
+def case_split_dropped_block_random_engine(lib, ref, cfg=SMALL_SPLIT):
+    """Beyond 2x a block draws its 2M - 2 time factors from the stream's random engine INSIDE the chunks of its main prediction (stretch.h:749,
+    :769), in bin order, when those chunks run.  In split mode a reset() between two interval boundaries drops the block in flight
+    (blockProcess = {}, :58): the engine has then moved on by the draws of the chunks that had run -- none early in the interval, all of
+    them late -- and every later random factor depends on that.  (Found by the API fuzz, walk 218: the product had advanced the engine by
+    the whole block when the block STARTED.)  Offsets before, inside and behind the main prediction of a 20-step stereo block."""
+    C, sr = 2, 48000
+    x = synth_input(0, C, 9000, sr) + 0.3*synth_input(3, C, 9000, sr)
+    I = cfg["interval"]
+    figures = {}
+    for off in (3, 40, 54, 55, 70, 90, 108, 109, 120, 127):
+        def play(o, off=off):
+            n1 = int((9*I + off)/2.6)
+            outs = [o.process(x[:, :n1], 9*I + off)]           # 2.6x: every hop draws
+            o.reset()
+            outs.append(o.process(x[:, n1:n1 + 800], 2100))    # ... and so does every hop after the reset
+            return np.concatenate([np.asarray(v) for v in outs], axis=1)
+        g, r = make("product", lib, ref, C, cfg, seed=5), make("ref", lib, ref, C, cfg, seed=5)
+        y, o = play(g), play(r)
+        tail = slice(9*I + off, None)
+        figures[off] = rel_rms(y[:, tail], o[:, tail])
+        assert figures[off] < 1e-4, ("reset with a randomised block in flight at offset %d" % off, figures)
+    return {k: "%.1e" % v for k, v in figures.items()}
+
+
 def case_split_batch_events(lib, monkeypatch=None, streams=5, channels=2, cfg=SMALL_SPLIT):
     """Split computation in a BATCH: every stream sits at another offset inside its interval (ragged per-stream sample counts), parameter
     changes hit single streams, a flush() takes some streams (negative counts leave the others alone) -- and every stream of the batch

@@ -202,3 +202,7 @@ def test_reconfigure_keeps_random_engine(emu, ref):
 def test_split_batch_events_emu(emu, monkeypatch):
     """split computation in a batch: streams at different offsets of their intervals, per-stream setters and flushes == every stream alone"""
     pc.case_split_batch_events(emu, monkeypatch)
+
+
+def test_split_dropped_block_random_engine_emu(emu, ref):
+    print(pc.case_split_dropped_block_random_engine(emu, ref))

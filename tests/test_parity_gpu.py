@@ -672,3 +672,7 @@ def test_fft_teams_equals_per_frame(hip, monkeypatch):
 def test_split_batch_events(hip, monkeypatch):
     """split computation in a batch: streams at different offsets of their intervals, per-stream setters and flushes == every stream alone"""
     pc.case_split_batch_events(hip, monkeypatch)
+
+
+def test_split_dropped_block_random_engine(hip, ref):
+    print(pc.case_split_dropped_block_random_engine(hip, ref))
