@@ -206,3 +206,9 @@ def test_split_batch_events_emu(emu, monkeypatch):
 
 def test_split_dropped_block_random_engine_emu(emu, ref):
     print(pc.case_split_dropped_block_random_engine(emu, ref))
+
+
+def test_api_surface_and_realtime_quanta_split_emu(emu, ref):
+    """seek / ragged chunks / flush / outputSeek / exact and the AudioWorklet calling patterns in split-computation mode"""
+    pc.case_api_surface(emu, ref, cfg=pc.SMALL_SPLIT)
+    pc.case_realtime_quanta(emu, ref, cfg=pc.SMALL_SPLIT)

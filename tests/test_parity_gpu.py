@@ -676,3 +676,9 @@ def test_split_batch_events(hip, monkeypatch):
 
 def test_split_dropped_block_random_engine(hip, ref):
     print(pc.case_split_dropped_block_random_engine(hip, ref))
+
+
+def test_api_surface_and_realtime_quanta_split(hip, ref):
+    """seek / ragged chunks / flush / outputSeek / exact and the AudioWorklet calling patterns in split-computation mode"""
+    pc.case_api_surface(hip, ref, cfg=pc.SMALL_SPLIT)
+    pc.case_realtime_quanta(hip, ref, cfg=pc.SMALL_SPLIT)
