@@ -1064,7 +1064,11 @@ void Batch::process(const float *in, long long inSS, long long inCS, const int *
 	}
 	if (!pendList.empty()) runPendingBlocks(nullptr);
 	const int nTiles = std::max(1, (maxHops + T - 1)/T);
-	const int hopStride = nTiles*T;
+	// One row of T hop descriptors per stream and tile -- except in the real-time calling pattern, where no stream fires more than one hop per
+	// call: the single-hop kernels index hop 0 only, so a row is ONE descriptor (4096 streams: 131 KB to clear and upload per 128-frame
+	// quantum instead of 8.4 MB -- a third of the quantum's cost).  (The wavefront kernels load a row of 64 blindly: they keep the full rows.)
+	const bool compactHops = maxHops <= 1 && singleHopSupported(d) && !noSingleHop && fusedSupported(d) && !noFuse;
+	const int hopStride = compactHops ? 1 : nTiles*T;
 	const int nSub = (S + subS - 1)/subS;
 
 	// per-call tables: pinned staging and device copies grow only when a call needs more hops than any earlier call -- and
