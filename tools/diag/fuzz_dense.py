@@ -1,6 +1,6 @@
 """Dense API fuzz: 60 calls per walk with an event (setter / flush / seek / reset / output-only / input-only call) in every second one, short
 process() calls (1 .. 150 samples) so that most events fall BETWEEN interval boundaries; product against oracle/_ref with the horizon-aware bound of
-tests/parity_cases.py.  usage: python tools/diag/fuzz_dense.py <first seed> <last seed + 1> split|plain   (SMST_FUZZ_EMU=1: the CPU stand-in)"""
+tests/parity_cases.py.  usage: python tools/diag/fuzz_dense.py <first seed> <last seed + 1> split|plain|cheaper48   (SMST_FUZZ_EMU=1: the CPU stand-in)"""
 import sys, ctypes, numpy as np
 import os
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -10,20 +10,21 @@ pkg = importlib.import_module("signalsmith-stretch_amd")
 import ref_oracle, parity_cases as pc
 from conftest import synth_input
 lib = pkg.bind(ctypes.CDLL(os.path.join(ROOT, "tests", "emu", "libsmst_emu.so"))) if os.environ.get("SMST_FUZZ_EMU") else pkg.load_library()
-lo, hi, split = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3] == "split"
-cfg = pc.SMALL_SPLIT if split else pc.SMALL
+lo, hi, split = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3] in ("split", "cheaper48")
+cfg = dict(preset="cheaper", sample_rate=48000.0) if sys.argv[3] == "cheaper48" else (pc.SMALL_SPLIT if split else pc.SMALL)  # cheaper48: presetCheaper at 48 kHz (split computation, interval 1920)
+q = 15 if sys.argv[3] == "cheaper48" else 1  # sample counts are written for an interval of 128
 sr = 48000
 bad = []
 for seed in range(lo, hi):
     C = 1 + seed % 3
     formants = seed % 4 == 3
-    x = synth_input(seed, C, 30000, sr) + 0.4*synth_input(seed + 7, C, 30000, sr)
+    x = synth_input(seed, C, 30000*q, sr) + 0.4*synth_input(seed + 7, C, 30000*q, sr)
     def play(o, xx, seed=seed, formants=formants):
         rng = np.random.default_rng(5000 + seed)
         pos, outs = 0, []
         ratio = float(rng.choice([0.75, 1.0, 1.3]))
-        outs.append(o.process(xx[:, :1500], 1500)); pos = 1500   # warm up: sound in the ring
-        for call in range(60):
+        outs.append(o.process(xx[:, :1500*q], 1500*q)); pos = 1500*q   # warm up: sound in the ring
+        for call in range(60 if q == 1 else 30):
             kind = rng.choice(["process", "param", "flush", "seek", "reset", "empty"], p=[0.5, 0.2, 0.12, 0.06, 0.04, 0.08])
             if kind == "param":
                 which = int(rng.integers(0, 4 if formants else 2))
@@ -32,17 +33,17 @@ for seed in range(lo, hi):
                 elif which == 2: o.setFormantFactor(float(rng.choice([0.9, 1.0, 1.15])), bool(rng.integers(0, 2)))
                 else: o.setFormantBase(float(rng.choice([0.0, 150.0/sr])))
                 ratio = float(rng.choice([0.75, 1.0, 1.3, 1.6, 2.6]))
-            elif kind == "flush": outs.append(o.flush(int(rng.integers(1, 200))))
+            elif kind == "flush": outs.append(o.flush(int(rng.integers(1, 200))*q))
             elif kind == "seek":
-                n = int(rng.integers(50, 700)); o.seek(xx[:, pos:pos + n], float(rng.choice([0.8, 1.0, 1.2]))); pos += n
+                n = int(rng.integers(50, 700))*q; o.seek(xx[:, pos:pos + n], float(rng.choice([0.8, 1.0, 1.2]))); pos += n
             elif kind == "reset": o.reset()
             elif kind == "empty":
-                if rng.integers(0, 2): outs.append(o.process(xx[:, pos:pos], int(rng.integers(1, 100))))
+                if rng.integers(0, 2): outs.append(o.process(xx[:, pos:pos], int(rng.integers(1, 100))*q))
                 else:
-                    n = int(rng.integers(1, 100)); outs.append(o.process(xx[:, pos:pos + n], 0)); pos += n
+                    n = int(rng.integers(1, 100))*q; outs.append(o.process(xx[:, pos:pos + n], 0)); pos += n
             else:
-                n = int(rng.integers(1, 150)); outs.append(o.process(xx[:, pos:pos + n], max(1, int(n*ratio)))); pos += n
-        outs.append(o.process(xx[:, pos:pos + 1500], 1800))
+                n = int(rng.integers(1, 150))*q + int(rng.integers(0, q)); outs.append(o.process(xx[:, pos:pos + n], max(1, int(n*ratio)))); pos += n
+        outs.append(o.process(xx[:, pos:pos + 1500*q], 1800*q))
         return np.concatenate([np.asarray(v) for v in outs], axis=1)
     try:
         pc.check_scenario(lib, ref_oracle, cfg, x, play, "dense walk %d" % seed, cap=pc.CAP_FORMANT if formants else pc.CAP_TONAL)
