@@ -11,6 +11,7 @@ struct DevBatch {
 	int Mp;                       // row pitch (elements) of the per-tile [.][C][M] arrays: M + 32 rounded up to 16
 	int recPitch;                 // float4 per wavefront step in REC: chunks*64 + 16
 	int histLen, carryLen, delta; // B+I, B+I, split ? I : 0
+	int histPitch;                // 2*(B+I): a call's input is appended behind the window until the row is full, then the window moves back to the front
 	int lag, ringSlots;           // wavefront skew (>= L+1) and LDS ring depth (power of two > lag)
 	int recSteps;                 // record rows per stream: M + lag*(T-1) rounded up to 64, plus prefetch slack
 	int hopStride, emitStride;    // row pitch of the per-call hop / emit tables
@@ -47,7 +48,8 @@ struct DevBatch {
 	// per-stream state
 	float2 *stInput, *stPrev, *stOut; // Band.input / .prevInput / .output   [S][C][M]
 	float *stEnergy;                  // Prediction.energy                   [S][C][M]
-	float *hist[2];                   // last B+I input samples              [S][C][B+I]
+	float *hist;                      // input history, a sliding window of B+I samples per row        [S][C][histPitch]
+	int *histBase[2];                 // where each stream's window begins in its rows (double-buffered with histCur: kHistory reads one, writes the other)  [S]
 	float *carrySum[2];               // overlap-add partial sums            [S][C][B+I]
 	float *carryWp[2];                // window products                     [S][B+I]
 	float *wpHead;                    // kSynthEmitTeams: the window products of a tile's first samples (those the carry reaches into), [S][wpHeadLen], written by kEmitProducts
@@ -138,7 +140,7 @@ void launchEmitProducts(const DevBatch &d, int sBase, int nStreams, int tileInde
 void launchSynthEmit(const DevBatch &d, const IoArgs &io, int sBase, int nStreams, int tileIndex, hipStream_t st);
 void launchCarryFeed(const DevBatch &d, int sBase, int nStreams, int hopBase, bool anyFormants, hipStream_t st);
 void launchCarryOut(const DevBatch &d, int sBase, int nStreams, hipStream_t st);
-void launchHistory(const DevBatch &d, const IoArgs &io, hipStream_t st);
+void launchHistory(const DevBatch &d, const IoArgs &io, int span, hipStream_t st);
 void launchPassThrough(const DevBatch &d, const IoArgs &io, const int *passFlags, int maxOut, hipStream_t st);
 // flags: per-stream bit masks or null = allBits for every stream.  keep (may be null): per stream, the first samples of the overlap-add ring that
 // stft.reset() does NOT reach -- split computation reads the rest of the interval from its stashed copy of the ring (signalsmith-stretch.h:407-415)

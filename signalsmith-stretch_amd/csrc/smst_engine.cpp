@@ -316,8 +316,11 @@ void Batch::construct(const FftPlan &plan, long seed) {
 	d.stOut = reinterpret_cast<float2 *>(devAlloc<unsigned char>(bandRows*sizeof(float2)/stateScale));
 	d.stEnergy = reinterpret_cast<float *>(devAlloc<unsigned char>(bandRows*sizeof(float)/stateScale + 16)); // (+16: PrevEnergy::at reads 8 bytes at an element)
 	SMST_HIP(hipMemset(d.stEnergy, 0, bandRows*sizeof(float)/stateScale + 16));
+	d.histPitch = 2*d.histLen;
+	d.hist = devAlloc<float>((size_t)S*C*d.histPitch);
 	for (int h = 0; h < 2; ++h) {
-		d.hist[h] = devAlloc<float>((size_t)S*C*d.histLen);
+		d.histBase[h] = devAlloc<int>((size_t)S);
+		SMST_HIP(hipMemset(d.histBase[h], 0, (size_t)S*sizeof(int)));
 		d.carrySum[h] = reinterpret_cast<float *>(devAlloc<unsigned char>((size_t)S*C*d.carryLen*sizeof(float)/stateScale));
 		d.carryWp[h] = devAlloc<float>((size_t)S*d.carryLen);
 	}
@@ -375,6 +378,7 @@ void Batch::construct(const FftPlan &plan, long seed) {
 	allocateWorkspace();
 	pend.assign(S, PendingBlock());
 	lastSteps.assign(S, 0);
+	histBase.assign(S, 0);
 	keepV.assign(S, 0);
 	if (split) { // the block in flight: its spectra, and the tables of the run that completes it (PendingBlock, smst_engine.h)
 		const size_t rows = (size_t)S*C*d.Mp;
@@ -525,6 +529,7 @@ void Batch::resetStreams(const int *bitsHost, int allBits, const int *keepHost) 
 	if (bitsHost) SMST_HIP(hipMemcpy(dResetBits, bitsHost, S*sizeof(int), hipMemcpyHostToDevice));
 	if (keepHost) SMST_HIP(hipMemcpy(dKeep, keepHost, S*sizeof(int), hipMemcpyHostToDevice));
 	launchResetStreams(d, bitsHost ? dResetBits : nullptr, allBits, dSeedWp, st, keepHost ? dKeep : nullptr);
+	for (int s = 0; s < S; ++s) if ((bitsHost ? bitsHost[s] : allBits) & 1) histBase[s] = 0; // (the host's copy of DevBatch::histBase: it sizes kHistory's launch)
 }
 
 void Batch::reset() { // signalsmith-stretch.h:49-60
@@ -1274,7 +1279,14 @@ void Batch::process(const float *in, long long inSS, long long inCS, const int *
 	});
 	timed(timings.otherMs, [&] {
 		if (anyPass) launchPassThrough(d, io, dFlags, maxOut, st);
-		launchHistory(d, io, st);
+		// the input history slides (kHistory): the host follows each stream's window to size the launch
+		int span = 0;
+		for (int s = 0; s < S; ++s) {
+			const int n = nIn[s];
+			if (histBase[s] + d.histLen + n <= d.histPitch) { histBase[s] += n; span = std::max(span, n); }
+			else { histBase[s] = 0; span = std::max(span, d.histLen); }
+		}
+		launchHistory(d, io, span, st);
 	});
 	d.histCur ^= 1;
 	SMST_HIP(hipEventRecord(cs.done, st));
@@ -1308,7 +1320,8 @@ void Batch::seek(const float *in, long long inSS, long long inCS, const int *inS
 	launchSeekHistory(d, io, dFlags, st);
 	d.histCur ^= 1;
 	// energy of the copied part only (:144-154) = energy over the new history (the zero padding adds nothing)
-	IoArgs ioE{d.hist[d.histCur], nullptr, (long long)C*d.histLen, (long long)d.histLen, 0, 0, dAux0, dOutSamples};
+	for (int s = 0; s < S; ++s) if (flags[s]) histBase[s] = 0;
+	IoArgs ioE{d.hist, nullptr, (long long)C*d.histPitch, (long long)d.histPitch, 0, 0, dAux0, dOutSamples}; // (the streams that seek: their windows are at the front of the rows now)
 	launchEnergy(d, ioE, 0, S, dEnergy, st);
 	SMST_HIP(hipMemcpyAsync(hSeekEnergy, dEnergy, (size_t)S*kEnergyParts*sizeof(float), hipMemcpyDeviceToHost, st));
 	SMST_HIP(hipStreamSynchronize(st));
@@ -1470,8 +1483,10 @@ void Batch::copyStateFrom(Batch &o) {
 	copy(d.stPrev, o.d.stPrev, bandRows*sizeof(float2));
 	copy(d.stOut, o.d.stOut, bandRows*sizeof(float2)/scale);
 	copy(d.stEnergy, o.d.stEnergy, bandRows*sizeof(float)/scale);
+	copy(d.hist, o.d.hist, (size_t)S*C*d.histPitch*sizeof(float));
+	histBase = o.histBase;
 	for (int h = 0; h < 2; ++h) {
-		copy(d.hist[h], o.d.hist[h], (size_t)S*C*d.histLen*sizeof(float));
+		copy(d.histBase[h], o.d.histBase[h], (size_t)S*sizeof(int));
 		copy(d.carrySum[h], o.d.carrySum[h], (size_t)S*C*d.carryLen*sizeof(float)/scale);
 		copy(d.carryWp[h], o.d.carryWp[h], (size_t)S*d.carryLen*sizeof(float));
 	}

@@ -159,6 +159,7 @@ private:
 	bool paramsDirty = true;
 	// ---- split computation: the block in flight (see PendingBlock) ----
 	std::vector<int> lastSteps;
+	std::vector<int> histBase;  // the host's copy of DevBatch::histBase (where each stream's input-history window begins)
 	std::vector<PendingBlock> pend;
 	float2 *dPendIn = nullptr, *dPendPrev = nullptr; // its spectra, [S][C][Mp]: Band.input and (re-analysed) Band.prevInput
 	struct PendSet { // tables of one run of blocks in flight (double-buffered like CallSet: pinned staging, asynchronous uploads)

@@ -357,7 +357,7 @@ __global__ __launch_bounds__(16*R3 > 256 ? 16*R3 : 256) __attribute__((amdgpu_wa
 	const int B = d.B, H = d.M, halfB = B/2, N = d.N;
 	const int base = hd.inputOffset - (which ? d.I : 0) - B;
 	const float *x = io.in + (size_t)(sBase + s)*io.inStreamStride + (size_t)c*io.inChannelStride;
-	const float *hist = d.hist[d.histCur] + ((size_t)(sBase + s)*d.C + c)*(size_t)d.histLen + d.histLen;
+	const float *hist = d.hist + ((size_t)(sBase + s)*d.C + c)*(size_t)d.histPitch + d.histBase[d.histCur][sBase + s] + d.histLen;
 	const float2 *__restrict__ winA = d.winA, *__restrict__ winB = d.winB;
 	float2 *dst = (which ? d.Xprev : d.Xcur) + rowOf(d, s, k, c);
 	auto prep = [](int, int) { return 0; };
@@ -876,7 +876,7 @@ __global__ __launch_bounds__(256) void kAnalyse(DevBatch d, IoArgs io, int sBase
 	const int B = d.B, H = d.M, halfB = B/2;
 	const int base = hd.inputOffset - (which ? d.I : 0) - B; // index of block element 0 in the call's input
 	const float *x = io.in + (size_t)(sBase + s)*io.inStreamStride + (size_t)c*io.inChannelStride;
-	const float *hist = d.hist[d.histCur] + ((size_t)(sBase + s)*d.C + c)*(size_t)d.histLen;
+	const float *hist = d.hist + ((size_t)(sBase + s)*d.C + c)*(size_t)d.histPitch + d.histBase[d.histCur][sBase + s];
 	const float *__restrict__ win = d.window;
 
 	for (int m = threadIdx.x; m < H; m += blockDim.x) {

@@ -46,19 +46,26 @@ __global__ __launch_bounds__(256) void kCarryOut(DevBatch d, int sBase) {
 	storeCarriedOutput(d, stateRow(d, sg, c) + b, d.OUT[rowOf(d, s, nh - 1, c) + b]);
 }
 
-// Input history for the next call: the last B+I samples of (history ++ this call's input)  (copyInput, :215-229,:418)
+// Input history for the next call: the last B+I samples of (history ++ this call's input)  (copyInput, :215-229,:418).  The window
+// slides: a short call appends its input behind the window (n samples written instead of B+I copied -- the 128-frame real-time
+// pattern spent a quarter of its no-hop quanta on that copy); when the row is full the window moves back to its front.  Moving is
+// safe in place: it happens only when base + n > B+I, so what is read lies behind what is written.
 __global__ __launch_bounds__(256) void kHistory(DevBatch d, IoArgs io) {
 	const int sg = blockIdx.z, c = blockIdx.y;
 	const int j = blockIdx.x*blockDim.x + threadIdx.x;
 	const int HL = d.histLen;
+	const int n = io.inSamples[sg], base = d.histBase[d.histCur][sg];
+	const bool append = base + HL + n <= d.histPitch;
+	if (j == 0 && c == 0) d.histBase[d.histCur ^ 1][sg] = append ? base + n : 0;
+	float *row = d.hist + ((size_t)sg*d.C + c)*(size_t)d.histPitch;
+	const float *x = io.in + (size_t)sg*io.inStreamStride + (size_t)c*io.inChannelStride;
+	if (append) {
+		if (j < n) row[base + HL + j] = x[j];
+		return;
+	}
 	if (j >= HL) return;
-	const int n = io.inSamples[sg];
-	const size_t row = ((size_t)sg*d.C + c)*(size_t)HL;
 	const int rel = n - HL + j;
-	float v;
-	if (rel >= 0) v = io.in[(size_t)sg*io.inStreamStride + (size_t)c*io.inChannelStride + rel];
-	else v = d.hist[d.histCur][row + HL + rel];
-	d.hist[d.histCur ^ 1][row + j] = v;
+	row[j] = (rel >= 0) ? x[rel] : row[base + HL + rel];
 }
 
 // Silence pass-through (signalsmith-stretch.h:252-267): outputs[c][i] = inputs[c][i % inputSamples] (or 0)
@@ -97,11 +104,12 @@ __global__ __launch_bounds__(256) void kResetStreams(DevBatch d, const int *__re
 				storeCarrySum(d, 0, ((size_t)sg*C + c)*CL + i, v);
 				storeCarrySum(d, 1, ((size_t)sg*C + c)*CL + i, v);
 			}
-			if (i < HL) {
-				d.hist[0][((size_t)sg*C + c)*HL + i] = 0.0f;
-				d.hist[1][((size_t)sg*C + c)*HL + i] = 0.0f;
+			if (i < HL) { // (the whole row: the window returns to its front)
+				d.hist[((size_t)sg*C + c)*d.histPitch + i] = 0.0f;
+				d.hist[((size_t)sg*C + c)*d.histPitch + HL + i] = 0.0f;
 			}
 		}
+		if (i == 0) d.histBase[0][sg] = d.histBase[1][sg] = 0;
 	}
 	if (i < M && (bits & 14)) {
 		const float2 zero = make_float2(0.f, 0.f);
@@ -134,22 +142,16 @@ __global__ __launch_bounds__(256) void kMaskOutRows(DevBatch d, int sBase, const
 	d.OUT[rowOf(d, s, 0, c) + b] = make_float2(0.f, 0.f);
 }
 
-// seek(): history = the last B+I samples of the (zero-padded) pre-roll  (signalsmith-stretch.h:140-158)
+// seek(): history = the last B+I samples of the (zero-padded) pre-roll  (signalsmith-stretch.h:140-158), written at the front of the row
 __global__ __launch_bounds__(256) void kSeekHistory(DevBatch d, IoArgs io, const int *__restrict__ seekFlags) {
 	const int sg = blockIdx.z, c = blockIdx.y;
 	const int j = blockIdx.x*blockDim.x + threadIdx.x;
 	const int HL = d.histLen;
-	if (j >= HL) return;
-	const size_t row = ((size_t)sg*d.C + c)*(size_t)HL;
-	float v;
-	if (seekFlags[sg]) {
-		const int n = io.inSamples[sg];
-		const int rel = n - HL + j;
-		v = (rel >= 0) ? io.in[(size_t)sg*io.inStreamStride + (size_t)c*io.inChannelStride + rel] : 0.0f;
-	} else {
-		v = d.hist[d.histCur][row + j];
-	}
-	d.hist[d.histCur ^ 1][row + j] = v;
+	if (j == 0 && c == 0) d.histBase[d.histCur ^ 1][sg] = seekFlags[sg] ? 0 : d.histBase[d.histCur][sg];
+	if (j >= HL || !seekFlags[sg]) return;
+	const int n = io.inSamples[sg];
+	const int rel = n - HL + j;
+	d.hist[((size_t)sg*d.C + c)*(size_t)d.histPitch + j] = (rel >= 0) ? io.in[(size_t)sg*io.inStreamStride + (size_t)c*io.inChannelStride + rel] : 0.0f;
 }
 
 // flush() tail (signalsmith-stretch.h:442-455): finishOutput(1) = running maximum of the window products from the
@@ -229,8 +231,8 @@ void launchCarryFeed(const DevBatch &d, int sBase, int nStreams, int hopBase, bo
 void launchCarryOut(const DevBatch &d, int sBase, int nStreams, hipStream_t st) {
 	hipLaunchKernelGGL(kCarryOut, dim3(divUp(d.M, 256), d.C, nStreams), dim3(256), 0, st, d, sBase);
 }
-void launchHistory(const DevBatch &d, const IoArgs &io, hipStream_t st) {
-	hipLaunchKernelGGL(kHistory, dim3(divUp(d.histLen, 256), d.C, d.S), dim3(256), 0, st, d, io);
+void launchHistory(const DevBatch &d, const IoArgs &io, int span, hipStream_t st) { // span: the most elements any row writes (its input if it appends, B+I if its window moves)
+	hipLaunchKernelGGL(kHistory, dim3(divUp(span < 1 ? 1 : span, 256), d.C, d.S), dim3(256), 0, st, d, io);
 }
 void launchPassThrough(const DevBatch &d, const IoArgs &io, const int *passFlags, int maxOut, hipStream_t st) {
 	int bx = divUp(maxOut, 256);
