@@ -11,6 +11,7 @@ struct DevBatch {
 	int Mp;                       // row pitch (elements) of the per-tile [.][C][M] arrays: M + 32 rounded up to 16
 	int recPitch;                 // float4 per wavefront step in REC: chunks*64 + 16
 	int histLen, carryLen, delta; // B+I, B+I, split ? I : 0
+	int carryPitch;               // B+I + 2*I: behind the window the rows hold what an empty ring position holds (sum 0, product 1e-30) -- written once, by kResetStreams
 	int histPitch;                // 2*(B+I): a call's input is appended behind the window until the row is full, then the window moves back to the front
 	int lag, ringSlots;           // wavefront skew (>= L+1) and LDS ring depth (power of two > lag)
 	int recSteps;                 // record rows per stream: M + lag*(T-1) rounded up to 64, plus prefetch slack
@@ -50,8 +51,10 @@ struct DevBatch {
 	float *stEnergy;                  // Prediction.energy                   [S][C][M]
 	float *hist;                      // input history, a sliding window of B+I samples per row        [S][C][histPitch]
 	int *histBase[2];                 // where each stream's window begins in its rows (double-buffered with histCur: kHistory reads one, writes the other)  [S]
-	float *carrySum[2];               // overlap-add partial sums            [S][C][B+I]
-	float *carryWp[2];                // window products                     [S][B+I]
+	float *carrySum[2];               // overlap-add partial sums: a window of B+I per row    [S][C][carryPitch]
+	float *carryWp[2];                // window products                                      [S][carryPitch]
+	int *carryBase[2];                // where each stream's window begins in the rows of that half: a call without a hop emits from the front of the window
+	                                  // and moves its beginning on (kEmitCarried) instead of copying what is left; everything else writes a window at 0.  [S]
 	float *wpHead;                    // kSynthEmitTeams: the window products of a tile's first samples (those the carry reaches into), [S][wpHeadLen], written by kEmitProducts
 	int wpHeadLen;                    // (ceil(B/I) + 2)*I
 	float *stFreq;                    // freqEstimateWeighted / Weight       [S][2]
@@ -115,7 +118,7 @@ __host__ __device__ inline bool analysisWindowInCall(int B, int M, int I, int in
 // form" tests assert through these that BOTH forms really ran.
 enum LaunchKind {
 	LK_VOC_ALIGNED, LK_VOC_STAGED, LK_VOC_GATHER, LK_VOC_N, LK_VOC_ONE, LK_VOC_ACROSS, LK_CHAIN_UNFUSED,
-	LK_ANALYSE_TEAMS, LK_ANALYSE_FAST, LK_ANALYSE_GENERIC, LK_SYNTH_TEAMS, LK_SYNTH_FAST, LK_SYNTH_GENERIC, LK_SYNTH_EMIT, LK_COUNT
+	LK_ANALYSE_TEAMS, LK_ANALYSE_FAST, LK_ANALYSE_GENERIC, LK_SYNTH_TEAMS, LK_SYNTH_FAST, LK_SYNTH_GENERIC, LK_SYNTH_EMIT, LK_EMIT_CARRIED, LK_COUNT
 };
 long long launchCount(const char *name); // -1: unknown name
 
@@ -133,6 +136,7 @@ bool acrossSupported(const DevBatch &d);
 void launchVocoderAcross(const DevBatch &d, int sBase, int nStreams, int hopBase, bool plain, hipStream_t st); // the same tiles, mono / stereo: lanes of the recurrence wave = streams
 void launchSynth(const DevBatch &d, int sBase, int nStreams, int hopBase, int tileHops, hipStream_t st);
 void launchEmit(const DevBatch &d, const IoArgs &io, int sBase, int nStreams, int tileIndex, int maxSpan, hipStream_t st);
+void launchEmitCarried(const DevBatch &d, const IoArgs &io, hipStream_t st); // a call without hops, every stream (emit table row 0)
 // synthesis + overlap-add + emission in one kernel: whether it applies to a tile; its window products (needs nothing of the tile's
 // spectra: launched ahead of the recurrence's completion); the kernel itself
 bool synthEmitApplies(const DevBatch &d, int nStreams, int tileHops);

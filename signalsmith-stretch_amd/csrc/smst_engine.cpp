@@ -153,7 +153,7 @@ void Batch::construct(const FftPlan &plan, long seed) {
 	}
 	// the cross-check switches: one struct, one table, read once (smst_switches.h)
 	const Switches sw = Switches::fromEnvironment();
-	overlap = sw.overlap; noFuse = sw.noFuse; noSingleHop = sw.noSingleHop; noAcross = sw.noAcross; checkLaunches = sw.checkLaunches;
+	overlap = sw.overlap; noFuse = sw.noFuse; noSingleHop = sw.noSingleHop; noAcross = sw.noAcross; carriedEmit = sw.carriedEmit != 0; checkLaunches = sw.checkLaunches;
 	workspaceGiB = sw.workspaceGiB;
 	subStreamsAsked = sw.subStreams;
 
@@ -317,12 +317,17 @@ void Batch::construct(const FftPlan &plan, long seed) {
 	d.stEnergy = reinterpret_cast<float *>(devAlloc<unsigned char>(bandRows*sizeof(float)/stateScale + 16)); // (+16: PrevEnergy::at reads 8 bytes at an element)
 	SMST_HIP(hipMemset(d.stEnergy, 0, bandRows*sizeof(float)/stateScale + 16));
 	d.histPitch = 2*d.histLen;
+	d.carryPitch = d.carryLen + 2*I;
 	d.hist = devAlloc<float>((size_t)S*C*d.histPitch);
+	dZeroEmit = devAlloc<EmitDesc>(S); // (settleCarry)
+	SMST_HIP(hipMemset(dZeroEmit, 0, (size_t)S*sizeof(EmitDesc)));
 	for (int h = 0; h < 2; ++h) {
 		d.histBase[h] = devAlloc<int>((size_t)S);
 		SMST_HIP(hipMemset(d.histBase[h], 0, (size_t)S*sizeof(int)));
-		d.carrySum[h] = reinterpret_cast<float *>(devAlloc<unsigned char>((size_t)S*C*d.carryLen*sizeof(float)/stateScale));
-		d.carryWp[h] = devAlloc<float>((size_t)S*d.carryLen);
+		d.carrySum[h] = reinterpret_cast<float *>(devAlloc<unsigned char>((size_t)S*C*d.carryPitch*sizeof(float)/stateScale));
+		d.carryWp[h] = devAlloc<float>((size_t)S*d.carryPitch);
+		d.carryBase[h] = devAlloc<int>((size_t)S);
+		SMST_HIP(hipMemset(d.carryBase[h], 0, (size_t)S*sizeof(int)));
 	}
 	d.wpHeadLen = ((B + I - 1)/I + 2)*I;
 	d.wpHead = devAlloc<float>((size_t)S*d.wpHeadLen);
@@ -379,6 +384,7 @@ void Batch::construct(const FftPlan &plan, long seed) {
 	pend.assign(S, PendingBlock());
 	lastSteps.assign(S, 0);
 	histBase.assign(S, 0);
+	carryBase.assign(S, 0);
 	keepV.assign(S, 0);
 	if (split) { // the block in flight: its spectra, and the tables of the run that completes it (PendingBlock, smst_engine.h)
 		const size_t rows = (size_t)S*C*d.Mp;
@@ -404,6 +410,7 @@ void Batch::construct(const FftPlan &plan, long seed) {
 		pendTileHas.assign((size_t)nSub*kTileHasStride, 0);
 		pendMaxSpan.assign(nSub, 0);
 	}
+	SMST_HIP(hipDeviceSynchronize()); // the hipMemset calls above are ordered with the null stream only; the engine's streams are non-blocking
 	reset();
 }
 
@@ -525,11 +532,28 @@ void Batch::uploadParams() {
 // stft.reset(0.1) / Band clearing for a set of streams (bit masks, see kResetStreams): one upload + one launch, instead
 // of six API calls per stream.  `bitsHost` == nullptr: `allBits` for every stream.  Not on the steady-state path (reset,
 // flush, first silent block), so the small synchronous upload is fine.
+// The kernels outside the tile pipeline (flush tail, pre-roll, the reset that keeps the samples of a split interval, the debug accessors) index
+// the overlap-add carry from the front of its rows: a call without hops may have left the windows further in (kEmitCarried) -- one
+// emission of nothing moves them back.
+void Batch::settleCarry() {
+	bool moved = false;
+	for (int s = 0; s < S && !moved; ++s) moved = carryBase[s] != 0;
+	if (!moved) return;
+	DevBatch dd = d;
+	dd.emit = dZeroEmit;
+	dd.emitStride = 1;
+	const IoArgs io{nullptr, nullptr, 0, 0, 0, 0, nullptr, nullptr};
+	launchEmit(dd, io, 0, S, 0, 0, st);
+	d.carryCur ^= 1;
+	std::fill(carryBase.begin(), carryBase.end(), 0);
+}
+
 void Batch::resetStreams(const int *bitsHost, int allBits, const int *keepHost) {
+	if (keepHost) settleCarry();
 	if (bitsHost) SMST_HIP(hipMemcpy(dResetBits, bitsHost, S*sizeof(int), hipMemcpyHostToDevice));
 	if (keepHost) SMST_HIP(hipMemcpy(dKeep, keepHost, S*sizeof(int), hipMemcpyHostToDevice));
 	launchResetStreams(d, bitsHost ? dResetBits : nullptr, allBits, dSeedWp, st, keepHost ? dKeep : nullptr);
-	for (int s = 0; s < S; ++s) if ((bitsHost ? bitsHost[s] : allBits) & 1) histBase[s] = 0; // (the host's copy of DevBatch::histBase: it sizes kHistory's launch)
+	for (int s = 0; s < S; ++s) if ((bitsHost ? bitsHost[s] : allBits) & 1) histBase[s] = carryBase[s] = 0; // (the host's copies of DevBatch::histBase / carryBase)
 }
 
 void Batch::reset() { // signalsmith-stretch.h:49-60
@@ -842,7 +866,7 @@ void Batch::runPendingBlocks(const int *synthChannels) {
 	d.hopStride = 1;
 	d.emitStride = 1;
 	const IoArgs io{nullptr, nullptr, 0, 0, 0, 0, dZeroCounts, dZeroCounts};
-	runTiles(TileRun{&io, 1, 1, pendTileHas.data(), pendMaxSpan.data(), ps.tileInfo, true, synthChannels ? ps.synthChannels : nullptr});
+	runTiles(TileRun{&io, 1, 1, pendTileHas.data(), pendMaxSpan.data(), ps.tileInfo, true, synthChannels ? ps.synthChannels : nullptr, false});
 	d.paramsPeaks = d.paramsForm0 = d.paramsForm2 = dParams;
 	if (anyZeroPrev) {
 		for (int s = 0; s < S; ++s) ps.hBits[s] = 0;
@@ -865,7 +889,13 @@ void Batch::runTiles(const TileRun &run) {
 	const IoArgs &io = *run.io;
 	const int T = d.T, nTiles = run.nTiles, maxHops = run.maxHops;
 	const int nSub = (S + subS - 1)/subS;
-	const int carryBase = d.carryCur;
+	if (run.carriedOnly) { // no stream fires a hop: the front of the carry is the output, and what is left stays where it is
+		timed(timings.emitMs, [&] { launchEmitCarried(d, io, st); if (profiling) ++timings.emitLaunches; });
+		checkLaunch("emission of the carried sums");
+		return;
+	}
+	std::fill(carryBase.begin(), carryBase.end(), 0); // every tile writes every stream's carry from the front of its rows
+	const int carryFirst = d.carryCur;
 	// Three HIP streams: `st` runs the feed-forward kernels of tile q, `stChain` the recurrence of tile q (a few
 	// hundred waves, instruction-issue bound), `stSynth` synthesis + emission.  Two workspaces alternate, so the bulk
 	// kernels of the next tile fill the machine while the recurrence of the current one is in flight.
@@ -892,7 +922,7 @@ void Batch::runTiles(const TileRun &run) {
 			DevBatch dd = d;
 			dd.Xcur = w.Xcur; dd.Xprev = w.Xprev; dd.PE = w.PE; dd.OUT = w.OUT; dd.REC = w.REC; dd.dump = w.dump;
 			dd.map = w.map; dd.ratio = w.ratio; dd.energyT = w.energyT; dd.smoothT = w.smoothT; dd.peaksT = w.peaksT; dd.est = w.est; dd.freqEst = w.freqEst; dd.frames = w.frames;
-			dd.carryCur = (carryBase + t) & 1;
+			dd.carryCur = (carryFirst + t) & 1;
 			dd.nHops = run.dTileInfo + ((size_t)(sub*nTiles + t)*2)*subS;
 			dd.lastNewHop = dd.nHops + subS;
 			if (!serial && q >= 2) { // this workspace was last used by tile q-2
@@ -970,7 +1000,7 @@ void Batch::runTiles(const TileRun &run) {
 			SMST_HIP(hipStreamWaitEvent(st, evSynth[i], 0));
 		}
 	}
-	d.carryCur = (carryBase + nTiles) & 1;
+	d.carryCur = (carryFirst + nTiles) & 1;
 }
 
 void Batch::process(const float *in, long long inSS, long long inCS, const int *inSamples,
@@ -1264,7 +1294,12 @@ void Batch::process(const float *in, long long inSS, long long inCS, const int *
 	d.hopStride = hopStride;
 	d.emitStride = nTiles;
 
-	runTiles(TileRun{&io, nTiles, maxHops, tileHasV.data(), maxSpanV.data(), dTileInfo, false, nullptr});
+	// no stream fires a hop (most quanta of a real-time host): the output is the front of the carried sums, and -- while the rows have room --
+	// what is left of them stays in place (kEmitCarried)
+	bool carriedOnly = maxHops == 0 && carriedEmit;
+	for (int s = 0; s < S && carriedOnly; ++s) carriedOnly = carryBase[s] + (passFlags[s] ? 0 : nOut[s]) + d.carryLen <= d.carryPitch;
+	if (carriedOnly) for (int s = 0; s < S; ++s) carryBase[s] += passFlags[s] ? 0 : nOut[s];
+	runTiles(TileRun{&io, nTiles, maxHops, tileHasV.data(), maxSpanV.data(), dTileInfo, false, nullptr, carriedOnly});
 	if (anyPendAnalysis) timed(timings.analyseMs, [&] {
 		// the blocks left in flight: their spectra (Band.input and, where :303 asks for it, the re-analysed Band.prevInput) into the pending
 		// buffers, laid out as a one-hop tile over ALL streams
@@ -1417,6 +1452,7 @@ void Batch::flush(float *out, long long outSS, long long outCS, const int *outSa
 	SMST_HIP(hipMemcpyAsync(dAux1, outOff.data(), S*sizeof(int), hipMemcpyHostToDevice, st));
 	SMST_HIP(hipStreamSynchronize(st));
 	IoArgs io{nullptr, out, 0, 0, outSS, outCS, dInSamples, dOutSamples};
+	settleCarry();
 	launchFlushTail(d, io, dAux0, dAux1, st);
 	// stft.reset(0.1) + zero prevInput/output (:456-463).  Split computation: the samples up to the end of the interval still come from
 	// the stashed ring (:407-415), which the reset does not touch -- the fresh ring begins behind them
@@ -1466,6 +1502,7 @@ void Batch::outputSeek(const float *in, long long inSS, long long inCS, const in
 	}
 	SMST_HIP(hipMemcpyAsync(dAux0, off.data(), S*sizeof(int), hipMemcpyHostToDevice, st));
 	SMST_HIP(hipStreamSynchronize(st));
+	settleCarry();
 	launchAddPreRoll(d, dScratchOut, outLat, dAux0, st);
 	SMST_HIP(hipGetLastError());
 }
@@ -1485,10 +1522,12 @@ void Batch::copyStateFrom(Batch &o) {
 	copy(d.stEnergy, o.d.stEnergy, bandRows*sizeof(float)/scale);
 	copy(d.hist, o.d.hist, (size_t)S*C*d.histPitch*sizeof(float));
 	histBase = o.histBase;
+	carryBase = o.carryBase;
 	for (int h = 0; h < 2; ++h) {
 		copy(d.histBase[h], o.d.histBase[h], (size_t)S*sizeof(int));
-		copy(d.carrySum[h], o.d.carrySum[h], (size_t)S*C*d.carryLen*sizeof(float)/scale);
-		copy(d.carryWp[h], o.d.carryWp[h], (size_t)S*d.carryLen*sizeof(float));
+		copy(d.carrySum[h], o.d.carrySum[h], (size_t)S*C*d.carryPitch*sizeof(float)/scale);
+		copy(d.carryWp[h], o.d.carryWp[h], (size_t)S*d.carryPitch*sizeof(float));
+		copy(d.carryBase[h], o.d.carryBase[h], (size_t)S*sizeof(int));
 	}
 	copy(d.stFreq, o.d.stFreq, (size_t)S*2*sizeof(float));
 	d.histCur = o.d.histCur;
@@ -1577,15 +1616,18 @@ void Batch::debugSetCarry(int stream, const float *sums, const float *products) 
 	if (stream < 0 || stream >= S) throw Error("debugSetCarry: bad stream");
 	SMST_HIP(hipSetDevice(dev));
 	SMST_HIP(hipStreamSynchronize(st));
-	const size_t n = (size_t)C*d.carryLen, off = (size_t)stream*n;
+	settleCarry();
+	SMST_HIP(hipStreamSynchronize(st));
+	// [C] rows of B+I values, carryPitch apart on the device
+	const size_t n = (size_t)C*d.carryLen, off = (size_t)stream*C*d.carryPitch, CL = d.carryLen, CP = d.carryPitch;
 	if (halfState) {
 		std::vector<half_t> tmp(n);
 		for (size_t i = 0; i < n; ++i) tmp[i] = half_t(sums[i]);
-		SMST_HIP(hipMemcpy(reinterpret_cast<half_t *>(d.carrySum[d.carryCur]) + off, tmp.data(), n*sizeof(half_t), hipMemcpyHostToDevice));
+		SMST_HIP(hipMemcpy2D(reinterpret_cast<half_t *>(d.carrySum[d.carryCur]) + off, CP*sizeof(half_t), tmp.data(), CL*sizeof(half_t), CL*sizeof(half_t), C, hipMemcpyHostToDevice));
 	} else {
-		SMST_HIP(hipMemcpy(d.carrySum[d.carryCur] + off, sums, n*sizeof(float), hipMemcpyHostToDevice));
+		SMST_HIP(hipMemcpy2D(d.carrySum[d.carryCur] + off, CP*sizeof(float), sums, CL*sizeof(float), CL*sizeof(float), C, hipMemcpyHostToDevice));
 	}
-	SMST_HIP(hipMemcpy(d.carryWp[d.carryCur] + (size_t)stream*d.carryLen, products, (size_t)d.carryLen*sizeof(float), hipMemcpyHostToDevice));
+	SMST_HIP(hipMemcpy(d.carryWp[d.carryCur] + (size_t)stream*CP, products, CL*sizeof(float), hipMemcpyHostToDevice));
 }
 bool Batch::debugGetMap(int stream, float *dst) {
 	if (stream < 0 || stream >= S) throw Error("debugGetMap: bad stream");
@@ -1599,15 +1641,17 @@ bool Batch::debugGetMap(int stream, float *dst) {
 void Batch::debugGetCarry(int stream, float *sums, float *products) {
 	SMST_HIP(hipSetDevice(dev));
 	SMST_HIP(hipStreamSynchronize(st));
-	const size_t n = (size_t)C*d.carryLen, off = (size_t)stream*n;
+	settleCarry();
+	SMST_HIP(hipStreamSynchronize(st));
+	const size_t n = (size_t)C*d.carryLen, off = (size_t)stream*C*d.carryPitch, CL = d.carryLen, CP = d.carryPitch;
 	if (halfState) {
 		std::vector<half_t> tmp(n);
-		SMST_HIP(hipMemcpy(tmp.data(), reinterpret_cast<const half_t *>(d.carrySum[d.carryCur]) + off, n*sizeof(half_t), hipMemcpyDeviceToHost));
+		SMST_HIP(hipMemcpy2D(tmp.data(), CL*sizeof(half_t), reinterpret_cast<const half_t *>(d.carrySum[d.carryCur]) + off, CP*sizeof(half_t), CL*sizeof(half_t), C, hipMemcpyDeviceToHost));
 		for (size_t i = 0; i < n; ++i) sums[i] = float(tmp[i]);
 	} else {
-		SMST_HIP(hipMemcpy(sums, d.carrySum[d.carryCur] + off, n*sizeof(float), hipMemcpyDeviceToHost));
+		SMST_HIP(hipMemcpy2D(sums, CL*sizeof(float), d.carrySum[d.carryCur] + off, CP*sizeof(float), CL*sizeof(float), C, hipMemcpyDeviceToHost));
 	}
-	SMST_HIP(hipMemcpy(products, d.carryWp[d.carryCur] + (size_t)stream*d.carryLen, (size_t)d.carryLen*sizeof(float), hipMemcpyDeviceToHost));
+	SMST_HIP(hipMemcpy(products, d.carryWp[d.carryCur] + (size_t)stream*CP, CL*sizeof(float), hipMemcpyDeviceToHost));
 }
 
 } // namespace smst

@@ -141,7 +141,7 @@ private:
 	int callCur = 0;
 	hipEvent_t evStart = nullptr, evFeed[2] = {nullptr, nullptr}, evChain[2] = {nullptr, nullptr}, evSynth[2] = {nullptr, nullptr};
 	struct TileBuffers { float2 *Xcur, *Xprev, *OUT, *dump, *map, *peaksT; float4 *REC; PredEntry *PE; float *ratio, *energyT, *smoothT, *est, *freqEst, *frames; } slots[2]{};
-	bool overlap = true, noFuse = false, noSingleHop = false, noAcross = false; // (smst_switches.h)
+	bool overlap = true, noFuse = false, noSingleHop = false, noAcross = false, carriedEmit = true; // (smst_switches.h)
 	double workspaceGiB = 0;
 	int subStreamsAsked = 0;
 	int subS = 0;
@@ -159,6 +159,8 @@ private:
 	bool paramsDirty = true;
 	// ---- split computation: the block in flight (see PendingBlock) ----
 	std::vector<int> lastSteps;
+	std::vector<int> carryBase; // the host's copy of DevBatch::carryBase[carryCur]
+	EmitDesc *dZeroEmit = nullptr;
 	std::vector<int> histBase;  // the host's copy of DevBatch::histBase (where each stream's input-history window begins)
 	std::vector<PendingBlock> pend;
 	float2 *dPendIn = nullptr, *dPendPrev = nullptr; // its spectra, [S][C][Mp]: Band.input and (re-analysed) Band.prevInput
@@ -177,7 +179,8 @@ private:
 	void freezePendingParams(int s);   // before a setter changes params[s]
 	unsigned seedAfterDroppedBlock(int s) const; // the random engine once the block in flight is dropped (reset / silence / configure)
 	void runPendingBlocks(const int *synthChannels); // runs the blocks of `pendList` (a tile of one hop per stream; no input, no output samples)
-	struct TileRun { const IoArgs *io; int nTiles, maxHops; const unsigned char *tileHas; const int *maxSpan; const int *dTileInfo; bool pendingRun; const int *dSynthChannels; };
+	struct TileRun { const IoArgs *io; int nTiles, maxHops; const unsigned char *tileHas; const int *maxSpan; const int *dTileInfo; bool pendingRun; const int *dSynthChannels; bool carriedOnly; };
+	void settleCarry();
 	void runTiles(const TileRun &run);
 	bool profiling = false, liveTiming = false;
 	std::vector<std::pair<hipEvent_t, hipEvent_t>> liveEvents; // pairs recorded since the last takeTimings()

@@ -618,10 +618,11 @@ __global__ __launch_bounds__(256) void kEmitProducts(DevBatch d, int sBase, int 
 	const int sg = sBase + blockIdx.y;
 	const EmitDesc ed = d.emit[(size_t)sg*d.emitStride + tileIndex];
 	const int span = ed.nHi - ed.nLo, CL = d.carryLen;
-	const float *carryWpOld = d.carryWp[d.carryCur] + (size_t)sg*CL;
+	const float *carryWpOld = d.carryWp[d.carryCur] + carryWpRow(d, sg) + d.carryBase[d.carryCur][sg];
 	const int i = blockIdx.x*blockDim.x + threadIdx.x;
+	if (i == 0) d.carryBase[d.carryCur ^ 1][sg] = 0; // the new carry is written from the front of its rows (here and by kSynthEmitTeams)
 	if (i < d.wpHeadLen) d.wpHead[(size_t)sg*d.wpHeadLen + i] = windowProductAt(d, ed, carryWpOld, i);
-	else if (i - d.wpHeadLen < CL) d.carryWp[d.carryCur ^ 1][(size_t)sg*CL + (i - d.wpHeadLen)] = windowProductAt(d, ed, carryWpOld, span + (i - d.wpHeadLen));
+	else if (i - d.wpHeadLen < CL) d.carryWp[d.carryCur ^ 1][carryWpRow(d, sg) + (i - d.wpHeadLen)] = windowProductAt(d, ed, carryWpOld, span + (i - d.wpHeadLen));
 }
 
 // K4a + K4b in one kernel: synthesis, overlap-add, window-product normalisation and emission (signalsmith-stretch.h:397-415) without
@@ -669,11 +670,12 @@ __global__ __launch_bounds__(512) void kSynthEmitTeams(DevBatch d, IoArgs io, in
 		const int s = item/d.C, c = item - s*d.C, sg = sBase + s;
 		const EmitDesc ed = d.emit[(size_t)sg*d.emitStride + tileIndex];
 		const int cnt = ed.hopCount, span = ed.nHi - ed.nLo;
-		const size_t carryRow = ((size_t)sg*d.C + c)*(size_t)CL;
-		const float *wpOld = d.carryWp[d.carryCur] + (size_t)sg*CL;
+		const int carryFrom = d.carryBase[d.carryCur][sg];
+		const size_t carryRow = carrySumRow(d, sg, c);
+		const float *wpOld = d.carryWp[d.carryCur] + carryWpRow(d, sg) + carryFrom;
 		const float *wpHead = d.wpHead + (size_t)sg*d.wpHeadLen; // (kEmitProducts; it also writes the new carry's products)
 		float *out = io.out + (size_t)sg*io.outStreamStride + (size_t)c*io.outChannelStride;
-		auto carryAt = [&](int i) { return i < CL ? loadCarrySum(d, d.carryCur, carryRow + i) : 0.0f; };
+		auto carryAt = [&](int i) { return i < CL ? loadCarrySum(d, d.carryCur, carryRow + carryFrom + i) : 0.0f; };
 		auto wpAt = [&](int i) { return i < CL ? wpOld[i] : 1e-30f; };
 		auto place = [&](int n, float sum, float wp) { // output sample n of the call: final, or part of what the next tile starts from
 			if (n < ed.nHi) out[n] = sum/wp;
@@ -959,18 +961,20 @@ __global__ __launch_bounds__(256) void kEmit(DevBatch d, IoArgs io, int sBase, i
 	const int total = span + CL;
 	if (i0 >= total) return;
 	const int B = d.B, I = d.I;
-	const size_t carryRow = ((size_t)sg*d.C + c)*(size_t)CL;
-	const float *carryWpOld = d.carryWp[d.carryCur] + (size_t)sg*CL;
+	const int carryFrom = d.carryBase[d.carryCur][sg];
+	const size_t carryRow = carrySumRow(d, sg, c);
+	const float *carryWpOld = d.carryWp[d.carryCur] + carryWpRow(d, sg) + carryFrom;
+	if (i0 == 0 && c == 0) d.carryBase[d.carryCur ^ 1][sg] = 0; // the new carry is written from the front of its rows
 	float sum[4], wp[4];
 	if (i0 + 3 < CL && !d.halfState) {
-		const float4 a = *reinterpret_cast<const float4 *>(d.carrySum[d.carryCur] + carryRow + i0), b = *reinterpret_cast<const float4 *>(carryWpOld + i0);
+		const float4 a = *reinterpret_cast<const float4 *>(d.carrySum[d.carryCur] + carryRow + carryFrom + i0), b = *reinterpret_cast<const float4 *>(carryWpOld + i0);
 		sum[0] = a.x; sum[1] = a.y; sum[2] = a.z; sum[3] = a.w;
 		wp[0] = b.x; wp[1] = b.y; wp[2] = b.z; wp[3] = b.w;
 	} else {
 #pragma unroll
 		for (int j = 0; j < 4; ++j) {
 			const int i = i0 + j;
-			sum[j] = (i < CL) ? loadCarrySum(d, d.carryCur, carryRow + i) : 0.0f;
+			sum[j] = (i < CL) ? loadCarrySum(d, d.carryCur, carryRow + carryFrom + i) : 0.0f;
 			wp[j] = (i < CL) ? carryWpOld[i] : 1e-30f;
 		}
 	}
@@ -1029,10 +1033,30 @@ __global__ __launch_bounds__(256) void kEmit(DevBatch d, IoArgs io, int sBase, i
 				out[i] = sum[j]/wp[j];
 			} else if (i < total) {
 				storeCarrySum(d, d.carryCur ^ 1, carryRow + (i - span), sum[j]);
-				if (c == 0) d.carryWp[d.carryCur ^ 1][(size_t)sg*CL + (i - span)] = wp[j];
+				if (c == 0) d.carryWp[d.carryCur ^ 1][carryWpRow(d, sg) + (i - span)] = wp[j];
 			}
 		}
 	}
+}
+
+// A call in which no stream fires a hop (most quanta of the 128-frame real-time pattern): its output is the front of the carried sums over
+// their window products -- kEmit's quotient -- and the carry that is left BEGINS LATER in the same rows instead of being copied
+// (B+I entries per row and call otherwise).  One workgroup per stream, so nobody reads the window's beginning while it moves.
+__global__ __launch_bounds__(256) void kEmitCarried(DevBatch d, IoArgs io) {
+	const int sg = blockIdx.x;
+	const EmitDesc ed = d.emit[(size_t)sg*d.emitStride];
+	const int span = ed.nHi - ed.nLo, CL = d.carryLen, from = d.carryBase[d.carryCur][sg];
+	const float *wpRow = d.carryWp[d.carryCur] + carryWpRow(d, sg) + from;
+	for (int c = 0; c < d.C; ++c) {
+		const size_t row = carrySumRow(d, sg, c) + from;
+		float *out = io.out + (size_t)sg*io.outStreamStride + (size_t)c*io.outChannelStride + ed.nLo;
+		for (int i = threadIdx.x; i < span; i += blockDim.x) {
+			const float sum = (i < CL) ? loadCarrySum(d, d.carryCur, row + i) : 0.0f, wp = (i < CL) ? wpRow[i] : 1e-30f;
+			out[i] = sum/wp;
+		}
+	}
+	__syncthreads();
+	if (threadIdx.x == 0) d.carryBase[d.carryCur][sg] = from + span;
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -1127,6 +1151,10 @@ void launchSynthEmit(const DevBatch &d, const IoArgs &io, int sBase, int nStream
 }
 void launchEmit(const DevBatch &d, const IoArgs &io, int sBase, int nStreams, int tileIndex, int maxSpan, hipStream_t st) {
 	hipLaunchKernelGGL(kEmit, dim3(divUp(divUp(maxSpan + d.carryLen, 4), 256), d.C, nStreams), dim3(256), 0, st, d, io, sBase, tileIndex);
+}
+void launchEmitCarried(const DevBatch &d, const IoArgs &io, hipStream_t st) {
+	hipLaunchKernelGGL(kEmitCarried, dim3(d.S), dim3(256), 0, st, d, io);
+	countLaunch(LK_EMIT_CARRIED);
 }
 
 } // namespace smst

@@ -93,6 +93,9 @@ __device__ __forceinline__ void storeCarriedEnergy(const DevBatch &d, size_t i, 
 	if (d.halfState) reinterpret_cast<half_t *>(d.stEnergy)[i] = half_t(__builtin_amdgcn_sqrtf(e));
 	else d.stEnergy[i] = e;
 }
+// rows of the overlap-add carry (DevBatch::carrySum / carryWp): element index of a row's first entry
+__device__ __forceinline__ size_t carrySumRow(const DevBatch &d, int sg, int c) { return ((size_t)sg*d.C + c)*(size_t)d.carryPitch; }
+__device__ __forceinline__ size_t carryWpRow(const DevBatch &d, int sg) { return (size_t)sg*(size_t)d.carryPitch; }
 __device__ __forceinline__ float loadCarrySum(const DevBatch &d, int buf, size_t i) {
 	return d.halfState ? float(reinterpret_cast<const half_t *>(d.carrySum[buf])[i]) : d.carrySum[buf][i];
 }

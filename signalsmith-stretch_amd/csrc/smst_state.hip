@@ -92,17 +92,20 @@ __global__ __launch_bounds__(256) void kResetStreams(DevBatch d, const int *__re
 	if (bits & 1) {
 		// split computation, between two interval boundaries: the samples up to the end of the interval are read from the stashed ring, which
 		// stft.reset() does not touch (:407-415); the real ring -- re-seeded -- begins behind them
-		const int kp = keep ? keep[sg] : 0, cur = d.carryCur;
-		if (i < CL) {
-			const float w = (i < kp) ? d.carryWp[cur][(size_t)sg*CL + i] : seedWp[i - kp];
-			d.carryWp[0][(size_t)sg*CL + i] = w;
-			d.carryWp[1][(size_t)sg*CL + i] = w;
+		// (the engine settles the carry before a reset that keeps samples: the window it reads from begins at the front of its rows, so no
+		// thread reads what another one writes)
+		const int kp = keep ? keep[sg] : 0, cur = d.carryCur, CP = d.carryPitch;
+		if (i < CP) {
+			const float w = (i < kp) ? d.carryWp[cur][carryWpRow(d, sg) + i] : (i < CL ? seedWp[i - kp] : 1e-30f);
+			d.carryWp[0][carryWpRow(d, sg) + i] = w;
+			d.carryWp[1][carryWpRow(d, sg) + i] = w;
 		}
+		if (i == 0) d.carryBase[0][sg] = d.carryBase[1][sg] = 0;
 		for (int c = 0; c < C; ++c) {
-			if (i < CL) {
-				const float v = (i < kp) ? loadCarrySum(d, cur, ((size_t)sg*C + c)*CL + i) : 0.0f;
-				storeCarrySum(d, 0, ((size_t)sg*C + c)*CL + i, v);
-				storeCarrySum(d, 1, ((size_t)sg*C + c)*CL + i, v);
+			if (i < CP) {
+				const float v = (i < kp) ? loadCarrySum(d, cur, carrySumRow(d, sg, c) + i) : 0.0f;
+				storeCarrySum(d, 0, carrySumRow(d, sg, c) + i, v);
+				storeCarrySum(d, 1, carrySumRow(d, sg, c) + i, v);
 			}
 			if (i < HL) { // (the whole row: the window returns to its front)
 				d.hist[((size_t)sg*C + c)*d.histPitch + i] = 0.0f;
@@ -163,7 +166,7 @@ __global__ __launch_bounds__(64) void kFlushTail(DevBatch d, IoArgs io, const in
 	if (tail < 0) return; // stream not part of this flush
 	const int off = tailOffset[sg]; // where the L1 read position sits relative to our carry (split mode: I - samplesSinceLast)
 	const int CL = d.carryLen, B = d.B;
-	float *wpRow = d.carryWp[d.carryCur] + (size_t)sg*CL;
+	float *wpRow = d.carryWp[d.carryCur] + carryWpRow(d, sg); // (settled by the engine: the window begins at the front of its rows)
 	if (threadIdx.x == 0) {
 		float mx = 0;
 		for (int i = 0; i < B; ++i) {
@@ -175,7 +178,7 @@ __global__ __launch_bounds__(64) void kFlushTail(DevBatch d, IoArgs io, const in
 	}
 	__syncthreads();
 	for (int c = 0; c < d.C; ++c) {
-		const size_t sumRow = ((size_t)sg*d.C + c)*(size_t)CL;
+		const size_t sumRow = carrySumRow(d, sg, c);
 		float *y = io.out + (size_t)sg*io.outStreamStride + (size_t)c*io.outChannelStride + outOffset[sg];
 		for (int i = threadIdx.x; i < tail; i += blockDim.x) {
 			int a = off + i, r = off + 2*tail - 1 - i;
@@ -195,8 +198,8 @@ __global__ __launch_bounds__(256) void kAddPreRoll(DevBatch d, const float *__re
 	const int idx = offsets[sg] + i;
 	if (idx >= CL) return;
 	const float v = -preRoll[((size_t)sg*d.C + c)*(size_t)length + (length - 1 - i)];
-	const size_t e = ((size_t)sg*d.C + c)*(size_t)CL + idx;
-	storeCarrySum(d, d.carryCur, e, loadCarrySum(d, d.carryCur, e) + v*d.carryWp[d.carryCur][(size_t)sg*CL + idx]);
+	const size_t e = carrySumRow(d, sg, c) + idx; // (settled by the engine: the window begins at the front of its rows)
+	storeCarrySum(d, d.carryCur, e, loadCarrySum(d, d.carryCur, e) + v*d.carryWp[d.carryCur][carryWpRow(d, sg) + idx]);
 }
 
 // Self-test of smst_complex.h (the packed-f32 helpers are inline assembly: their operand selects and negations are checked
@@ -218,7 +221,7 @@ void launchComplexSelfTest(const float *in, float *out, int n, hipStream_t st) {
 static std::atomic<long long> gLaunchCounts[LK_COUNT];
 static const char *const kLaunchNames[LK_COUNT] = {
 	"vocoder_aligned", "vocoder_staged", "vocoder_gather", "vocoder_n", "vocoder_one", "vocoder_across", "chain_unfused",
-	"analyse_teams", "analyse_fast", "analyse_generic", "synth_teams", "synth_fast", "synth_generic", "synth_emit"};
+	"analyse_teams", "analyse_fast", "analyse_generic", "synth_teams", "synth_fast", "synth_generic", "synth_emit", "emit_carried"};
 void countLaunch(LaunchKind k) { gLaunchCounts[k].fetch_add(1, std::memory_order_relaxed); }
 long long launchCount(const char *name) {
 	for (int i = 0; i < LK_COUNT; ++i) if (name && std::strcmp(name, kLaunchNames[i]) == 0) return gLaunchCounts[i].load(std::memory_order_relaxed);
@@ -241,7 +244,7 @@ void launchPassThrough(const DevBatch &d, const IoArgs &io, const int *passFlags
 	hipLaunchKernelGGL(kPassThrough, dim3(bx, d.C, d.S), dim3(256), 0, st, d, io, passFlags);
 }
 void launchResetStreams(const DevBatch &d, const int *flags, int allBits, const float *seedWp, hipStream_t st, const int *keep) {
-	const int span = d.carryLen > d.M ? (d.carryLen > d.histLen ? d.carryLen : d.histLen) : (d.M > d.histLen ? d.M : d.histLen);
+	const int span = d.carryPitch > d.M ? d.carryPitch : d.M; // (carryPitch > histLen)
 	hipLaunchKernelGGL(kResetStreams, dim3(divUp(span, 256), d.S), dim3(256), 0, st, d, flags, allBits, seedWp, keep);
 }
 void launchPendingToTile(const DevBatch &d, int sBase, int nStreams, const float2 *pendIn, const float2 *pendPrev, hipStream_t st) {

@@ -19,6 +19,7 @@
 //   SMST_FEED_SERIAL       unset    set: bin-by-bin feed recurrences (kFeedSerial) instead of the scan form
 //   SMST_FFT_TEAMS         1        0: one frame per workgroup; 2: persistent teams even for tiles with few frames per team (tests)
 //   SMST_SYNTH_EMIT        1        0: kSynthTeams + kEmit; 2: kSynthEmitTeams also for small tiles (tests)
+//   SMST_CARRIED_EMIT      1        0: a call without hops emits through kEmit (which copies the carry) instead of kEmitCarried (cross-check: bit-identical)
 //   SMST_VOCN_WIDE         1        0: kVocoderN's producer passes 16 rows x 4 steps (the first form) instead of 8 rows x 8 steps
 //   SMST_DEBUG_MODE        0        timing experiments; only in builds with -DSMST_EXPERIMENTS
 //   SMST_WORKSPACE_GIB     auto     tile workspace budget per workspace in GiB (a tuning knob, not a cross-check: always read)
@@ -32,7 +33,7 @@ namespace smst {
 
 struct Switches {
 	bool overlap = true, noFuse = false, noSingleHop = false, noAcross = false, checkLaunches = false;
-	int noFeedFusion = 0, fftTeams = 1, synthEmit = 1, debugMode = 0, vocNWide = 1;
+	int noFeedFusion = 0, fftTeams = 1, synthEmit = 1, debugMode = 0, vocNWide = 1, carriedEmit = 1;
 	bool noStage = false, noAlign = false, alignAll = false, noFastFft = false, fftLean = false, feedSerial = false;
 	double workspaceGiB = 0; // 0: automatic
 	int subStreams = 0;      // 0: automatic
@@ -58,6 +59,7 @@ struct Switches {
 		s.feedSerial = set("SMST_FEED_SERIAL");
 		s.fftTeams = num("SMST_FFT_TEAMS", 1);
 		s.synthEmit = num("SMST_SYNTH_EMIT", 1);
+		s.carriedEmit = num("SMST_CARRIED_EMIT", 1);
 		s.vocNWide = num("SMST_VOCN_WIDE", 1);
 #ifdef SMST_EXPERIMENTS
 		s.debugMode = num("SMST_DEBUG_MODE", 0);

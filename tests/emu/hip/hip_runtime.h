@@ -103,6 +103,7 @@ enum hipDeviceAttribute_t { hipDeviceAttributeMultiprocessorCount };
 static inline hipError_t hipDeviceGetAttribute(int *v, hipDeviceAttribute_t, int) { *v = 8; return 0; } // a small machine: persistent kernels loop over their jobs
 static inline hipError_t hipStreamCreateWithFlags(hipStream_t *s, unsigned) { *s = (hipStream_t)1; return 0; }
 static inline hipError_t hipStreamSynchronize(hipStream_t) { return 0; }
+static inline hipError_t hipDeviceSynchronize() { return 0; }
 static inline hipError_t hipDeviceGetStreamPriorityRange(int *lo, int *hi) { *lo = 0; *hi = 0; return 0; }
 static inline hipError_t hipStreamCreateWithPriority(hipStream_t *s, unsigned, int) { *s = (hipStream_t)1; return 0; }
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
@@ -132,6 +133,10 @@ static inline hipError_t hipFree(void *p) { std::free(p); return 0; }
 static inline hipError_t hipHostMalloc(void **p, size_t n, unsigned) { *p = std::calloc(n ? n : 1, 1); return *p ? 0 : 2; }
 static inline hipError_t hipHostFree(void *p) { std::free(p); return 0; }
 static inline hipError_t hipMemcpy(void *d, const void *s, size_t n, hipMemcpyKind) { std::memcpy(d, s, n); return 0; }
+static inline hipError_t hipMemcpy2D(void *d, size_t dpitch, const void *s, size_t spitch, size_t width, size_t height, hipMemcpyKind) {
+	for (size_t r = 0; r < height; ++r) std::memcpy(static_cast<char *>(d) + r*dpitch, static_cast<const char *>(s) + r*spitch, width);
+	return 0;
+}
 static inline hipError_t hipMemcpyAsync(void *d, const void *s, size_t n, hipMemcpyKind, hipStream_t) { std::memcpy(d, s, n); return 0; }
 static inline hipError_t hipMemset(void *d, int v, size_t n) { std::memset(d, v, n); return 0; }
 static inline hipError_t hipMemsetAsync(void *d, int v, size_t n, hipStream_t) { std::memset(d, v, n); return 0; }

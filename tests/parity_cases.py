@@ -1090,6 +1090,65 @@ def case_synth_emit_equals_two_kernels(lib, monkeypatch, presets=(("cheaper", 48
             assert np.array_equal(outs[0], outs[1]), (preset, sr, split, float(np.abs(outs[0] - outs[1]).max()))
 
 
+def case_carried_emit_equals_copy(lib, monkeypatch, streams=5, channels=2, splits=(False, True), half_state=False):
+    """A call in which no stream fires a hop emits the front of the overlap-add carry and leaves the rest where it is (kEmitCarried: the window's
+    beginning moves); SMST_CARRIED_EMIT=0 sends such calls through kEmit, which copies the carry.  Same quotients: output and carry are
+    bit-identical -- over short calls (37 .. 61 samples; every third stream idle now and then, one a sample short each time, one silent at first: pass-through), with everything
+    that indexes the carry from the front of its rows in between: flush() of some streams (inside a split interval too), outputSeek(), reset(),
+    the debug accessors, a clone."""
+    pkg = package()
+    sr, quanta = 48000, 70
+    for split in splits:
+        outs, carries = [], []
+        for carried in (True, False):
+            monkeypatch.setenv("SMST_CARRIED_EMIT", "1" if carried else "0")
+            count = pkg.launch_count("emit_carried", lib)
+            b = pkg.StretchBatch(streams, channels, block=512, interval=128, split=split, lib=lib, **({"half_state": True} if half_state else {}))
+            b.setTransposeSemitones(3.0, 0.2, stream=1)
+            x = np.stack([synth_input(s, channels, 61*quanta + 2000, sr) for s in range(streams)])
+            x[2, :, :1500] = 0.0   # silent at first: the pass-through streams take nothing from the carry
+            parts, pos = [], 0
+            parts.append(np.array(b.process(np.ascontiguousarray(x[:, :, :700]), 700), copy=True)); pos = 700
+            for k in range(quanta):
+                n = np.array([0 if (s % 3 == 0 and k % 7 == 0) else 37 + (3*k) % 25 - (s == 4) for s in range(streams)], np.int32)
+                y = np.array(b.process(np.ascontiguousarray(x[:, :, pos:pos + 61]), n, in_samples=n), copy=True)
+                pos += 61
+                parts.append(y[:, :, :61] if y.shape[2] >= 61 else np.pad(y, ((0, 0), (0, 0), (0, 61 - y.shape[2]))))
+                if k == 20:
+                    counts = np.array([90 if s % 2 else -1 for s in range(streams)], np.int32)
+                    parts.append(np.array(b.flush(counts), copy=True))
+                if k == 33:
+                    L = b.outputSeekLength(1.0)
+                    b.outputSeek(np.ascontiguousarray(x[:, :, pos:pos + L])); pos += L
+                if k == 41:
+                    sums, prods = b.debug_carry(3)
+                    b.debug_set_carry(3, sums, prods)
+                if k == 58:
+                    b.reset()
+            carries.append([np.concatenate([a.ravel() for a in b.debug_carry(s)]) for s in range(streams)])
+            parts.append(np.array(b.flush(b.outputLatency() + 60), copy=True))
+            b.close()
+            one = pkg.SignalsmithStretch(seed=3, lib=lib)   # ... and a copy made while the window sits inside its rows
+            one.configure(channels, 512, 128, split)
+            parts.append(np.array(one.process(x[0][:, :700], 700), copy=True))
+            for k in range(3):
+                parts.append(np.array(one.process(x[0][:, 700 + 40*k:740 + 40*k], 40), copy=True))
+            twin = one.clone()
+            ya, yb = one.process(x[0][:, 820:1200], 380), twin.process(x[0][:, 820:1200], 380)
+            assert np.array_equal(ya, yb), "the copy diverges"
+            parts.append(np.array(ya, copy=True))
+            one.close(); twin.close()
+            outs.append(parts)
+            grew = pkg.launch_count("emit_carried", lib) - count
+            assert (grew > quanta//4) if carried else (grew == 0), (carried, split, grew)
+        monkeypatch.delenv("SMST_CARRIED_EMIT", raising=False)
+        assert max(float(np.abs(p).max()) for p in outs[0]) > 0.05
+        for i, (p, q) in enumerate(zip(outs[0], outs[1])):
+            assert np.array_equal(p, q), (split, i, float(np.abs(p - q).max()))
+        for s in range(streams):
+            assert np.array_equal(carries[0][s], carries[1][s]), (split, s)
+
+
 def case_clone(lib):
     """smst_clone (the drop-in's copy constructor): the copy continues exactly as the original does, and independently of it."""
     pkg = package()

@@ -155,6 +155,10 @@ def test_across_equals_single_hop_emu(emu, monkeypatch):
     pc.case_across_equals_single_hop(emu, monkeypatch, streams=5, channel_counts=(2,), setup=lambda b: b.setTransposeSemitones(5, 0.2))
 
 
+def test_carried_emit_equals_copy_emu(emu, monkeypatch):
+    pc.case_carried_emit_equals_copy(emu, monkeypatch)
+
+
 def test_random_call_sequences_emu(emu, ref):
     pc.case_random_call_sequences(emu, ref, seeds=range(6))
 

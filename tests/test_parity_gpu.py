@@ -619,6 +619,11 @@ def test_split_events_vs_checker(hip, ref):
     _report("split_events_vs_checker/cheaper48k", pc.case_split_events_vs_checker(hip, ref, channels=2, cfg=dict(preset="cheaper", sample_rate=48000.0)))
 
 
+def test_carried_emit_equals_copy(hip, monkeypatch):
+    pc.case_carried_emit_equals_copy(hip, monkeypatch, streams=37)
+    pc.case_carried_emit_equals_copy(hip, monkeypatch, streams=5, splits=(True,), half_state=True)
+
+
 def test_across_equals_single_hop(hip, monkeypatch):
     pc.case_across_equals_single_hop(hip, monkeypatch, streams=300)
     pc.case_across_equals_single_hop(hip, monkeypatch, streams=5, channel_counts=(2,), setup=lambda b: b.setTransposeSemitones(5, 0.2))

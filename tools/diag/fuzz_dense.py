@@ -9,7 +9,7 @@ import importlib
 pkg = importlib.import_module("signalsmith-stretch_amd")
 import ref_oracle, parity_cases as pc
 from conftest import synth_input
-lib = pkg.bind(ctypes.CDLL(os.path.join(ROOT, "tests", "emu", "libsmst_emu.so"))) if os.environ.get("SMST_FUZZ_EMU") else pkg.load_library()
+lib = pkg.bind(ctypes.CDLL(os.environ.get("SMST_EMU_LIBRARY", os.path.join(ROOT, "tests", "emu", "libsmst_emu.so")))) if os.environ.get("SMST_FUZZ_EMU") else pkg.load_library()
 lo, hi, split = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3] in ("split", "cheaper48")
 cfg = dict(preset="cheaper", sample_rate=48000.0) if sys.argv[3] == "cheaper48" else (pc.SMALL_SPLIT if split else pc.SMALL)  # cheaper48: presetCheaper at 48 kHz (split computation, interval 1920)
 q = 15 if sys.argv[3] == "cheaper48" else 1  # sample counts are written for an interval of 128
