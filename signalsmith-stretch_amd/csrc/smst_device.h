@@ -122,7 +122,7 @@ enum LaunchKind {
 };
 long long launchCount(const char *name); // -1: unknown name
 
-void launchEnergy(const DevBatch &d, const IoArgs &io, int sBase, int nStreams, float *energyOut, hipStream_t st);
+void launchEnergy(const DevBatch &d, const IoArgs &io, int sBase, int nStreams, int maxSamples, float *energyOut, hipStream_t st);
 void launchAnalyse(const DevBatch &d, const IoArgs &io, int sBase, int nStreams, int hopBase, int tileHops, bool anyInCall, bool anyLate, hipStream_t st);
 bool launchFeed(const DevBatch &d, int sBase, int nStreams, int hopBase, int tileHops, bool anyFormants, hipStream_t st); // true: pass A done too
 void launchPredict(const DevBatch &d, int sBase, int nStreams, int hopBase, int tileHops, bool plain, bool passADone, hipStream_t st);

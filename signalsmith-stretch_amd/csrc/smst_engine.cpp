@@ -1017,20 +1017,21 @@ void Batch::process(const float *in, long long inSS, long long inCS, const int *
 	dInSamples = cs.inSamples; dOutSamples = cs.outSamples; dFlags = cs.flags;
 	const int T = d.T;
 	int *nIn = cs.hInSamples, *nOut = cs.hOutSamples;
-	int maxOut = 0;
+	int maxOut = 0, maxIn = 0;
 	for (int s = 0; s < S; ++s) {
 		bool on = !active || active[s];
 		nIn[s] = on ? inSamples[s] : 0;
 		nOut[s] = on ? outSamples[s] : 0;
 		if (nIn[s] < 0 || nOut[s] < 0) throw Error("negative sample count");
 		maxOut = std::max(maxOut, nOut[s]);
+		maxIn = std::max(maxIn, nIn[s]);
 	}
 	SMST_HIP(hipMemcpyAsync(dInSamples, nIn, S*sizeof(int), hipMemcpyHostToDevice, stGate));
 	SMST_HIP(hipMemcpyAsync(dOutSamples, nOut, S*sizeof(int), hipMemcpyHostToDevice, stGate));
 	IoArgs io{in, out, inSS, inCS, outSS, outCS, dInSamples, dOutSamples};
 
 	// K5: silence gate needs the input energy on the host (one 64-byte-per-stream readback per call)
-	launchEnergy(d, io, 0, S, dEnergy, stGate);
+	launchEnergy(d, io, 0, S, maxIn, dEnergy, stGate);
 	SMST_HIP(hipMemcpyAsync(cs.hEnergy, dEnergy, (size_t)S*kEnergyParts*sizeof(float), hipMemcpyDeviceToHost, stGate));
 	SMST_HIP(hipStreamSynchronize(stGate));
 
@@ -1357,7 +1358,7 @@ void Batch::seek(const float *in, long long inSS, long long inCS, const int *inS
 	// energy of the copied part only (:144-154) = energy over the new history (the zero padding adds nothing)
 	for (int s = 0; s < S; ++s) if (flags[s]) histBase[s] = 0;
 	IoArgs ioE{d.hist, nullptr, (long long)C*d.histPitch, (long long)d.histPitch, 0, 0, dAux0, dOutSamples}; // (the streams that seek: their windows are at the front of the rows now)
-	launchEnergy(d, ioE, 0, S, dEnergy, st);
+	launchEnergy(d, ioE, 0, S, d.histLen, dEnergy, st);
 	SMST_HIP(hipMemcpyAsync(hSeekEnergy, dEnergy, (size_t)S*kEnergyParts*sizeof(float), hipMemcpyDeviceToHost, st));
 	SMST_HIP(hipStreamSynchronize(st));
 	for (int s = 0; s < S; ++s) {

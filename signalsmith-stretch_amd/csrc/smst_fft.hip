@@ -831,8 +831,10 @@ __global__ __launch_bounds__(512) void kSynthEmitTeams(DevBatch d, IoArgs io, in
 // K5: per-stream input energy (silence gate, signalsmith-stretch.h:231-238)
 // ------------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void kEnergy(DevBatch d, IoArgs io, int sBase, float *__restrict__ energyOut) {
-	// grid (stream, part): partial sums, the host adds the kEnergyParts partials of a stream
+	// grid (stream, part): partial sums, the host adds the kEnergyParts partials of a stream (short inputs are launched with fewer parts:
+	// the slots that are left hold zeros)
 	const int s = blockIdx.x, part = blockIdx.y, parts = gridDim.y;
+	if (part == 0 && (int)threadIdx.x >= parts && (int)threadIdx.x < kEnergyParts) energyOut[(size_t)(sBase + s)*kEnergyParts + threadIdx.x] = 0.0f;
 	const int n = io.inSamples[sBase + s];
 	const int lo = (int)((long long)n*part/parts), hi = (int)((long long)n*(part + 1)/parts);
 	float acc = 0;
@@ -851,7 +853,7 @@ __global__ __launch_bounds__(256) void kEnergy(DevBatch d, IoArgs io, int sBase,
 		if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
 		__syncthreads();
 	}
-	if (threadIdx.x == 0) energyOut[(size_t)(sBase + s)*parts + part] = red[0];
+	if (threadIdx.x == 0) energyOut[(size_t)(sBase + s)*kEnergyParts + part] = red[0];
 }
 
 // ------------------------------------------------------------------------------------------------------
@@ -1062,8 +1064,10 @@ __global__ __launch_bounds__(256) void kEmitCarried(DevBatch d, IoArgs io) {
 // ------------------------------------------------------------------------------------------------------
 // host-side launchers
 // ------------------------------------------------------------------------------------------------------
-void launchEnergy(const DevBatch &d, const IoArgs &io, int sBase, int nStreams, float *energyOut, hipStream_t st) {
-	hipLaunchKernelGGL(kEnergy, dim3(nStreams, kEnergyParts), dim3(256), 256*sizeof(float), st, d, io, sBase, energyOut);
+void launchEnergy(const DevBatch &d, const IoArgs &io, int sBase, int nStreams, int maxSamples, float *energyOut, hipStream_t st) {
+	// a part per 1024 samples of the longest input: a 128-frame quantum of 4096 streams is 4096 workgroups, not 65536 (56 -> 8 us)
+	const int parts = std::max(1, std::min(kEnergyParts, maxSamples/1024));
+	hipLaunchKernelGGL(kEnergy, dim3(nStreams, parts), dim3(256), 256*sizeof(float), st, d, io, sBase, energyOut);
 }
 void launchAnalyse(const DevBatch &d, const IoArgs &io, int sBase, int nStreams, int hopBase, int tileHops, bool anyInCall, bool anyLate, hipStream_t st) {
 	const dim3 grid(tileHops, d.C*2, nStreams);
