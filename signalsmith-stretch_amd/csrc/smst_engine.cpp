@@ -149,6 +149,7 @@ void Batch::construct(const FftPlan &plan, long seed) {
 	for (int i = 0; i < 2; ++i) {
 		SMST_HIP(hipEventCreateWithFlags(&evFeed[i], hipEventDisableTiming));
 		SMST_HIP(hipEventCreateWithFlags(&evChain[i], hipEventDisableTiming));
+		SMST_HIP(hipEventCreateWithFlags(&evOut[i], hipEventDisableTiming));
 		SMST_HIP(hipEventCreateWithFlags(&evSynth[i], hipEventDisableTiming));
 	}
 	// the cross-check switches: one struct, one table, read once (smst_switches.h)
@@ -442,8 +443,9 @@ void Batch::releaseAll() {
 	for (int i = 0; i < 2; ++i) {
 		if (evFeed[i]) hipEventDestroy(evFeed[i]);
 		if (evChain[i]) hipEventDestroy(evChain[i]);
+		if (evOut[i]) hipEventDestroy(evOut[i]);
 		if (evSynth[i]) hipEventDestroy(evSynth[i]);
-		evFeed[i] = evChain[i] = evSynth[i] = nullptr;
+		evFeed[i] = evChain[i] = evOut[i] = evSynth[i] = nullptr;
 	}
 	if (stGate) hipStreamDestroy(stGate);
 	if (stChain) hipStreamDestroy(stChain);
@@ -949,6 +951,9 @@ void Batch::runTiles(const TileRun &run) {
 				SMST_HIP(hipEventRecord(evFeed[slot], sF));
 				SMST_HIP(hipStreamWaitEvent(sC, evFeed[slot], 0));
 			}
+			// synthesis + overlap-add + emission in one kernel where the geometry and the batch allow it
+			const bool emitted = th[0] && !th[8] && synthEmitApplies(dd, ns, tileHops); // (th[8]: a hop that began before the call's first sample -- kSynthTeams + kEmit place its frame)
+			const bool earlySynth = emitted || tileHops == 1;
 			if (th[0]) {
 				hipEvent_t liveA = nullptr, liveB = nullptr;
 				if (liveTiming && !serial) {
@@ -969,20 +974,27 @@ void Batch::runTiles(const TileRun &run) {
 					SMST_HIP(hipEventRecord(liveB, sC));
 					liveEvents.emplace_back(liveA, liveB);
 				}
+				// synthesis needs the recurrence's rows only: the hand-over of the tile's last rows to the carried state (two copies at HBM rate --
+				// 250 us of a 4096-stream hop quantum) runs beside it, behind the event synthesis waits for.  Where synthesis is a grid of
+				// per-frame workgroups and more recurrence launches follow (config 5) the hand-over goes first, as before: it is what the NEXT
+				// recurrence waits for, and behind a machine full of synthesis workgroups it would start late (config 5: 99.6 -> 101 ms)
 				timed(timings.otherMs, [&] {
-					if (fused) launchCarryFeed(dd, sBase, ns, hopBase, th[2] != 0, sC);
-					launchCarryOut(dd, sBase, ns, sC);
-					if (run.dSynthChannels) launchMaskOutRows(dd, sBase, ns, run.dSynthChannels, sC);
+					if (run.dSynthChannels || !earlySynth) { // (the carried output state takes the rows as the recurrence left them)
+						launchCarryOut(dd, sBase, ns, sC);
+						if (run.dSynthChannels) launchMaskOutRows(dd, sBase, ns, run.dSynthChannels, sC);
+					}
+					if (!earlySynth && fused) launchCarryFeed(dd, sBase, ns, hopBase, th[2] != 0, sC);
+					if (!serial) SMST_HIP(hipEventRecord(evOut[slot], sC));
+					if (earlySynth && fused) launchCarryFeed(dd, sBase, ns, hopBase, th[2] != 0, sC);
+					if (earlySynth && !run.dSynthChannels) launchCarryOut(dd, sBase, ns, sC);
 				});
 			}
 			checkLaunch("bin recurrence");
-			// synthesis + overlap-add + emission in one kernel where the geometry and the batch allow it; its window products depend on
-			// nothing the recurrence writes: queued in front of the wait for it
-			const bool emitted = th[0] && !th[8] && synthEmitApplies(dd, ns, tileHops); // (th[8]: a hop that began before the call's first sample -- kSynthTeams + kEmit place its frame)
+			// kSynthEmitTeams' window products depend on nothing the recurrence writes: queued in front of the wait for it
 			if (emitted) timed(timings.otherMs, [&] { launchEmitProducts(dd, sBase, ns, t, sS); });
 			if (!serial) {
 				SMST_HIP(hipEventRecord(evChain[slot], sC));
-				SMST_HIP(hipStreamWaitEvent(sS, evChain[slot], 0));
+				SMST_HIP(hipStreamWaitEvent(sS, th[0] ? evOut[slot] : evChain[slot], 0));
 			}
 			if (th[0]) timed(timings.synthMs, [&] {
 				if (emitted) launchSynthEmit(dd, io, sBase, ns, t, sS);

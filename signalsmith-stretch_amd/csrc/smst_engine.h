@@ -139,7 +139,7 @@ private:
 		std::vector<void *> retiredDevice, retiredPinned; // outgrown tables that the previous call may still read
 	} callSets[2]{};
 	int callCur = 0;
-	hipEvent_t evStart = nullptr, evFeed[2] = {nullptr, nullptr}, evChain[2] = {nullptr, nullptr}, evSynth[2] = {nullptr, nullptr};
+	hipEvent_t evStart = nullptr, evFeed[2] = {nullptr, nullptr}, evChain[2] = {nullptr, nullptr}, evOut[2] = {nullptr, nullptr}, evSynth[2] = {nullptr, nullptr};
 	struct TileBuffers { float2 *Xcur, *Xprev, *OUT, *dump, *map, *peaksT; float4 *REC; PredEntry *PE; float *ratio, *energyT, *smoothT, *est, *freqEst, *frames; } slots[2]{};
 	bool overlap = true, noFuse = false, noSingleHop = false, noAcross = false, carriedEmit = true; // (smst_switches.h)
 	double workspaceGiB = 0;
