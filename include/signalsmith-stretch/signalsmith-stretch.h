@@ -131,24 +131,19 @@ struct SignalsmithStretch {
 #endif
 		gather(inputs, inputSamples, 0);
 		prepareOut(outputSamples);
-		// The reference announces every step of a block (STEP(step, steps)) and closes it (ENDSTEP), :327-404.  Here a call's device work
-		// is ONE asynchronous submission: it is attributed to step 0, and the block's remaining steps -- counted exactly as the reference
-		// counts them for this block (smst_block_steps) -- are announced after it, so that a harness that sizes its per-step tables from
-		// `steps` (cmd/main-dev.cpp:44-52) sees the reference's step count.
-#ifdef SIGNALSMITH_STRETCH_PROFILE_PROCESS_STEP
-		{
-			const int before = smst_block_steps(h());
-			SIGNALSMITH_STRETCH_PROFILE_PROCESS_STEP(size_t(0), size_t(before > 0 ? before : 1));
-		}
-#endif
+		// The reference announces every step of a block (STEP(step, steps)) and closes it (ENDSTEP) as the steps run, interleaved with the
+		// output samples (:327-404).  Here a call's device work is ONE asynchronous submission, so the per-step attribution is SYNTHETIC:
+		// after the call, and only if a block began in it (smst_blocks_started), every step of the newest block is announced and closed at
+		// once with ONE count -- the reference's own for that block's flags and channel count (smst_block_steps) -- so that a harness
+		// which sizes its per-step tables from `steps` (cmd/main-dev.cpp:44-52) sees consistent values.  The call's time lies between
+		// START and the first STEP; a call that began several blocks still reports one (the newest); a call that began none reports none.
 		check(smst_process(h(), inPtrs.data(), inputSamples, outPtrs.data(), outputSamples));
-#ifdef SIGNALSMITH_STRETCH_PROFILE_PROCESS_ENDSTEP
-		SIGNALSMITH_STRETCH_PROFILE_PROCESS_ENDSTEP();
-#endif
 #if defined(SIGNALSMITH_STRETCH_PROFILE_PROCESS_STEP) && defined(SIGNALSMITH_STRETCH_PROFILE_PROCESS_ENDSTEP)
-		for (int step = 1, steps = smst_block_steps(h()); step < steps; ++step) {
-			SIGNALSMITH_STRETCH_PROFILE_PROCESS_STEP(size_t(step), size_t(steps));
-			SIGNALSMITH_STRETCH_PROFILE_PROCESS_ENDSTEP();
+		if (smst_blocks_started(h()) > 0) {
+			for (int step = 0, steps = smst_block_steps(h()); step < steps; ++step) {
+				SIGNALSMITH_STRETCH_PROFILE_PROCESS_STEP(size_t(step), size_t(steps));
+				SIGNALSMITH_STRETCH_PROFILE_PROCESS_ENDSTEP();
+			}
 		}
 #endif
 		scatter(outputs, outputSamples);

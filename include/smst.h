@@ -108,6 +108,10 @@ int smst_split_computation(const smst_stretch *h);
  * synthesis steps as the reference counts them for this block's flags and channel count); 0 before the first block.  The C++ drop-in
  * header reports it through the reference's SIGNALSMITH_STRETCH_PROFILE_PROCESS_STEP(step, steps) hook (:329-331). */
 int smst_block_steps(const smst_stretch *h);
+/* Number of blocks that BEGAN in the most recent smst_process() call (the `blockProcess.samplesSinceLast >= interval` branch,
+ * signalsmith-stretch.h:281, taken that many times); 0 for a call that only emitted samples of a block already under way.  The drop-in
+ * header announces steps through the reference's profiling hooks only for calls in which a block began. */
+int smst_blocks_started(const smst_stretch *h);
 int smst_seek_length(const smst_stretch *h);
 int smst_output_seek_length(const smst_stretch *h, float playbackRate);
 

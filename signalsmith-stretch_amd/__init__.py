@@ -50,6 +50,7 @@ _SIGNATURES = {
     "smst_output_latency": (C.c_int, [C.c_void_p]),
     "smst_split_computation": (C.c_int, [C.c_void_p]),
     "smst_block_steps": (C.c_int, [C.c_void_p]),
+    "smst_blocks_started": (C.c_int, [C.c_void_p]),
     "smst_seek_length": (C.c_int, [C.c_void_p]),
     "smst_output_seek_length": (C.c_int, [C.c_void_p, C.c_float]),
     "smst_reset": (C.c_int, [C.c_void_p]),

@@ -284,7 +284,10 @@ int smst_create(smst_stretch **out, long seed, int device) {
 	SMST_TRY
 	int n = 0;
 	if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) throw smst::Error("hipGetDeviceCount: no HIP device available (the gfx950 path has no CPU fallback)", true);
-	if (device < 0 || device >= n) throw smst::Error(g_defaultDeviceError.empty() ? std::string("device ordinal out of range") : g_defaultDeviceError);
+	// (the SMST_DEVICE message only for the sentinel smst_default_device() returns when the variable named no device: an explicit ordinal
+	// that is out of range has nothing to do with the default device)
+	if (device == -1 && !g_defaultDeviceError.empty()) throw smst::Error(g_defaultDeviceError);
+	if (device < 0 || device >= n) throw smst::Error("device ordinal " + std::to_string(device) + " out of range: this process sees " + std::to_string(n) + " device(s)");
 	smst_stretch *h = new smst_stretch();
 	h->seed = seed;
 	h->device = device;
@@ -381,6 +384,7 @@ STRETCH_Q(smst_input_latency, e.inputLatency())
 STRETCH_Q(smst_output_latency, e.outputLatency())
 STRETCH_Q(smst_split_computation, e.splitComputation() ? 1 : 0)
 STRETCH_Q(smst_block_steps, e.lastBlockSteps(0))
+STRETCH_Q(smst_blocks_started, e.lastCallBlocks(0))
 STRETCH_Q(smst_seek_length, e.seekLength())
 int smst_output_seek_length(const smst_stretch *h, float rate) { if (!h || !h->batch) return fail("unconfigured handle"); return h->batch->engine->outputSeekLength(rate); }
 

@@ -63,7 +63,7 @@ struct DevBatch {
 	// findPeaks (:874), updateFormants step 0 (:982-983) and step 2 (:1020-1021) of the block in flight may each see other values.  In every
 	// other launch the three point at `params`.
 	const StreamParams *paramsPeaks, *paramsForm0, *paramsForm2;
-	const float *mapTable;            // [S][mapTableLen] custom frequency maps (table form of setFreqMap)
+	const float *mapTable;            // [S][kMapSlots][mapTableLen] custom frequency maps (table form of setFreqMap; StreamParams.mapSlot selects the row)
 	// per-call tables
 	const HopDesc *hops;   // [S][hopStride]
 	const EmitDesc *emit;  // [S][emitStride]

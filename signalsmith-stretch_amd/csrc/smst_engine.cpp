@@ -384,6 +384,7 @@ void Batch::construct(const FftPlan &plan, long seed) {
 	allocateWorkspace();
 	pend.assign(S, PendingBlock());
 	lastSteps.assign(S, 0);
+	lastStarts.assign(S, 0);
 	histBase.assign(S, 0);
 	carryBase.assign(S, 0);
 	keepV.assign(S, 0);
@@ -396,7 +397,8 @@ void Batch::construct(const FftPlan &plan, long seed) {
 		const int nSub = (S + subS - 1)/subS;
 		for (int i = 0; i < 2; ++i) {
 			PendSet &ps = pendSets[i];
-			ps.hops = devAlloc<HopDesc>(S); ps.hHops = pinnedAlloc<HopDesc>(S);
+			ps.hops = devAlloc<HopDesc>(S + kTileHops); ps.hHops = pinnedAlloc<HopDesc>(S); // (+ a tile's worth: the wavefront kernels cache a blind row of 64 descriptors per stream, hopStride 1)
+			SMST_HIP(hipMemset(ps.hops, 0, (size_t)(S + kTileHops)*sizeof(HopDesc)));
 			ps.emit = devAlloc<EmitDesc>(S); ps.hEmit = pinnedAlloc<EmitDesc>(S);
 			ps.tileInfo = devAlloc<int>((size_t)nSub*2*subS); ps.hTileInfo = pinnedAlloc<int>((size_t)nSub*2*subS);
 			ps.bits = devAlloc<int>(S); ps.hBits = pinnedAlloc<int>(S);
@@ -564,6 +566,7 @@ void Batch::reset() { // signalsmith-stretch.h:49-60
 	resetStreams(nullptr, 1 | 2 | 4 | 8);
 	for (auto &lh : lastHop) lh = LastHop();
 	std::fill(lastSteps.begin(), lastSteps.end(), 0);
+	std::fill(lastStarts.begin(), lastStarts.end(), 0);
 	d.histCur = 0;
 	d.carryCur = 0;
 	for (int s = 0; s < S; ++s) {
@@ -609,8 +612,10 @@ void Batch::setFormantBase(int stream, float baseFreq) { // :133-135
 	paramsDirty = true;
 }
 void Batch::setFreqMapTable(int stream, const float *table, int n) { // table form of :120-122
-	// (split computation: the table itself is not snapshotted -- a block in flight whose findPeaks has already run keeps its flag and
-	// length but would read the NEW knots in updateFormants' step 2; the reference's std::function is replaced as a whole, :120-122)
+	// Split computation: the steps of a block in flight that have already run keep the map they saw -- flag, length AND knots: every stream
+	// has kMapSlots table rows, StreamParams.mapSlot names the live one, and a new table goes to a row that neither findPeaks' (:874) nor
+	// updateFormants step 2's (:1020) latched parameters of the block in flight refer to (freezePendingParams).  The reference replaces its
+	// std::function as a whole (:120-122): a step that ran before the call evaluated the old function, a step that runs after it the new one.
 	forStreams(S, stream, [&](int s) { freezePendingParams(s); });
 	if (n <= 0 || !table) {
 		forStreams(S, stream, [&](int s) { params[s].hasCustomMap = 0; });
@@ -625,27 +630,36 @@ void Batch::setFreqMapTable(int stream, const float *table, int n) { // table fo
 	// seen so far -- a longer table makes the array grow and the existing rows are copied as they are.  (Rounds 2-3 re-evaluated the
 	// stored rows on the longer table's grid, which cuts the corner at every old knot: a stream's map could change because ANOTHER
 	// stream was given a longer table.)  When no stream holds a table any more the next one starts afresh.
+	auto latched = [&](int s, int slot) { // a step of the stream's block in flight ran with the table in this row
+		if (!split || !pend[s].valid) return false;
+		const PendingBlock &pb = pend[s];
+		return (pb.frozenPeaks && pb.peaks.hasCustomMap && pb.peaks.mapSlot == slot) || (pb.frozenForm2 && pb.form2.hasCustomMap && pb.form2.mapSlot == slot);
+	};
 	bool anyCustom = false;
-	for (int s = 0; s < S; ++s) anyCustom = anyCustom || params[s].hasCustomMap;
+	for (int s = 0; s < S; ++s) {
+		anyCustom = anyCustom || params[s].hasCustomMap;
+		for (int slot = 0; slot < kMapSlots; ++slot) anyCustom = anyCustom || latched(s, slot);
+	}
 	if (!anyCustom) d.mapTableLen = 0;
 	if (n > d.mapTableLen) {
-		std::vector<float> grown((size_t)S*n, 0.0f);
-		for (int s = 0; s < S && d.mapTableLen > 0; ++s) {
-			if (!params[s].hasCustomMap) continue;
-			std::copy(hostMapTable.begin() + (size_t)s*d.mapTableLen, hostMapTable.begin() + (size_t)s*d.mapTableLen + params[s].mapLen, grown.begin() + (size_t)s*n);
-		}
+		std::vector<float> grown((size_t)S*kMapSlots*n, 0.0f);
+		for (size_t row = 0; row < (size_t)S*kMapSlots && d.mapTableLen > 0; ++row) // (rows that hold no table are zeros either way)
+			std::copy(hostMapTable.begin() + row*d.mapTableLen, hostMapTable.begin() + (row + 1)*d.mapTableLen, grown.begin() + row*n);
 		SMST_HIP(hipStreamSynchronize(st)); // kernels of earlier calls may still read the old array
 		if (dMapTable) devFree(dMapTable);
-		dMapTable = devAlloc<float>((size_t)S*n);
+		dMapTable = devAlloc<float>((size_t)S*kMapSlots*n);
 		hostMapTable.swap(grown);
 		d.mapTableLen = n;
 		d.mapTable = dMapTable;
 	}
 	const int pitch = d.mapTableLen;
 	forStreams(S, stream, [&](int s) {
-		std::copy(table, table + n, hostMapTable.begin() + (size_t)s*pitch);
+		int slot = 0;
+		while (slot < kMapSlots - 1 && latched(s, slot)) ++slot; // at most two rows are latched: one is always free
+		std::copy(table, table + n, hostMapTable.begin() + ((size_t)s*kMapSlots + slot)*pitch);
 		params[s].hasCustomMap = 1;
 		params[s].mapLen = n;
+		params[s].mapSlot = slot;
 	});
 	SMST_HIP(hipStreamSynchronize(st)); // kernels of earlier calls may still read the old table
 	SMST_HIP(hipMemcpy(dMapTable, hostMapTable.data(), hostMapTable.size()*sizeof(float), hipMemcpyHostToDevice));
@@ -963,10 +977,12 @@ void Batch::runTiles(const TileRun &run) {
 					SMST_HIP(hipEventRecord(liveA, sC));
 				}
 				timed(timings.chainMs, [&] {
-					// (th[7]: a block that a flush() interrupted inside its main prediction -- only kVocoderOne knows HopDesc.startBin)
+					// (th[7]: a block that a flush() interrupted inside its main prediction, HopDesc.startBin > 0.  Every form that forms its
+					// records through computeRecord honours it (all-zero records below the start bin); the staged / line-aligned producers of
+					// kVocoder do not go through it, so such a tile takes the gathering form -- `bounded` false)
 					if (fused && tileHops == 1 && singleHop && !noAcross && acrossSupported(dd) && !th[7]) launchVocoderAcross(dd, sBase, ns, hopBase, plain, sC);
 					else if (fused && tileHops == 1 && singleHop) launchVocoderOne(dd, sBase, ns, hopBase, plain, sC);
-					else if (fused) launchVocoder(dd, sBase, ns, hopBase, plain, !th[4], sC);
+					else if (fused) launchVocoder(dd, sBase, ns, hopBase, plain, !th[4] && !th[7], sC);
 					else launchChain(dd, sBase, ns, hopBase, sC);
 					if (profiling) ++timings.chainLaunches;
 				});
@@ -1088,6 +1104,7 @@ void Batch::process(const float *in, long long inSS, long long inCS, const int *
 		const int first = (sc.samplesSinceLast >= size_t(I)) ? 0 : int(size_t(I) - sc.samplesSinceLast);
 		hopFirst[s] = first;
 		const int starts = (nOut[s] > first) ? (nOut[s] - first + I - 1)/I : 0; // blocks that begin in this call (:281)
+		lastStarts[s] = starts;
 		if (split) {
 			// split computation: a block is finished when its interval is (:321-325).  The block in flight from earlier calls runs now if
 			// this call reaches the end of its interval; the last block that begins here stays in flight unless its interval ends here too
@@ -1549,13 +1566,15 @@ void Batch::copyStateFrom(Batch &o) {
 	params = o.params;
 	paramsDirty = true;
 	pend = o.pend;
+	lastSteps = o.lastSteps; // smst_block_steps of a clone = the original's newest block
+	lastStarts = o.lastStarts;
 	if (split) {
 		copy(dPendIn, o.dPendIn, (size_t)S*C*d.Mp*sizeof(float2));
 		copy(dPendPrev, o.dPendPrev, (size_t)S*C*d.Mp*sizeof(float2));
 	}
 	if (o.d.mapTableLen > 0) {
 		if (dMapTable) devFree(dMapTable);
-		dMapTable = devAlloc<float>((size_t)S*o.d.mapTableLen);
+		dMapTable = devAlloc<float>((size_t)S*kMapSlots*o.d.mapTableLen);
 		hostMapTable = o.hostMapTable;
 		SMST_HIP(hipMemcpy(dMapTable, hostMapTable.data(), hostMapTable.size()*sizeof(float), hipMemcpyHostToDevice));
 		d.mapTableLen = o.d.mapTableLen;

@@ -100,6 +100,7 @@ public:
 	void signalStream(hipStream_t other);
 	int subBatchStreams() const { return subS; }
 	int lastBlockSteps(int stream) const { return (stream >= 0 && stream < S) ? lastSteps[stream] : 0; } // blockProcess.steps of the stream's newest block (:284-318)
+	int lastCallBlocks(int stream) const { return (stream >= 0 && stream < S) ? lastStarts[stream] : 0; } // blocks that began in the stream's most recent process() (:281)
 	// the object is copyable in the reference (a plain struct, signalsmith-stretch.h:34-35): same geometry required; every piece of
 	// carried state, the parameters and the scheduler state of `other` replace this batch's
 	void copyStateFrom(Batch &other);
@@ -158,7 +159,7 @@ private:
 	std::vector<StreamParams> params;
 	bool paramsDirty = true;
 	// ---- split computation: the block in flight (see PendingBlock) ----
-	std::vector<int> lastSteps;
+	std::vector<int> lastSteps, lastStarts;
 	std::vector<int> carryBase; // the host's copy of DevBatch::carryBase[carryCur]
 	EmitDesc *dZeroEmit = nullptr;
 	std::vector<int> histBase;  // the host's copy of DevBatch::histBase (where each stream's input-history window begins)

@@ -19,7 +19,7 @@ __device__ __forceinline__ const float2 *prevRow(const DevBatch &d, const HopDes
 
 __device__ __forceinline__ float mapFreqDev(const DevBatch &d, const StreamParams &p, int sGlobal, float freq) { // :850-856
 	if (p.hasCustomMap) {
-		const float *t = d.mapTable + (size_t)sGlobal*d.mapTableLen; // row pitch: the longest table of the batch
+		const float *t = d.mapTable + ((size_t)sGlobal*kMapSlots + p.mapSlot)*d.mapTableLen; // row pitch: the longest table of the batch
 		const int n = p.mapLen;                                      // this stream's own knots
 		float pos = freq*2*float(n) - 0.5f;
 		if (pos <= 0) return t[0] + (t[1] - t[0])*pos;
@@ -301,6 +301,11 @@ __device__ __forceinline__ float2 twistFinish(const DevBatch &d, const PrevEnerg
 template <int CH, bool PLAIN, bool LOCK, bool SPEC, int NFLOATS, bool ROT_LDS = false, bool FOLD0 = false>
 __device__ __forceinline__ void computeRecord(const DevBatch &d, const HopDesc &hd, const HopDesc &hp, int s, int sg, int k, int b, float (&f)[NFLOATS],
                                               const float2 *rotLds = nullptr) {
+	// Split computation: a flush() between two chunks of this block's main prediction zeroed the bins the earlier chunks had computed
+	// (:458-463) and the later chunks started from those zeros (HopDesc.startBin; 0 in every other hop).  An all-zero record gives
+	// exactly zero in every recurrence kernel (outputs and history alike) -- so the bins below startBin keep the zeros the caller put
+	// into `f`, and kVocoder's gathering form, kVocoderN, kVocoderOne, ACROSS and kPredictB + kChain all honour it the same way.
+	if (b < hd.startBin) return;
 	const float2 *rot;
 	if constexpr (ROT_LDS) rot = rotLds; else rot = d.rot;
 	const int M = d.M, L = d.L;

@@ -55,7 +55,10 @@ struct StreamParams {
 	int formantCompensation;  // :127
 	int hasCustomMap;         // :120 (table form)
 	int mapLen;               // points of this stream's table (the batch's array has one row pitch: the longest table's length)
+	int mapSlot;              // which of the stream's kMapSlots table rows holds them: a new table goes to a row that no step of a split-computation
+	                          // block in flight has latched (Batch::setFreqMapTable), as the reference's std::function is replaced as a whole (:120-122)
 };
+constexpr int kMapSlots = 3; // findPeaks' table (:874) + updateFormants step 2's (:1020) of the block in flight + the live one
 
 // fp16 storage of the carried state (opt-in per batch): fp32 <-> half conversions only, no half arithmetic
 typedef _Float16 half_t;

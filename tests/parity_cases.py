@@ -1229,11 +1229,24 @@ def case_split_mid_interval_flush(lib, ref):
     interval is complete, or as far as a flush() needs it (smst_engine.h: PendingBlock): every offset agrees with the reference,
     in the flushed tail AND in what process() returns afterwards.  (Rounds 1-4 completed the block at the interval's first sample
     and pinned the resulting deviation here: 0.05 .. 1.0 of the tail at interior offsets.)"""
-    C, sr = 2, 48000
+    return _split_mid_interval_flush(lib, ref, 2, SMALL_SPLIT, (0, 1, 5, 32, 54, 55, 64, 100, 115, 116, 121, 122, 127))
+
+
+def case_split_mid_interval_flush_wide(lib, ref, channels=2, block=768, offsets=(54, 100, 104, 108, 112, 116, 121)):
+    """The same where the single-hop kernel does not apply (a vertical step round(fft/interval) outside 2..5 --
+    block 768 / 896 / 1024 at interval 128 give 6 / 7 / 8 -- or SMST_NO_SINGLE_HOP): the block in flight then runs through the
+    wavefront kernels, whose records honour HopDesc.startBin (computeRecord) -- until round 6 only kVocoderOne did, and a flush
+    between two chunks of the main prediction (offsets 100..116 here) left 0.47 of the next process() wrong."""
+    return _split_mid_interval_flush(lib, ref, channels, dict(preset="configure", block=block, interval=128, split=True), offsets, long_flush=False)
+
+
+def _split_mid_interval_flush(lib, ref, C, cfg, offsets, long_flush=True):
+    sr = 48000
+    SMALL_SPLIT = cfg
     x = synth_input(0, C, 12000, sr)
     I = 128
     figures = {}
-    for offset in (0, 1, 5, 32, 54, 55, 64, 100, 115, 116, 121, 122, 127):
+    for offset in offsets:
         g, r = make("product", lib, ref, C, SMALL_SPLIT), make("ref", lib, ref, C, SMALL_SPLIT)
         nout = 55*I + offset
         a, b = g.process(x[:, :6000], nout), r.process(x[:, :6000], nout)
@@ -1243,6 +1256,8 @@ def case_split_mid_interval_flush(lib, ref):
         level = float(np.sqrt(np.mean(np.square(b, dtype=np.float64))))
         figures[offset] = (rel_rms(fa, fb), float(np.sqrt(np.mean(np.square(np.asarray(pa, np.float64) - pb))))/level)
     assert all(f < 1e-4 and after < 1e-4 for f, after in figures.values()), figures
+    if not long_flush:
+        return {k: ("%.1e" % v[0], "%.1e" % v[1]) for k, v in figures.items()}
     # a flush longer than one interval finishes the block first (it runs process() on silence, :439-440), from any offset
     g, r = make("product", lib, ref, C, SMALL_SPLIT), make("ref", lib, ref, C, SMALL_SPLIT)
     g.process(x[:, :6000], 55*I + 40), r.process(x[:, :6000], 55*I + 40)
@@ -1273,6 +1288,40 @@ def case_split_events_golden(lib, ref, geometry):
         kind = name.rsplit("_", 1)[0]
         worst[kind] = max(worst.get(kind, 0.0), max(e["after"]))
     return {k: "%.1e" % v for k, v in worst.items()}
+
+
+def case_split_freq_map_mid_interval(lib, ref, channels=2, cfg=SMALL_SPLIT, offsets=(3, 40, 46, 47, 52, 56, 57, 61, 70, 100)):
+    """setFreqMap between two interval boundaries in split-computation mode (signalsmith-stretch.h:120-122 replaces the std::function as a
+    whole): findPeaks (:874) of the block in flight evaluates the OLD map if it ran before the call, updateFormants step 2 (:1020, with
+    formant compensation) the NEW one if it runs after it.  The product keeps up to three table rows per stream and a step's latched
+    parameters name the row it saw (StreamParams.mapSlot) -- until round 6 the knots were shared, and a findPeaks that had run with
+    table A was re-run at the interval's end on table B's knots.  The WASM ABI has no setFreqMap: against oracle/_ref, whose step
+    partition the split_events fixtures pin.  A second change inside the same interval (a third table) exercises the third row."""
+    sr = 48000
+    I = make("ref", lib, ref, channels, cfg).intervalSamples()
+    x = synth_input(0, channels, 9000, sr) + 0.3*synth_input(3, channels, 9000, sr)
+    n = 64
+    grid = (np.arange(n) + 0.5)/(2*n)
+    table_a = (grid*1.26).astype(np.float32)                                   # +4 semitones
+    table_b = np.where(grid < 0.1, grid*0.84, 0.084 + (grid - 0.1)).astype(np.float32)  # -3 semitones below 0.1, then parallel
+    table_c = (grid*1.06 + 0.002).astype(np.float32)
+    figures = {}
+    for off in offsets:
+        def play(o, xx=x, off=off):
+            o.setFormantFactor(1.1, True)
+            o.setFreqMapTable(table_a)
+            outs = [o.process(xx[:, :1500], 8*I + off)]
+            o.setFreqMapTable(table_b)
+            outs.append(o.process(xx[:, 1500:1510], 6))
+            o.setFreqMapTable(table_c)
+            outs.append(o.process(xx[:, 1510:1510 + 3*I], 3*I))
+            return np.concatenate(outs, axis=1)
+        g, r = make("product", lib, ref, channels, cfg), make("ref", lib, ref, channels, cfg)
+        y, o = np.asarray(play(g)), play(r)
+        o2 = [play(make("ref", lib, ref, channels, cfg), xx=perturbed(x, k)) for k in SELF_SEEDS]
+        assert_parity(y, o, o2, I, "freq map at %d" % off, cap=CAP_FORMANT)
+        figures[off] = rel_rms(y, o)
+    return {k: "%.1e" % v for k, v in figures.items()}
 
 
 def case_split_events_vs_checker(lib, ref, channels=3, cfg=SMALL_SPLIT):

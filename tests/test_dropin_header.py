@@ -121,3 +121,51 @@ def test_moved_from_objects_stay_usable(emu, tmp_path):
     assert r.returncode == 0, r.stderr[-3000:]
     r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, (r.returncode, r.stdout, r.stderr[-2000:])
+
+
+PROFILE_HOOKS = textwrap.dedent(r'''
+    #include <cstdio>
+    #include <cstddef>
+    #include <vector>
+    // what a harness like cmd/main-dev.cpp:12-58 sees: per call, the (step, steps) pairs and whether every STEP was closed
+    static std::vector<std::pair<size_t, size_t>> seen;
+    static int opened = 0, closed = 0, started = 0, ended = 0;
+    #define SIGNALSMITH_STRETCH_PROFILE_PROCESS_START(inputSamples, outputSamples) (++started, seen.clear())
+    #define SIGNALSMITH_STRETCH_PROFILE_PROCESS_STEP(step, count) (++opened, seen.emplace_back(size_t(step), size_t(count)))
+    #define SIGNALSMITH_STRETCH_PROFILE_PROCESS_ENDSTEP() (++closed)
+    #define SIGNALSMITH_STRETCH_PROFILE_PROCESS_END() (++ended)
+    #include "signalsmith-stretch/signalsmith-stretch.h"
+    using Stretch = signalsmith::stretch::SignalsmithStretch<float>;
+    static bool consistent() { // ONE count per call, steps 0 .. count-1 in order
+        for (size_t i = 0; i < seen.size(); ++i) if (seen[i].first != i || seen[i].second != seen.size()) return false;
+        return opened == closed;
+    }
+    int main() {
+        Stretch s;
+        s.configure(2, 512, 128);
+        std::vector<std::vector<float>> in(2, std::vector<float>(4096)), out(2, std::vector<float>(4096));
+        for (int c = 0; c < 2; ++c) for (int i = 0; i < 4096; ++i) in[c][i] = 0.3f*float((i*7 + c*13)%97)/97 - 0.15f;
+        s.process(in, 100, out, 100);                          // the first block begins: plain, stereo
+        if (seen.empty() || !consistent()) { std::printf("first call: %zu steps\n", seen.size()); return 1; }
+        const size_t plainSteps = seen.size();
+        s.process(in, 20, out, 20);                            // inside the interval: no block begins, nothing is announced
+        if (!seen.empty()) { std::printf("a call without a block announced %zu steps\n", seen.size()); return 2; }
+        s.setTransposeSemitones(4, 0);
+        s.process(in, 300, out, 300);                          // a mapped block: more steps, and again ONE count
+        if (seen.size() <= plainSteps || !consistent()) { std::printf("mapped call: %zu steps (plain %zu)\n", seen.size(), plainSteps); return 3; }
+        std::printf("ok plain %zu mapped %zu calls %d/%d\n", plainSteps, seen.size(), started, ended);
+        return (started == 3 && ended == 3) ? 0 : 4;
+    }
+''')
+
+
+def test_profiling_hooks_report_one_count_per_call(emu, tmp_path):
+    """ADVICE r5: STEP(step, steps) carried two different `steps` in one call, and a call without a block re-announced the last one's."""
+    src, exe = tmp_path / "hooks.cpp", tmp_path / "hooks"
+    src.write_text(PROFILE_HOOKS)
+    emu_dir = os.path.join(ROOT, "tests", "emu")
+    r = subprocess.run(["g++", "-std=c++11", "-O1", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe), "-L" + emu_dir, "-l:libsmst_emu.so",
+                        "-Wl,-rpath," + emu_dir], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    r = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, (r.returncode, r.stdout, r.stderr[-2000:])

@@ -150,6 +150,17 @@ def test_split_mid_interval_flush_emu(emu, ref):
     print(pc.case_split_mid_interval_flush(emu, ref))
 
 
+@pytest.mark.parametrize("variant", ["L6", "L7", "L8", "L6_3ch", "no_single_hop", "no_single_hop_3ch"])
+def test_split_mid_interval_flush_wide_emu(emu, ref, monkeypatch, variant):
+    """HopDesc.startBin in every recurrence form, not only kVocoderOne"""
+    if variant.startswith("no_single_hop"):
+        monkeypatch.setenv("SMST_NO_SINGLE_HOP", "1")
+        print(pc.case_split_mid_interval_flush_wide(emu, ref, channels=3 if variant.endswith("3ch") else 2, block=512))
+        return
+    block = {"L6": 768, "L7": 896, "L8": 1024}[variant[:2]]
+    print(pc.case_split_mid_interval_flush_wide(emu, ref, channels=3 if variant.endswith("3ch") else 2, block=block))
+
+
 def test_across_equals_single_hop_emu(emu, monkeypatch):
     pc.case_across_equals_single_hop(emu, monkeypatch, streams=11)
     pc.case_across_equals_single_hop(emu, monkeypatch, streams=5, channel_counts=(2,), setup=lambda b: b.setTransposeSemitones(5, 0.2))
@@ -216,3 +227,7 @@ def test_api_surface_and_realtime_quanta_split_emu(emu, ref):
     """seek / ragged chunks / flush / outputSeek / exact and the AudioWorklet calling patterns in split-computation mode"""
     pc.case_api_surface(emu, ref, cfg=pc.SMALL_SPLIT)
     pc.case_realtime_quanta(emu, ref, cfg=pc.SMALL_SPLIT)
+
+
+def test_split_freq_map_mid_interval_emu(emu, ref):
+    print(pc.case_split_freq_map_mid_interval(emu, ref))

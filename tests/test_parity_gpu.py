@@ -608,6 +608,20 @@ def test_split_mid_interval_flush(hip, ref):
     _report("split_mid_interval_flush", pc.case_split_mid_interval_flush(hip, ref))
 
 
+@pytest.mark.parametrize("variant", ["L6", "L7", "L8", "L6_3ch", "no_single_hop", "no_single_hop_3ch"])
+def test_split_mid_interval_flush_wide(hip, ref, monkeypatch, variant):
+    """HopDesc.startBin in every recurrence form, not only kVocoderOne"""
+    _report("split_mid_interval_flush_wide/" + variant, _split_flush_wide(hip, ref, monkeypatch, variant))
+
+
+def _split_flush_wide(lib, ref, monkeypatch, variant):
+    if variant.startswith("no_single_hop"):
+        monkeypatch.setenv("SMST_NO_SINGLE_HOP", "1")
+        return pc.case_split_mid_interval_flush_wide(lib, ref, channels=3 if variant.endswith("3ch") else 2, block=512)
+    block = {"L6": 768, "L7": 896, "L8": 1024}[variant[:2]]
+    return pc.case_split_mid_interval_flush_wide(lib, ref, channels=3 if variant.endswith("3ch") else 2, block=block)
+
+
 @pytest.mark.parametrize("geometry", scenarios.split_event_geometries())
 def test_split_events_golden(hip, ref, geometry):
     """the reference's shipped WASM build on flush / parameter change / reset / seek between interval boundaries (split computation)"""
@@ -687,3 +701,8 @@ def test_api_surface_and_realtime_quanta_split(hip, ref):
     """seek / ragged chunks / flush / outputSeek / exact and the AudioWorklet calling patterns in split-computation mode"""
     pc.case_api_surface(hip, ref, cfg=pc.SMALL_SPLIT)
     pc.case_realtime_quanta(hip, ref, cfg=pc.SMALL_SPLIT)
+
+
+def test_split_freq_map_mid_interval(hip, ref):
+    """ADVICE round 5 / review item 8: the frequency-map TABLE is latched with the step that read it"""
+    _report("split_freq_map_mid_interval", pc.case_split_freq_map_mid_interval(hip, ref))
