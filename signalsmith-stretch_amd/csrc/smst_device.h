@@ -83,6 +83,21 @@ struct DevBatch {
 	const int *lastNewHop; // [subS] tile-local index of the last hop with a new spectrum, or -1
 };
 
+// The continuous wavefront of the fused mono / stereo recurrence (kVocoderCont, smst_vocoder_cont.hip): launch `tile` covers the global
+// blocks [n0, n1) of a wavefront that runs through ALL tiles of a call without draining -- the rows (lanes) finish tile - 1 and begin
+// `tile` in it.  `[0]` = the workspace of tile - 1, `[1]` = the workspace of `tile`.
+struct ContArgs {
+	float2 *Xcur[2], *Xprev[2], *OUT[2];
+	const int *tileInfo; // [tile][2][subS]: hops per stream and tile (row 0 of each pair), as the tile kernels' DevBatch::nHops
+	int tileStride;      // 2*subS
+	int nTiles;          // tiles of the call
+	int tile;            // the tile that BEGINS in this launch (its row 0 starts at block n0 = tile*period), counted from the wavefront's first tile
+	int hopBase;         // index of that first tile's first hop in the rows of the call's hop table
+	int n0, n1;          // global block range; both even
+	int period;          // blocks per tile and row: M/8 + 2 (a zero line between two hops of a row: see the kernel)
+	float2 *save;        // [S][8*C*64]: the recurrence wave's last eight outputs per lane, from one launch to the next
+};
+
 struct IoArgs {
 	const float *in;
 	float *out;
@@ -117,7 +132,7 @@ __host__ __device__ inline bool analysisWindowInCall(int B, int M, int I, int in
 // Which kernel variant a launcher chose, counted per process (test hook: smst_debug_launch_count).  "Bit-identical to the other
 // form" tests assert through these that BOTH forms really ran.
 enum LaunchKind {
-	LK_VOC_ALIGNED, LK_VOC_STAGED, LK_VOC_GATHER, LK_VOC_N, LK_VOC_ONE, LK_VOC_ACROSS, LK_CHAIN_UNFUSED,
+	LK_VOC_ALIGNED, LK_VOC_STAGED, LK_VOC_GATHER, LK_VOC_N, LK_VOC_ONE, LK_VOC_ACROSS, LK_VOC_CONT, LK_CHAIN_UNFUSED,
 	LK_ANALYSE_TEAMS, LK_ANALYSE_FAST, LK_ANALYSE_GENERIC, LK_SYNTH_TEAMS, LK_SYNTH_FAST, LK_SYNTH_GENERIC, LK_SYNTH_EMIT, LK_EMIT_CARRIED, LK_COUNT
 };
 long long launchCount(const char *name); // -1: unknown name
@@ -130,6 +145,9 @@ void launchChain(const DevBatch &d, int sBase, int nStreams, int hopBase, hipStr
 void launchPredictFused(const DevBatch &d, int sBase, int nStreams, int hopBase, int tileHops, bool plain, bool passADone, hipStream_t st);
 void launchVocoder(const DevBatch &d, int sBase, int nStreams, int hopBase, bool plain, bool bounded, hipStream_t st); // bounded: no random time factors in the tile
 bool fusedSupported(const DevBatch &d);
+bool continuousSupported(const DevBatch &d); // the geometries of the line-aligned producers (mono / stereo, L <= 4, M a multiple of 16, fp32 state)
+int continuousPeriod(const DevBatch &d);     // blocks per tile of the continuous wavefront
+void launchVocoderContinuous(const DevBatch &d, const ContArgs &a, int sBase, int nStreams, hipStream_t st);
 bool singleHopSupported(const DevBatch &d);
 void launchVocoderOne(const DevBatch &d, int sBase, int nStreams, int hopBase, bool plain, hipStream_t st); // tiles in which no stream has more than one hop
 bool acrossSupported(const DevBatch &d);

@@ -146,7 +146,7 @@ void Batch::construct(const FftPlan &plan, long seed) {
 	}
 	SMST_HIP(hipEventCreateWithFlags(&evStart, hipEventDisableTiming));
 	SMST_HIP(hipEventCreateWithFlags(&evOrder, hipEventDisableTiming));
-	for (int i = 0; i < 2; ++i) {
+	for (int i = 0; i < 3; ++i) {
 		SMST_HIP(hipEventCreateWithFlags(&evFeed[i], hipEventDisableTiming));
 		SMST_HIP(hipEventCreateWithFlags(&evChain[i], hipEventDisableTiming));
 		SMST_HIP(hipEventCreateWithFlags(&evOut[i], hipEventDisableTiming));
@@ -154,7 +154,7 @@ void Batch::construct(const FftPlan &plan, long seed) {
 	}
 	// the cross-check switches: one struct, one table, read once (smst_switches.h)
 	const Switches sw = Switches::fromEnvironment();
-	overlap = sw.overlap; noFuse = sw.noFuse; noSingleHop = sw.noSingleHop; noAcross = sw.noAcross; carriedEmit = sw.carriedEmit != 0; checkLaunches = sw.checkLaunches;
+	overlap = sw.overlap; noFuse = sw.noFuse; noSingleHop = sw.noSingleHop; noAcross = sw.noAcross; carriedEmit = sw.carriedEmit != 0; checkLaunches = sw.checkLaunches; noContinuous = sw.noContinuous;
 	workspaceGiB = sw.workspaceGiB;
 	subStreamsAsked = sw.subStreams;
 
@@ -442,7 +442,7 @@ void Batch::releaseAll() {
 	if (evStart) hipEventDestroy(evStart);
 	if (evOrder) hipEventDestroy(evOrder);
 	evStart = evOrder = nullptr;
-	for (int i = 0; i < 2; ++i) {
+	for (int i = 0; i < 3; ++i) {
 		if (evFeed[i]) hipEventDestroy(evFeed[i]);
 		if (evChain[i]) hipEventDestroy(evChain[i]);
 		if (evOut[i]) hipEventDestroy(evOut[i]);
@@ -515,6 +515,18 @@ void Batch::allocateWorkspace() {
 				w.freqEst = devAlloc<float>((size_t)subS*d.T);
 				w.frames = devAlloc<float>((size_t)subS*d.T*C*B);
 			}
+			// The continuous wavefront (kVocoderCont) finishes tile t in launch t+1, so tile t+1's analysis needs a third place to write to:
+			// the spectra, the results and the frames of a PLAIN tile only, and only where that form can run at all (one sub-batch)
+			slots[2] = TileBuffers{};
+			dContSave = nullptr;
+			if (continuousSupported(d) && fusedSupported(d) && !noFuse && !noContinuous && subS == S) {
+				TileBuffers &w = slots[2];
+				w.Xcur = devAlloc<float2>(rows);
+				w.Xprev = devAlloc<float2>(rows);
+				w.OUT = devAlloc<float2>(rows);
+				w.frames = devAlloc<float>((size_t)subS*d.T*C*B);
+				dContSave = devAlloc<float2>((size_t)S*8*C*64);
+			}
 			break;
 		} catch (const Error &) {
 			while (allocations.size() > mark) { hipFree(allocations.back()); allocations.pop_back(); }
@@ -523,7 +535,7 @@ void Batch::allocateWorkspace() {
 			subS = (subS + 1)/2;
 		}
 	}
-	wsBytes = 2*perStream*subS;
+	wsBytes = 2*perStream*subS + (slots[2].Xcur ? (size_t)subS*d.T*C*((size_t)d.Mp*3*sizeof(float2) + (size_t)B*sizeof(float)) : 0);
 }
 
 void Batch::uploadParams() {
@@ -903,8 +915,7 @@ void Batch::runPendingBlocks(const int *synthChannels) {
 // over three HIP streams and two workspaces.
 void Batch::runTiles(const TileRun &run) {
 	const IoArgs &io = *run.io;
-	const int T = d.T, nTiles = run.nTiles, maxHops = run.maxHops;
-	const int nSub = (S + subS - 1)/subS;
+	const int nTiles = run.nTiles;
 	if (run.carriedOnly) { // no stream fires a hop: the front of the carry is the output, and what is left stays where it is
 		timed(timings.emitMs, [&] { launchEmitCarried(d, io, st); if (profiling) ++timings.emitLaunches; });
 		checkLaunch("emission of the carried sums");
@@ -912,6 +923,30 @@ void Batch::runTiles(const TileRun &run) {
 	}
 	std::fill(carryBase.begin(), carryBase.end(), 0); // every tile writes every stream's carry from the front of its rows
 	const int carryFirst = d.carryCur;
+	// Runs of two or more tiles that the continuous wavefront can take (kVocoderCont) go to it, the tiles around them -- the first tile
+	// after a reset, whose first hop draws random time factors; a tile with a pitch map -- tile by tile; the segments follow each other on `st`.
+	int t = 0;
+	while (t < nTiles) {
+		int e = t;
+		while (e < nTiles && continuousApplies(run, e)) ++e;
+		if (e - t >= 2) { runTilesContinuous(run, t, e, carryFirst); t = e; continue; }
+		e = std::max(e, t + 1);
+		for (;;) { // extend the tile-by-tile segment up to the next run of two
+			int r = e;
+			while (r < nTiles && continuousApplies(run, r)) ++r;
+			if (e >= nTiles || r - e >= 2) break;
+			e = std::max(r, e + 1);
+		}
+		runTilesRange(run, t, e, carryFirst);
+		t = e;
+	}
+	d.carryCur = (carryFirst + nTiles) & 1;
+}
+
+void Batch::runTilesRange(const TileRun &run, int tile0, int tile1, int carryFirst) {
+	const IoArgs &io = *run.io;
+	const int T = d.T, nTiles = run.nTiles, maxHops = run.maxHops;
+	const int nSub = (S + subS - 1)/subS;
 	// Three HIP streams: `st` runs the feed-forward kernels of tile q, `stChain` the recurrence of tile q (a few
 	// hundred waves, instruction-issue bound), `stSynth` synthesis + emission.  Two workspaces alternate, so the bulk
 	// kernels of the next tile fill the machine while the recurrence of the current one is in flight.
@@ -923,11 +958,11 @@ void Batch::runTiles(const TileRun &run) {
 		SMST_HIP(hipStreamWaitEvent(sC, evStart, 0));
 		SMST_HIP(hipStreamWaitEvent(sS, evStart, 0));
 	}
-	int q = 0;
+	int q = tile0; // (the workspace of tile t of a single sub-batch is slots[t & 1] whatever segment it runs in: debugGetMap relies on it)
 	for (int sub = 0; sub < nSub; ++sub) {
 		const int sBase = sub*subS;
 		const int ns = std::min(subS, S - sBase);
-		for (int t = 0; t < nTiles; ++t, ++q) {
+		for (int t = tile0; t < tile1; ++t, ++q) {
 			const unsigned char *th = run.tileHas + (size_t)(sub*nTiles + t)*kTileHasStride;
 			const int hopBase = t*T;
 			const int tileHops = std::min(T, std::max(1, maxHops - hopBase));
@@ -941,11 +976,11 @@ void Batch::runTiles(const TileRun &run) {
 			dd.carryCur = (carryFirst + t) & 1;
 			dd.nHops = run.dTileInfo + ((size_t)(sub*nTiles + t)*2)*subS;
 			dd.lastNewHop = dd.nHops + subS;
-			if (!serial && q >= 2) { // this workspace was last used by tile q-2
+			if (!serial && q - tile0 >= 2) { // this workspace was last used by tile q-2
 				SMST_HIP(hipStreamWaitEvent(sF, evChain[slot], 0));
 				SMST_HIP(hipStreamWaitEvent(sF, evSynth[slot], 0));
 			}
-			if (!serial && fused && !plain && q >= 1) SMST_HIP(hipStreamWaitEvent(sF, evChain[slot ^ 1], 0)); // pass A reads the carried state
+			if (!serial && fused && !plain && q - tile0 >= 1) SMST_HIP(hipStreamWaitEvent(sF, evChain[slot ^ 1], 0)); // pass A reads the carried state
 			if (th[0]) {
 				if (th[8]) timed(timings.otherMs, [&] { launchPendingToTile(dd, sBase, ns, dPendIn, dPendPrev, sF); }); // blocks that began in an earlier call: their spectra are waiting
 				if (th[3]) timed(timings.analyseMs, [&] { launchAnalyse(dd, io, sBase, ns, hopBase, tileHops, th[5] != 0, th[6] != 0, sF); if (profiling) ++timings.analyseLaunches; });
@@ -1023,12 +1058,124 @@ void Batch::runTiles(const TileRun &run) {
 		}
 	}
 	if (!serial) { // everything the caller can observe is ordered on `st` again
-		for (int i = 0; i < 2 && i < q; ++i) {
+		for (int i = 0; i < 2 && i < q - tile0; ++i) {
 			SMST_HIP(hipStreamWaitEvent(st, evChain[i], 0));
 			SMST_HIP(hipStreamWaitEvent(st, evSynth[i], 0));
 		}
 	}
-	d.carryCur = (carryFirst + nTiles) & 1;
+}
+
+// Whether a tile can be part of a continuous wavefront (kVocoderCont; runs of two or more such tiles are): the geometries of the
+// line-aligned producers, one sub-batch, the tile plain, bounded, whole-line -- what launchVocoder sends to the aligned form -- with a
+// new spectrum in every hop (the rows of a later tile then never read the carried feed-forward state).
+bool Batch::continuousApplies(const TileRun &run, int t) const {
+	if (!slots[2].Xcur || run.pendingRun || run.carriedOnly || subS != S) return false;
+	if (!(d.L == 4 || d.alignAll)) return false; // (as launchVocoder chooses the aligned producers)
+	const unsigned char *th = run.tileHas + (size_t)t*kTileHasStride;
+	return th[0] && !th[1] && !th[2] && !th[4] && !th[7] && !th[8] && !th[9];
+}
+
+// The same pipeline as runTiles -- analysis of tile t+1, recurrence, synthesis + emission over three HIP streams -- with the recurrence as
+// launch t of the continuous wavefront: it begins tile t and finishes tile t-1, so synthesis runs one tile later and the workspaces rotate
+// over three slots (launch t reads the spectra of tiles t-1 and t while tile t+1 is analysed).  The carried state is read by launch 0 only
+// (the call's first hop); it is written once per stream, from its last tile, behind the launch that finishes that tile.
+void Batch::runTilesContinuous(const TileRun &run, int tile0, int tile1, int carryFirst) {
+	const IoArgs &io = *run.io;
+	const int T = d.T, maxHops = run.maxHops;
+	const bool serial = profiling || !overlap;
+	hipStream_t sF = st, sC = serial ? st : stChain, sS = serial ? st : stSynth;
+	if (!serial) {
+		SMST_HIP(hipEventRecord(evStart, st));
+		SMST_HIP(hipStreamWaitEvent(sC, evStart, 0));
+		SMST_HIP(hipStreamWaitEvent(sS, evStart, 0));
+	}
+	const int P = continuousPeriod(d);
+	auto tileView = [&](int t) {
+		const TileBuffers &w = slots[t%3];
+		DevBatch dd = d;
+		dd.Xcur = w.Xcur; dd.Xprev = w.Xprev; dd.OUT = w.OUT; dd.frames = w.frames;
+		dd.PE = nullptr; dd.REC = nullptr; dd.map = nullptr; dd.ratio = nullptr; // (plain tiles: never touched)
+		dd.carryCur = (carryFirst + t) & 1;
+		dd.nHops = run.dTileInfo + ((size_t)t*2)*subS;
+		dd.lastNewHop = dd.nHops + subS;
+		return dd;
+	};
+	auto tileHops = [&](int t) { return std::min(T, std::max(1, maxHops - t*T)); };
+	auto lastOfSomeStream = [&](int t) {
+		if (t == tile1 - 1) return true; // (the tiles behind the segment, if any, start from the carried state)
+		for (int s = 0; s < S; ++s) if (hopCount[s] > 0 && (hopCount[s] - 1)/T == t) return true;
+		return false;
+	};
+	// tile t is complete (its last rows ran in the launch just enqueued on sC): hand-over to the carried state, synthesis + emission
+	auto finishTile = [&](int t, int launch) {
+		const DevBatch dd = tileView(t);
+		const bool emitted = synthEmitApplies(dd, S, tileHops(t));
+		if (lastOfSomeStream(t)) // (only a stream's last tile goes to the carried state)
+		 timed(timings.otherMs, [&] {
+			launchCarryFeed(dd, 0, S, t*T, false, sC);
+			launchCarryOut(dd, 0, S, sC);
+		});
+		if (!serial) SMST_HIP(hipEventRecord(evChain[t%3], sC)); // (everything that reads tile t's workspace on sC is in front of this)
+		if (emitted) timed(timings.otherMs, [&] { launchEmitProducts(dd, 0, S, t, sS); });
+		if (!serial) SMST_HIP(hipStreamWaitEvent(sS, evOut[launch%3], 0));
+		timed(timings.synthMs, [&] {
+			if (emitted) launchSynthEmit(dd, io, 0, S, t, sS);
+			else launchSynth(dd, 0, S, t*T, tileHops(t), sS);
+			if (profiling) ++timings.synthLaunches;
+		});
+		if (!emitted) timed(timings.emitMs, [&] { launchEmit(dd, io, 0, S, t, run.maxSpan[t], sS); if (profiling) ++timings.emitLaunches; });
+		checkLaunch("synthesis / emission");
+		if (!serial) SMST_HIP(hipEventRecord(evSynth[t%3], sS));
+	};
+	for (int t = tile0; t < tile1; ++t) {
+		const unsigned char *th = run.tileHas + (size_t)t*kTileHasStride;
+		const DevBatch dd = tileView(t);
+		if (!serial && t >= tile0 + 3) { // this workspace held tile t-3: its spectra were last read by launch t-2, its results by the synthesis of tile t-3
+			SMST_HIP(hipStreamWaitEvent(sF, evChain[t%3], 0));
+			SMST_HIP(hipStreamWaitEvent(sF, evSynth[t%3], 0));
+		}
+		timed(timings.analyseMs, [&] { launchAnalyse(dd, io, 0, S, t*T, tileHops(t), th[5] != 0, th[6] != 0, sF); if (profiling) ++timings.analyseLaunches; });
+		checkLaunch("analysis");
+		if (!serial) {
+			SMST_HIP(hipEventRecord(evFeed[t%3], sF));
+			SMST_HIP(hipStreamWaitEvent(sC, evFeed[t%3], 0));
+		}
+		ContArgs a{};
+		const TileBuffers &w0 = slots[(t + 2)%3], &w1 = slots[t%3]; // tile t-1, tile t
+		a.Xcur[0] = w0.Xcur; a.Xprev[0] = w0.Xprev; a.OUT[0] = w0.OUT;
+		a.Xcur[1] = w1.Xcur; a.Xprev[1] = w1.Xprev; a.OUT[1] = w1.OUT;
+		a.tileInfo = run.dTileInfo + ((size_t)tile0*2)*subS; // the kernel counts tiles, hops and blocks from the segment's first tile
+		a.tileStride = 2*subS;
+		a.nTiles = tile1 - tile0;
+		a.tile = t - tile0;
+		a.hopBase = tile0*T;
+		a.period = P;
+		a.n0 = P*a.tile;
+		a.n1 = (t == tile1 - 1) ? P*(a.tile + 1) + 62 : P*(a.tile + 1); // the last launch runs until row 63 of the last tile is through
+		a.save = dContSave;
+		hipEvent_t liveA = nullptr, liveB = nullptr;
+		if (liveTiming && !serial) {
+			if (liveEvents.size() == livePool.size()) growLivePool(livePool.size() + 64);
+			liveA = livePool[liveEvents.size()].first;
+			liveB = livePool[liveEvents.size()].second;
+			SMST_HIP(hipEventRecord(liveA, sC));
+		}
+		timed(timings.chainMs, [&] { launchVocoderContinuous(d, a, 0, S, sC); if (profiling) ++timings.chainLaunches; });
+		if (liveA) {
+			SMST_HIP(hipEventRecord(liveB, sC));
+			liveEvents.emplace_back(liveA, liveB);
+		}
+		checkLaunch("bin recurrence (continuous)");
+		if (!serial) SMST_HIP(hipEventRecord(evOut[t%3], sC));
+		if (t > tile0) finishTile(t - 1, t);
+	}
+	finishTile(tile1 - 1, tile1 - 1);
+	if (!serial) {
+		for (int i = 0; i < 3 && i < tile1 - tile0; ++i) { // everything the caller can observe is ordered on `st` again
+			SMST_HIP(hipStreamWaitEvent(st, evChain[i], 0));
+			SMST_HIP(hipStreamWaitEvent(st, evSynth[i], 0));
+		}
+	}
 }
 
 void Batch::process(const float *in, long long inSS, long long inCS, const int *inSamples,
@@ -1294,6 +1441,7 @@ void Batch::process(const float *in, long long inSS, long long inCS, const int *
 					for (int which = 0; which < ((f & HOP_REANALYSE_PREV) ? 2 : 1); ++which) th[analysisWindowInCall(d.B, d.M, d.I, list[h].inputOffset, which, nIn[s]) ? 5 : 6] = 1;
 				}
 				th[0] = 1;
+				if (!(f & HOP_NEW_SPECTRUM)) th[9] = 1; // (a hop that re-uses the spectrum before it: the continuous wavefront asks for a new one per hop)
 				if (f & HOP_MAPPED) th[1] = 1;
 				if (f & HOP_FORMANTS) th[2] = 1;
 				if (f & HOP_RANDOM_TF) th[4] = 1;

@@ -140,9 +140,10 @@ private:
 		std::vector<void *> retiredDevice, retiredPinned; // outgrown tables that the previous call may still read
 	} callSets[2]{};
 	int callCur = 0;
-	hipEvent_t evStart = nullptr, evFeed[2] = {nullptr, nullptr}, evChain[2] = {nullptr, nullptr}, evOut[2] = {nullptr, nullptr}, evSynth[2] = {nullptr, nullptr};
-	struct TileBuffers { float2 *Xcur, *Xprev, *OUT, *dump, *map, *peaksT; float4 *REC; PredEntry *PE; float *ratio, *energyT, *smoothT, *est, *freqEst, *frames; } slots[2]{};
-	bool overlap = true, noFuse = false, noSingleHop = false, noAcross = false, carriedEmit = true; // (smst_switches.h)
+	hipEvent_t evStart = nullptr, evFeed[3] = {nullptr, nullptr, nullptr}, evChain[3] = {nullptr, nullptr, nullptr}, evOut[3] = {nullptr, nullptr, nullptr}, evSynth[3] = {nullptr, nullptr, nullptr}; // (the third set: the continuous wavefront's tile pipeline is one stage deeper)
+	struct TileBuffers { float2 *Xcur, *Xprev, *OUT, *dump, *map, *peaksT; float4 *REC; PredEntry *PE; float *ratio, *energyT, *smoothT, *est, *freqEst, *frames; } slots[3]{}; // [2]: only what a plain tile touches, only where the continuous wavefront applies (allocateWorkspace)
+	bool overlap = true, noFuse = false, noSingleHop = false, noAcross = false, carriedEmit = true, noContinuous = false; // (smst_switches.h)
+	float2 *dContSave = nullptr; // kVocoderCont: the recurrence wave's history between two launches, [S][8*C*64]
 	double workspaceGiB = 0;
 	int subStreamsAsked = 0;
 	int subS = 0;
@@ -183,6 +184,9 @@ private:
 	struct TileRun { const IoArgs *io; int nTiles, maxHops; const unsigned char *tileHas; const int *maxSpan; const int *dTileInfo; bool pendingRun; const int *dSynthChannels; bool carriedOnly; };
 	void settleCarry();
 	void runTiles(const TileRun &run);
+	void runTilesRange(const TileRun &run, int tile0, int tile1, int carryFirst); // tile by tile
+	bool continuousApplies(const TileRun &run, int tile) const;
+	void runTilesContinuous(const TileRun &run, int tile0, int tile1, int carryFirst); // the recurrence as ONE wavefront through the tiles [tile0, tile1) (kVocoderCont)
 	bool profiling = false, liveTiming = false;
 	std::vector<std::pair<hipEvent_t, hipEvent_t>> liveEvents; // pairs recorded since the last takeTimings()
 	std::vector<std::pair<hipEvent_t, hipEvent_t>> livePool;   // every pair ever created; [0, liveEvents.size()) are in use

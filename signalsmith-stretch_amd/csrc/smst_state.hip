@@ -220,7 +220,7 @@ void launchComplexSelfTest(const float *in, float *out, int n, hipStream_t st) {
 
 static std::atomic<long long> gLaunchCounts[LK_COUNT];
 static const char *const kLaunchNames[LK_COUNT] = {
-	"vocoder_aligned", "vocoder_staged", "vocoder_gather", "vocoder_n", "vocoder_one", "vocoder_across", "chain_unfused",
+	"vocoder_aligned", "vocoder_staged", "vocoder_gather", "vocoder_n", "vocoder_one", "vocoder_across", "vocoder_continuous", "chain_unfused",
 	"analyse_teams", "analyse_fast", "analyse_generic", "synth_teams", "synth_fast", "synth_generic", "synth_emit", "emit_carried"};
 void countLaunch(LaunchKind k) { gLaunchCounts[k].fetch_add(1, std::memory_order_relaxed); }
 long long launchCount(const char *name) {

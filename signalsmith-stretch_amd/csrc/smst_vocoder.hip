@@ -1,5 +1,5 @@
 // K3 fused, mono / stereo: the bin recurrence and its record producers in one kernel (kVocoder; ACROSS form for single-hop tiles) and its launchers.
-#include "smst_recurrence.h"
+#include "smst_vocoder_common.h"
 
 namespace smst {
 
@@ -275,15 +275,6 @@ __device__ __forceinline__ void vocoderProduceStaged(const DevBatch &d, int s, i
 // needs.  The 8-bin lag costs 63*3 more steps per tile (+5.6 %) and puts rows r and r+1 on complementary halves of the LDS
 // banks with no row padding.  Same operands, same operations in the same order as vocoderProduceStaged / computeRecord:
 // bit-identical records.
-template <int CH, int L>
-struct AlignGeom {
-	static constexpr int RING = 32;                   // bins per (row, array): two lines
-	static constexpr int ROWLEN = 2*CH*RING;          // float2 per row: CH input buffers, then CH previous-input buffers
-	static constexpr int XLEN = CH*16;                // the row above the wave's first row: 16 bins per channel
-	static constexpr int PER_PRODUCER = 8*ROWLEN + XLEN;
-	static constexpr int LOADS = CH;                  // (4 rows x 2*CH arrays x 8 pieces) / 64 lanes
-};
-
 template <int CH, int L, int NB, bool FIRST>
 __device__ __forceinline__ void vocoderProduceAligned(const DevBatch &d, int s, int sg, int nh, int it, int k, int totalBlocks,
                                                       float4 *recs, volatile int *sync, const HopDesc *hopsLds, float2 *sbuf, const CarriedOutput &stOut) {
@@ -536,19 +527,6 @@ __device__ __forceinline__ void vocoderProduceAligned(const DevBatch &d, int s, 
 		step(n + 1, 0, vE, vO);
 	}
 	asyncWait<0>(); // the requests that ran past the tile's last block: nothing of this wave stays in flight behind it
-}
-
-constexpr int kVocBlockSteps = 8, kVocBlocks = 3, kVocBlocksStaged = 2, kVocStagedProducers = 8, kVocOutBlocks = 4; // (kVocWaves: smst_recurrence.h)
-constexpr int kVocOutBlocksAligned = 3; // lag 8: a row's 16-bin line lies in exactly two result blocks
-// results ring: [block][step][channel][kVocOutPitch] -- 66, not 64: the writer reads a row's values of steps 2 apart in adjacent
-// lane groups, and 2*CH*64 float2 is a multiple of the 32 banks (an 8-way conflict on every writer read with the first layout)
-constexpr int kVocOutPitch = 66;
-
-__device__ __forceinline__ float2 selectPair(bool pick, float2 a, float2 b) { return make_float2(pick ? a.x : b.x, pick ? a.y : b.y); }
-__device__ __forceinline__ float2 fromLaneBelow(float2 v, float2 lane0) { // lane k receives lane k-1's v; lane 0 keeps its `lane0`
-	// DPP wave_shr:1 without bound_ctrl: a lane with no source lane keeps the old value of the destination register
-	return make_float2(__int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(lane0.x), __float_as_int(v.x), 0x138, 0xf, 0xf, false)),
-	                   __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(lane0.y), __float_as_int(v.y), 0x138, 0xf, 0xf, false)));
 }
 
 // ACROSS (single-hop tiles, the real-time calling pattern: every stream fires at most one hop per call): the 64 lanes of the

@@ -10,7 +10,7 @@
 set -e
 HERE=$(cd "$(dirname "$0")" && pwd)
 SRC=$HERE/../../signalsmith-stretch_amd/csrc
-KERNELS="$SRC/smst_fft.hip $SRC/smst_feed.hip $SRC/smst_vocoder.hip $SRC/smst_vocoder_n.hip $SRC/smst_state.hip"
+KERNELS="$SRC/smst_fft.hip $SRC/smst_feed.hip $SRC/smst_vocoder.hip $SRC/smst_vocoder_cont.hip $SRC/smst_vocoder_n.hip $SRC/smst_state.hip"
 if [ "$1" = "asan" ]; then
   g++ -O1 -g -std=c++17 -fPIC -shared -fsanitize=address,undefined -fno-omit-frame-pointer -I"$HERE" -x c++ $KERNELS "$SRC/smst_engine.cpp" \
       "$SRC/smst_capi.cpp" "$HERE/hip_emu.cpp" -o "$HERE/libsmst_emu_asan.so" -Wno-unused-value

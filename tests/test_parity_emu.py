@@ -231,3 +231,7 @@ def test_api_surface_and_realtime_quanta_split_emu(emu, ref):
 
 def test_split_freq_map_mid_interval_emu(emu, ref):
     print(pc.case_split_freq_map_mid_interval(emu, ref))
+
+
+def test_continuous_equals_tiled_emu(emu, monkeypatch):
+    print(pc.case_continuous_equals_tiled(emu, monkeypatch))

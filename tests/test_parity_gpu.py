@@ -706,3 +706,18 @@ def test_api_surface_and_realtime_quanta_split(hip, ref):
 def test_split_freq_map_mid_interval(hip, ref):
     """ADVICE round 5 / review item 8: the frequency-map TABLE is latched with the step that read it"""
     _report("split_freq_map_mid_interval", pc.case_split_freq_map_mid_interval(hip, ref))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant", ["small", "default48", "default96_mono"])
+def test_continuous_equals_tiled(hip, monkeypatch, variant):
+    """kVocoderCont (one wavefront through the tiles of a call) against kVocoder tile by tile: bit-identical outputs and carried state;
+    the launch counters prove which ran.  On the device this is also the test of the kernel's own load tracking (smst_async.h) and of
+    row 0 reading back, through memory, what the same workgroup's writer wave stored a few hundred blocks earlier."""
+    if variant == "small":
+        _report("continuous_equals_tiled/small", pc.case_continuous_equals_tiled(hip, monkeypatch))
+    elif variant == "default48":
+        _report("continuous_equals_tiled/default48", pc.case_continuous_equals_tiled(hip, monkeypatch, geometry=dict(preset="default", interval=1440), channel_counts=(2,), streams=9))
+    else:
+        monkeypatch.setenv("SMST_ALIGN_ALL", "1")
+        _report("continuous_equals_tiled/default96_mono", pc.case_continuous_equals_tiled(hip, monkeypatch, geometry=dict(preset="default", interval=2880, sr=96000), channel_counts=(1,), ratios=(1.5,)))

@@ -18,7 +18,11 @@ fi
 # the patch scripts address ONE kernel file: the variant is built from the translation units joined into smst_kernels.hip
 # (the headers are `#pragma once`, every unit opens and closes the namespace itself); a --git revision that still has the single file is used as it is
 K=$TMP/signalsmith-stretch_amd/csrc
-if [ ! -f $K/smst_kernels.hip ]; then cat $K/smst_fft.hip $K/smst_feed.hip $K/smst_vocoder.hip $K/smst_vocoder_n.hip $K/smst_state.hip > $K/smst_kernels.hip; fi
+if [ ! -f $K/smst_kernels.hip ]; then
+  for unit in smst_fft smst_feed smst_vocoder smst_vocoder_cont smst_vocoder_n smst_state; do  # (a --git revision may predate a unit)
+    if [ -f $K/$unit.hip ]; then cat $K/$unit.hip >> $K/smst_kernels.hip; fi
+  done
+fi
 EXTRA=""
 while [ $# -gt 0 ]; do
   if [ "$1" = "--" ]; then shift; EXTRA="$*"; break; fi
