@@ -154,7 +154,7 @@ void Batch::construct(const FftPlan &plan, long seed) {
 	}
 	// the cross-check switches: one struct, one table, read once (smst_switches.h)
 	const Switches sw = Switches::fromEnvironment();
-	overlap = sw.overlap; noFuse = sw.noFuse; noSingleHop = sw.noSingleHop; noAcross = sw.noAcross; carriedEmit = sw.carriedEmit != 0; checkLaunches = sw.checkLaunches; noContinuous = sw.noContinuous;
+	overlap = sw.overlap; noFuse = sw.noFuse; noSingleHop = sw.noSingleHop; noAcross = sw.noAcross; carriedEmit = sw.carriedEmit != 0; checkLaunches = sw.checkLaunches; continuous = sw.continuous;
 	workspaceGiB = sw.workspaceGiB;
 	subStreamsAsked = sw.subStreams;
 
@@ -519,7 +519,7 @@ void Batch::allocateWorkspace() {
 			// the spectra, the results and the frames of a PLAIN tile only, and only where that form can run at all (one sub-batch)
 			slots[2] = TileBuffers{};
 			dContSave = nullptr;
-			if (continuousSupported(d) && fusedSupported(d) && !noFuse && !noContinuous && subS == S) {
+			if (continuous && continuousSupported(d) && fusedSupported(d) && !noFuse && subS == S) {
 				TileBuffers &w = slots[2];
 				w.Xcur = devAlloc<float2>(rows);
 				w.Xprev = devAlloc<float2>(rows);

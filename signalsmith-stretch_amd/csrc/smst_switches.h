@@ -14,7 +14,8 @@
 //   SMST_NO_STAGE          unset    set: the fused kernel's producers gather from HBM where staging applies
 //   SMST_NO_ALIGN          unset    set: staged producers with per-row windows and lag L + 1 instead of the line-aligned form
 //   SMST_ALIGN_ALL         unset    set: the line-aligned producers for every geometry they are valid for (default: L = 4 only)
-//   SMST_NO_CONTINUOUS     unset    set: the recurrence tile by tile (kVocoder) where the continuous wavefront across a call's tiles (kVocoderCont) applies
+//   SMST_CONTINUOUS        unset    set: runs of plain stereo / mono tiles through ONE wavefront across the tiles (kVocoderCont) instead of tile by tile (kVocoder):
+//                                   bit-identical, measured equal in speed (EXPERIMENTS.md 6.1), kept as a cross-check of the tile form
 //   SMST_NO_FAST_FFT       unset    set: the generic radix-4/2/3/5 ladder even where a register-blocked FFT exists
 //   SMST_FFT_TABLES        full     lean: the smaller FFT tables (one more rounding per element: opt-in, see smst_engine.cpp)
 //   SMST_FEED_SERIAL       unset    set: bin-by-bin feed recurrences (kFeedSerial) instead of the scan form
@@ -35,7 +36,7 @@ namespace smst {
 struct Switches {
 	bool overlap = true, noFuse = false, noSingleHop = false, noAcross = false, checkLaunches = false;
 	int noFeedFusion = 0, fftTeams = 1, synthEmit = 1, debugMode = 0, vocNWide = 1, carriedEmit = 1;
-	bool noStage = false, noAlign = false, alignAll = false, noFastFft = false, fftLean = false, feedSerial = false, noContinuous = false;
+	bool noStage = false, noAlign = false, alignAll = false, noFastFft = false, fftLean = false, feedSerial = false, continuous = false;
 	double workspaceGiB = 0; // 0: automatic
 	int subStreams = 0;      // 0: automatic
 
@@ -55,7 +56,7 @@ struct Switches {
 		s.noStage = set("SMST_NO_STAGE");
 		s.noAlign = set("SMST_NO_ALIGN");
 		s.alignAll = set("SMST_ALIGN_ALL");
-		s.noContinuous = set("SMST_NO_CONTINUOUS");
+		s.continuous = set("SMST_CONTINUOUS");
 		s.noFastFft = set("SMST_NO_FAST_FFT");
 		if (const char *env = std::getenv("SMST_FFT_TABLES")) s.fftLean = std::string(env) == "lean";
 		s.feedSerial = set("SMST_FEED_SERIAL");

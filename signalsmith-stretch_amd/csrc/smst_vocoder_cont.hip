@@ -31,14 +31,20 @@ struct RowInfo { float tf; unsigned flags; int inSrc, prevSrc; }; // what the ke
 // one after (reached only by requests that run ahead and in the last launch's extra blocks: never valid).  mm: block within the period.
 struct TilePos { int rel, mm; };
 
+// The producer waves are the kernel's critical path and they are bound by what a wave can ISSUE (EXPERIMENTS.md 4.2): the first form of
+// this function located every row at every block with compares and a multiply (m = n - row -> tile, block within the period), kept its
+// cursors packed, and took 440 vector instructions per block where the tile form takes 255 -- 8.3 ms per step against 6.4 with 12 % fewer
+// blocks.  Now: the wave index is made scalar (everything that depends on the block number and the wave alone runs on the scalar unit), a
+// lane's position is two counters that step once per block, and whatever changes only at a hop boundary sits behind a rarely taken branch.
 template <int CH, int L, bool FIRST>
 __device__ __forceinline__ void contProduce(const DevBatch &d, const ContArgs &a, int s, int sg, int it, int k, int n0, int n1,
                                             float4 *recs, volatile int *sync, const RowInfo *rowInfo, float2 *sbuf) {
 	using G = AlignGeom<CH, L>;
 	constexpr int NF = 9 + 3*CH, NCH = (NF + 3)/4, BS = 8, NB = kVocBlocksStaged;
 	static_assert(2*L <= 8 && 7 + L <= 11, "the windows must fit the two lines around the row's bins");
-	const int M = d.M, P = a.period, MB = M >> 3, LP = P >> 1, ML = M >> 4;
+	const int M = d.M, P = a.period, MB = M >> 3, LP = P >> 1;
 	const int PQ0 = P*a.tile, PQ1 = PQ0 + P;
+	// (set-up only: where row `row` stands at block n = m + row)
 	auto posOf = [&](int m) { TilePos t; t.rel = (m >= PQ0 ? 1 : 0) + (m >= PQ1 ? 1 : 0); t.mm = m - PQ0 + P - P*t.rel; return t; };
 	auto infoOf = [&](int rel, int row) { // rel 0 / 1: parity of tile - 1 + rel
 		RowInfo r = rowInfo[(((a.tile + 1 + rel) & 1) << 6) + row];
@@ -58,8 +64,8 @@ __device__ __forceinline__ void contProduce(const DevBatch &d, const ContArgs &a
 		}
 		if (ri.prevSrc == SRC_REANALYSED) return (r2 ? a.Xprev[1] : a.Xprev[0]) + rowOf(d, s, row, c);
 		if (ri.prevSrc >= 0) return (r2 ? a.Xcur[1] : a.Xcur[0]) + rowOf(d, s, ri.prevSrc, c);
-		// SRC_STATE: Band.prevInput as the hop before left it.  Every hop of a continuous call analyses a new spectrum (the engine's condition),
-		// so that is the input of the tile before's last row -- or, in the call's first tile, the carried state
+		// SRC_STATE: Band.prevInput as the hop before left it.  Every hop of a continuous run analyses a new spectrum (the engine's condition),
+		// so that is the input of the tile before's last row -- or, in the run's first tile, the carried state
 		if (a.tile - 1 + rel == 0) return d.stPrev + stateRow(d, sg, c);
 		if (rel == 1) return a.Xcur[0] + rowOf(d, s, kTileHops - 1, c);
 		valid = false; // (tile - 2: only the first row of tile - 1 could ask, and it has finished before this launch)
@@ -72,110 +78,124 @@ __device__ __forceinline__ void contProduce(const DevBatch &d, const ContArgs &a
 	__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 	const int nS = n0 - 4; // warm-up: two parks per row fill its two-line buffer (no records, no hand-off words)
 	// ---- this lane's line pieces: [parity of the rows][load].  Rows of parity `par` take a new line in the blocks n with n + 1 = par (mod 2)
-	// (their m = n - row is odd there).  Per piece: where the NEXT request reads (lptr, local line ll of its hop) and whether the request
-	// last issued was for a line that exists (lvalid bit: read by the park that follows).
-	// Registers: the kernel sits at its 128-register budget (scratch fails the build), so a piece keeps its cursor (8 bytes), its local line
-	// (16 bits) and two flag bits; row, array and LDS position are recomputed from the lane index where they are needed.
+	// (their m = n - row is odd there).  Per piece: the cursor of the NEXT request (lptr; line lline of its hop), whether that hop exists,
+	// and whether the request issued last was for a line that exists (read by the park that follows it).
 	const float2 *lptr[2][G::LOADS];
-	unsigned llPacked[2] = {0u, 0u}; // [par]: 16 bits per load
-	unsigned lflags = 0;             // bit par*LOADS + i: the line requested last exists; bit 8 + par*LOADS + i: the hop the cursor walks exists
-	auto pieceRow = [&](int par, int i) { return 8*it + 2*(((k + 64*i) >> 3)/(2*CH)) + par; };
+	int llds[2][G::LOADS], linc[2][G::LOADS]; // linc: 16 bins per request while the hop exists, 0 (the cursor rests on the rotation table) while it does not
+	bool lreq[2][G::LOADS];
+	auto pieceLocalRow = [&](int par, int i) { return 2*(((k + 64*i) >> 3)/(2*CH)) + par; };
 	auto pieceArray = [&](int i) { return ((k + 64*i) >> 3)%(2*CH); };
-	auto pieceLds = [&](int par, int i) { return (2*(((k + 64*i) >> 3)/(2*CH)) + par)*G::ROWLEN + pieceArray(i)*G::RING + 2*(k & 7); };
-	auto getLine = [&](int par, int i) { return int((llPacked[par] >> (16*i)) & 0xffffu); };
-	auto setLine = [&](int par, int i, int v) { llPacked[par] = (llPacked[par] & ~(0xffffu << (16*i))) | (unsigned(v) << (16*i)); };
-	static_assert(G::LOADS <= 2, "two 16-bit line counters per register");
 #pragma unroll
 	for (int par = 0; par < 2; ++par) {
 #pragma unroll
 		for (int i = 0; i < G::LOADS; ++i) {
-			const int row = pieceRow(par, i);
+			const int prow = 8*it + pieceLocalRow(par, i);
+			llds[par][i] = pieceLocalRow(par, i)*G::ROWLEN + pieceArray(i)*G::RING + 2*(k & 7);
 			const int nF = nS + 1 - par;           // the first block at or after nS in which this parity parks
-			const TilePos t = posOf(nF - row);     // mm odd
+			const TilePos t = posOf(nF - prow);    // mm odd
 			int line = (t.mm + 1) >> 1, rel = t.rel;
 			if (line == LP) { line = 0; ++rel; }   // the last gap block brings line 0 of the next hop
 			bool valid;
-			const float2 *base = rowBase(rel, row, pieceArray(i), valid);
+			const float2 *base = rowBase(rel, prow, pieceArray(i), valid);
 			lptr[par][i] = base + 2*(k & 7) + (valid ? 16*line : 0);
-			setLine(par, i, line);
-			if (valid) lflags |= 256u << (par*G::LOADS + i);
+			linc[par][i] = valid ? 16 : 0;
+			lreq[par][i] = false;
 		}
 	}
 	const int st = k & 7, r = k >> 3, row = 8*it + r;
 	const int xc = (k >> 3) < CH ? (k >> 3) : 0, xpiece = k & 7;
 	const bool xlane = k < 8*CH;
+	// the hop above the wave's first row, by the tile that row is in (rel 0 / 1): the row before it in the same tile -- FIRST: the tile
+	// before's last row, or above the run's very first hop the carried Prediction.energy (one source per launch: row 0 works in tile `a.tile`)
+	const float2 *xsrcRel[2] = {d.rot, d.rot};
+	int xkindRel[2] = {0, 0}; // 0 nothing (zeros), 1 carried energies, 2 a hop's input
+	if (FIRST) {
+		if (a.tile == 0) { xsrcRel[1] = reinterpret_cast<const float2 *>(d.stEnergy + stateRow(d, sg, xc)); xkindRel[1] = 1; }
+		else { xsrcRel[1] = a.Xcur[0] + rowOf(d, s, kTileHops - 1, xc); xkindRel[1] = 2; } // (the tile before is full: a later one exists)
+	} else {
+#pragma unroll
+		for (int rel = 0; rel < 2; ++rel) {
+			bool hv;
+			const float2 *base = rowBase(rel, 8*it - 1, xc, hv);
+			if (hv) { xsrcRel[rel] = base; xkindRel[rel] = 2; }
+		}
+	}
+	// FIRST: the taps of row 0's records (FOLD0) -- the carried Band.output in the run's first tile, the tile before's last row afterwards
+	const float2 *tapBase[CH];
+#pragma unroll
+	for (int c = 0; c < CH; ++c) tapBase[c] = (a.tile == 0) ? static_cast<const float2 *>(carriedOutput(d, sg).base) + (size_t)c*M : a.OUT[0] + rowOf(d, s, kTileHops - 1, c);
 	Async16 vE[G::LOADS], vO[G::LOADS], xv;
 	Async8 rotNext1, rotNextL, carNext1[CH], carNextL[CH];
 	float2 rot1 = make_float2(1.f, 0.f), rotL = rot1;
 	float2 car1[CH], carL[CH];
 #pragma unroll
 	for (int c = 0; c < CH; ++c) car1[c] = carL[c] = make_float2(0.f, 0.f);
-	int xKind = 0; // what the staged piece of the row above is: 0 nothing (zeros), 1 the carried Prediction.energy (FIRST, the call's first tile), 2 a hop's input
+	// ---- positions, stepped once per block.  Scalar: the wave's first row (mmA, relA).  Per lane: the lane's own row (mmL, relL).
+	int mmA, relA, mmL, relL;
+	{ const TilePos t = posOf(nS - 8*it); mmA = t.mm; relA = t.rel; }
+	{ const TilePos t = posOf(nS - row); mmL = t.mm; relL = t.rel; }
+	auto hopWords = [&]() { return reinterpret_cast<const float2 *>(rowInfo)[2*((((a.tile + 1 + relL) & 1) << 6) + row)]; };
+	float2 tfFlags = hopWords();
+	int xKind = 0;     // of the piece staged for the block at hand
+	int xKindNext = 0; // ... and for the one after it (set by issueSmall)
 
-	// block nPark's lines of parity par: request, then move the piece's cursor on by one line (a hop boundary every LP lines)
-	auto issueLines = [&](int nPark, int par, Async16 (&v)[G::LOADS]) {
+	// Block nPark = n + 2's lines of parity par (n: the block the counters stand at): request at the cursor, move it on by one line.  Only
+	// in the eight blocks per period in which some row of the wave asks for the zero line between two hops is there anything to decide:
+	// that request brings nothing and the cursor jumps to the next hop's first line (a wave-uniform branch around it all).
+	auto issueLines = [&](int par, Async16 (&v)[G::LOADS]) {
+		// A row with local index pr stands at block mmA - pr of its period (mod P; in the tile before the wave's first row's if that is
+		// negative) and asks for the line of the block two on: the zero line when that block is MB - 1 = P - 3, i.e. mmA - pr = -5 (mod P)
+		const bool window = mmA >= P - 5 || mmA <= 2; // scalar
 #pragma unroll
 		for (int i = 0; i < G::LOADS; ++i) {
-			const unsigned bit = 1u << (par*G::LOADS + i);
-			const int line = getLine(par, i);
-			const bool valid = (lflags & (bit << 8)) && line < ML; // line ML of a hop is the zero line between two hops
-			asyncLoad16(v[i], valid ? lptr[par][i] : d.rot);
-			lflags = valid ? (lflags | bit) : (lflags & ~bit);
-			lptr[par][i] += 16;
-			if (line + 1 == LP) { // the next request of this piece (block nPark + 2) opens the hop after
-				const int row = pieceRow(par, i);
-				const TilePos t = posOf(nPark + 2 - row + 1);
+			bool zeroLine = false;
+			int dRow = 0;
+			if (window) { dRow = mmA - pieceLocalRow(par, i); zeroLine = dRow == P - 5 || dRow == -5; }
+			asyncLoad16(v[i], zeroLine ? d.rot : lptr[par][i]);
+			lreq[par][i] = linc[par][i] != 0 && !zeroLine;
+			lptr[par][i] += linc[par][i];
+			if (window && zeroLine) { // the piece's next request (two blocks on) is line 0 of the hop after
+				const int prow = 8*it + pieceLocalRow(par, i);
 				bool hv;
-				const float2 *base = rowBase(t.rel, row, pieceArray(i), hv);
+				const float2 *base = rowBase((dRow >= 0 ? relA : relA - 1) + 1, prow, pieceArray(i), hv);
 				lptr[par][i] = base + 2*(k & 7);
-				setLine(par, i, 0);
-				lflags = hv ? (lflags | (bit << 8)) : (lflags & ~(bit << 8));
-			} else {
-				setLine(par, i, line + 1);
+				linc[par][i] = hv ? 16 : 0;
 			}
 		}
 	};
-	// the small loads of block nn: the 16 bins of the hop above the wave's first row, the rotation factors of the lane's two previous-hop
-	// bins, FIRST: the carried taps of row 0.  Request counts do not depend on the data (the waits count requests).
+	// the small loads of the block AFTER the one the counters stand at: the 16 bins of the hop above the wave's first row, the rotation
+	// factors of the lane's two previous-hop bins, FIRST: the taps of row 0.  Request counts do not depend on the data (the waits count requests).
 	auto issueSmall = [&](int nn) {
-		const TilePos tA = posOf(nn - 8*it); // the wave's first row
-		const int x0 = BS*tA.mm + 2*xpiece, xcl = min(max(x0, 0), M - 2);
-		const float2 *xsrc = d.rot;
-		xKind = 0;
-		int xoff = 0;
-		if (FIRST) {
-			// (one 16-byte request either way: of the carried energies it brings four floats, the first two are the piece's -- stEnergy has the slack)
-			const int tileA = a.tile - 1 + tA.rel;
-			if (tA.rel <= 1 && tileA == 0) { xsrc = reinterpret_cast<const float2 *>(d.stEnergy + stateRow(d, sg, xc) + xcl); xKind = 1; }
-			else if (tA.rel == 1) { xsrc = a.Xcur[0] + rowOf(d, s, kTileHops - 1, xc); xKind = 2; xoff = xcl; } // (the tile before is full: a later one exists)
-		} else {
-			bool hv;
-			const float2 *base = rowBase(tA.rel, 8*it - 1, xc, hv);
-			if (hv) { xsrc = base; xKind = 2; xoff = xcl; }
-		}
-		asyncLoad16(xv, xsrc + xoff);
-		const TilePos t = posOf(nn - row);
-		const int b = BS*t.mm + st;
+		const int mmA1 = (mmA + 1 == P) ? 0 : mmA + 1, relA1 = relA + (mmA + 1 == P ? 1 : 0); // scalar
+		const int x0 = BS*mmA1 + 2*xpiece, xcl = min(x0, M - 2);
+		const int kind = relA1 <= 1 ? (relA1 ? xkindRel[1] : xkindRel[0]) : 0;
+		const float2 *xsrc = relA1 ? xsrcRel[1] : xsrcRel[0];
+		xKindNext = kind;
+		// (FIRST, carried energies: one 16-byte request brings four floats, the first two are the piece's -- stEnergy has the slack)
+		const float2 *xaddr = (kind == 2) ? xsrc + xcl : ((kind == 1) ? reinterpret_cast<const float2 *>(reinterpret_cast<const float *>(xsrc) + xcl) : d.rot);
+		asyncLoad16(xv, xaddr);
+		const int mmL1 = (mmL + 1 == P) ? 0 : mmL + 1;
+		const int b = BS*mmL1 + st;
 		asyncLoad8(rotNext1, d.rot + min(b + 1, M - 1));
 		asyncLoad8(rotNextL, d.rot + min(b + L, M - 1));
-		if (FIRST) { // row 0 (lanes 0..7; the other lanes request in-range values they never use): m = nn
-			const TilePos t0 = posOf(nn);
-			const int tile0 = a.tile - 1 + t0.rel;
-			const int b0 = min(BS*t0.mm + st, M - 1);
-			const bool fromState = tile0 <= 0 || t0.rel != 1; // (rel 0 / 2 only in the warm-up and behind the last tile: gap bins, never used)
-			if (!fromState) {
+		if (FIRST) { // row 0 (lanes 0..7; the other lanes request the same in-range values and never use them): its position is the wave's (mmA1, relA1)
+			const int b0 = min(BS*mmA1 + st, M - 1);
+			if (a.tile > 0 && relA1 == 1) {
 				// The rows of tile - 1 are written by this workgroup's writer wave or by the launch before.  Row 0 at block nn reads bins up to
 				// 8 mm + 11 of lane 63's hop, which that lane produced by block nn - P + 65 and the writer stored with the line's completion one
-				// block later: wait until the stores through block nn - P + 66 have COMPLETED (the writer publishes that every 16 blocks and
-				// is never more than a few blocks behind the recurrence: with P >= 128 this never waits for anything still to come)
-				while (ldsPeek(&sync[NB + 3]) < nn - (P - 67)) __builtin_amdgcn_s_sleep(2);
-				asm volatile("" ::: "memory");
+				// block later: the stores through block nn - P + 66 must have COMPLETED (the writer publishes that every 16 blocks and is never
+				// more than a few blocks behind the recurrence: with P >= 128 this never waits for anything still to come).  A launch's first
+				// look happens in its warm-up (n0 - 4 + 4 is a multiple of 16 only by chance): `flushed` starts at n0, which covers every
+				// request before block n0 + P - 67
+				if ((nn & 15) == 0) { // (the word moves every 16 blocks, three blocks behind the writer: cover the requests up to the next look)
+					while (ldsPeek(&sync[NB + 3]) < nn + 15 - (P - 67)) __builtin_amdgcn_s_sleep(2);
+					asm volatile("" ::: "memory");
+				}
 			}
 #pragma unroll
-			for (int c = 0; c < CH; ++c) {
-				const float2 *tap = fromState ? static_cast<const float2 *>(carriedOutput(d, sg).base) + (size_t)c*M : a.OUT[0] + rowOf(d, s, kTileHops - 1, c);
-				asyncLoad8(carNext1[c], tap + min(b0 + 1, M - 1));
-				asyncLoad8(carNextL[c], tap + min(b0 + L, M - 1));
+			for (int c = 0; c < CH; ++c) { // (outside its own tile row 0 is in gap bins: whatever these bring is never used)
+				asyncLoad8(carNext1[c], tapBase[c] + min(b0 + 1, M - 1));
+				asyncLoad8(carNextL[c], tapBase[c] + min(b0 + L, M - 1));
 			}
 		}
 	};
@@ -191,19 +211,19 @@ __device__ __forceinline__ void contProduce(const DevBatch &d, const ContArgs &a
 			for (int c = 0; c < CH; ++c) { asyncArrived(carNext1[c]); asyncArrived(carNextL[c]); }
 		}
 	};
-	auto park = [&](int n, int par, Async16 (&v)[G::LOADS]) {
+	auto park = [&](int par, Async16 (&v)[G::LOADS]) {
 		if (FIRST) {
 #pragma unroll
 			for (int c = 0; c < CH; ++c) { car1[c] = asyncValue(carNext1[c]); carL[c] = asyncValue(carNextL[c]); }
 		}
 #pragma unroll
 		for (int i = 0; i < G::LOADS; ++i) { // upper line -> lower half, the new line -> upper half (this lane's piece of both)
-			float4 *lower = reinterpret_cast<float4 *>(sbuf + pieceLds(par, i)), *upper = lower + 8;
+			float4 *lower = reinterpret_cast<float4 *>(sbuf + llds[par][i]), *upper = lower + 8;
 			*lower = *upper;
-			*upper = (lflags & (1u << (par*G::LOADS + i))) ? asyncValue(v[i]) : make_float4(0.f, 0.f, 0.f, 0.f);
+			*upper = lreq[par][i] ? asyncValue(v[i]) : make_float4(0.f, 0.f, 0.f, 0.f);
 		}
 		if (xlane) {
-			const int x0 = BS*posOf(n - 8*it).mm + 2*xpiece;
+			const int x0 = BS*mmA + 2*xpiece;
 			float4 piece = asyncValue(xv);
 			if (FIRST && xKind == 1) piece = make_float4(piece.x, 0.f, piece.y, 0.f); // two carried energies, staged as (E, 0) pairs
 			*reinterpret_cast<float4 *>(xbuf + xc*16 + 2*xpiece) = (xKind != 0 && x0 + 1 < M) ? piece : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -212,29 +232,28 @@ __device__ __forceinline__ void contProduce(const DevBatch &d, const ContArgs &a
 		rotL = asyncValue(rotNextL);
 	};
 	auto step = [&](int n, int par, Async16 (&v)[G::LOADS], Async16 (&vNextBlock)[G::LOADS]) {
-		const bool energyAbove = FIRST && xKind == 1; // (as staged for THIS block: issueSmall below decides about the next one)
-		park(n, par, v);
+		xKind = xKindNext;
+		park(par, v);
 		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 		__builtin_amdgcn_wave_barrier();
 		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 		issueSmall(n + 1);
-		issueLines(n + 2, par, v);
+		issueLines(par, v);
 		if (n >= n0) {
 			const int slot = n%NB;
 			while (n - ldsPeek(&sync[NB]) >= NB) __builtin_amdgcn_s_sleep(2); // slot still being read
 			asm volatile("" ::: "memory");
-			const TilePos t = posOf(n - row);
-			const RowInfo ri = infoOf(t.rel, row);
-			const int b = BS*t.mm + st;
+			const unsigned flags = relL <= 1 ? unsigned(__float_as_int(tfFlags.y)) : 0u;
+			const int b = BS*mmL + st;
 			float f[NCH*4];
 #pragma unroll
 			for (int j = 0; j < NCH*4; ++j) f[j] = 0.0f;
-			if ((ri.flags & HOP_ACTIVE) && t.mm < MB) {
+			if ((flags & HOP_ACTIVE) && mmL < MB) {
 				// the arithmetic of vocoderProduceAligned (= computeRecord<CH, true, false, false>), operands from the line buffers: this row's
 				// buffer holds the lines (j-1, j) in its even blocks (b0 = 16j) and (j, j+1) in its odd ones; the row above runs 8 bins ahead
-				const bool rotate = ri.flags & HOP_NEW_SPECTRUM;
-				const float tf = ri.tf;
-				const bool odd = t.mm & 1;
+				const bool rotate = flags & HOP_NEW_SPECTRUM;
+				const float tf = tfFlags.x;
+				const bool odd = mmL & 1;
 				const float2 *mine = sbuf + r*G::ROWLEN + (odd ? 8 : 16) + st;
 				const float2 *above = (r > 0) ? sbuf + (r - 1)*G::ROWLEN + (odd ? 8 : 0) + st : xbuf + st;
 				const int abovePitch = (r > 0) ? G::RING : 16;
@@ -257,6 +276,7 @@ __device__ __forceinline__ void contProduce(const DevBatch &d, const ContArgs &a
 				const float fb = float(b);
 				float2 A = cmulc(Pm, lerpIN(mc, lerpIndex(fb - tf)));
 				float2 B = cmulc(Pm, lerpIN(mc, lerpIndex(fb - L*tf)));
+				const bool energyAbove = FIRST && xKind == 1 && r == 0; // the carried Prediction.energy only above the run's very first hop
 				auto twist = [&](int off, float2 rotV, float stepMul) {
 					const int bc = min(b + off, M - 1);
 					const float2 rotB = rotate ? rotV : make_float2(1.f, 0.f);
@@ -265,7 +285,7 @@ __device__ __forceinline__ void contProduce(const DevBatch &d, const ContArgs &a
 					const float2 TW = cmul(rotB, cmulc(Px, Q));
 					const float eNow = cnorm(Px);
 					const float2 up = above[mc*abovePitch + off];
-					const float ePrev = (energyAbove && r == 0) ? up.x : cnorm(up); // the carried Prediction.energy only above the call's very first hop
+					const float ePrev = energyAbove ? up.x : cnorm(up);
 					const float den = fmaxf(ePrev, eNow) + 1e-15f;
 					const float2 down = cmulc(Px, lerpIN(mc, lerpIndex(float(bc) - stepMul*tf)));
 					const float2 rr = cmulc(TW, down);
@@ -294,15 +314,28 @@ __device__ __forceinline__ void contProduce(const DevBatch &d, const ContArgs &a
 			asm volatile("" ::: "memory");
 			if (k == 0) ldsCount(&sync[slot]);
 		}
+		// on to the next block
+		if (++mmA == P) { mmA = 0; ++relA; }
+		{ const bool wrap = mmL + 1 == P; mmL = wrap ? 0 : mmL + 1; relL += wrap ? 1 : 0; }
+		tfFlags = hopWords(); // (tf, flags) of the lane's hop in the next block: 8 bytes out of LDS, asked for a block ahead of their use
 		__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
 		__builtin_amdgcn_wave_barrier(); // every lane has read its operands before the next block's lines are parked
 		__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 		landed(vNextBlock);
 	};
-	// nS is even: its parking rows have parity 1 (register set "O"), block nS + 1 the others
-	issueLines(nS, 1, vO);
-	issueSmall(nS);
-	issueLines(nS + 1, 0, vE);
+	// nS is even: its parking rows have parity 1 (register set "O"), block nS + 1 the others.  issueSmall(n) is called with the counters
+	// standing at block n - 1
+	{ // the small loads of block nS itself: step the counters back by one block for the call
+		const int keepA = mmA, keepRA = relA, keepL = mmL, keepRL = relL;
+		if (mmA == 0) { mmA = P - 1; --relA; } else --mmA;
+		if (mmL == 0) { mmL = P - 1; --relL; } else --mmL;
+		issueSmall(nS);
+		if (mmA == 0) { mmA = P - 1; --relA; } else --mmA;
+		issueLines(1, vO); // (the lines of block nS: the counters two blocks before it)
+		if (++mmA == P) { mmA = 0; ++relA; }
+		issueLines(0, vE); // (block nS + 1)
+		mmA = keepA; relA = keepRA; mmL = keepL; relL = keepRL;
+	}
 	landed(vO);
 	for (int n = nS; n < n1; n += 2) {
 		step(n, 1, vO, vE);
@@ -334,7 +367,7 @@ __global__ __launch_bounds__(64*kContWaves) __attribute__((amdgpu_waves_per_eu(3
 	if (nhPrev == 0 && nhCur == 0) return;
 	const int n0 = a.n0;
 	const int n1 = nhCur > 0 ? a.n1 : min(a.n1, P*a.tile + 62); // (only rows finishing tile - 1: row r is done after block P*tile - 3 + r)
-	const int wave = threadIdx.x >> 6, k = threadIdx.x & 63;
+	const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), k = threadIdx.x & 63; // (scalar: what depends on it and the block number alone runs on the scalar unit)
 	const int PQ0 = P*a.tile, PQ1 = PQ0 + P;
 	auto posOf = [&](int m) { TilePos t; t.rel = (m >= PQ0 ? 1 : 0) + (m >= PQ1 ? 1 : 0); t.mm = m - PQ0 + P - P*t.rel; return t; };
 
@@ -354,36 +387,52 @@ __global__ __launch_bounds__(64*kContWaves) __attribute__((amdgpu_waves_per_eu(3
 		if (wave == 4) {
 			// ---------------- writer: whole aligned 128-byte lines of OUT, as kVocoder's (lag 8: rows of one parity complete a line per block) ----------------
 			const int g8 = k & 7, part = k >> 3;
+			// which of this lane's rows hold a hop, per tile of the launch: bit rel*8 + pass*2 + par for row 2*(8*pass + g8) + par
+			unsigned active = 0;
+#pragma unroll
+			for (int rel = 0; rel < 2; ++rel) {
+#pragma unroll
+				for (int j = 0; j < 8; ++j) {
+					const int row = 2*(8*(j >> 1) + g8) + (j & 1);
+					if (rowInfo[(((a.tile + 1 + rel) & 1) << 6) + row].flags & HOP_ACTIVE) active |= 1u << (rel*8 + j);
+				}
+			}
+			float2 *const outS[2] = {a.OUT[0] + rowOf(d, s, 0, 0), a.OUT[1] + rowOf(d, s, 0, 0)}; // the stream's first row in both workspaces (scalar)
+			const int Mp = d.Mp;
+			int mm0 = posOf(n0).mm, rel0 = posOf(n0).rel; // row 0's position (scalar), stepped once per block
+			const int i0 = (2*part) & 7;
 			for (int n = n0; n < n1; ++n) {
 				while (ldsPeek(&sync[NB + 1]) <= n) __builtin_amdgcn_s_sleep(2);
 				asm volatile("" ::: "memory");
 				const int par = (n + 1) & 1; // the rows whose m = n - row is odd
+				const int rbNow = n%OB, rbBefore = (n + OB - 1)%OB; // (scalar; n0 - 1 >= -1)
+				const int rb = (part < 4) ? rbBefore : rbNow;      // bins 16G .. 16G+7 came with the block before
 #pragma unroll
 				for (int pass = 0; pass < 4; ++pass) {
 					const int row = 2*(8*pass + g8) + par;
-					const TilePos t = posOf(n - row);
-					const int G16 = (t.mm - 1) >> 1;                 // the line whose upper half this block produced
-					const RowInfo ri = rowInfo[(((a.tile + 1 + t.rel) & 1) << 6) + row];
-					const bool ok = t.rel <= 1 && (ri.flags & HOP_ACTIVE) && G16 < ML;
+					int mm = mm0 - row, rel = rel0;
+					if (mm < 0) { mm += P; --rel; }
+					const int G16 = (mm - 1) >> 1;                   // the line whose upper half this block produced
+					const bool ok = rel >= 0 && rel <= 1 && ((active >> (rel*8 + pass*2 + par)) & 1u) && G16 < ML;
 					const int b = 16*G16 + 2*part;
-					const int nb = (part < 4) ? n - 1 : n, i0 = (2*part) & 7; // bins 16G .. 16G+7 came with the block before
-					const int rb = ((nb%OB) + OB)%OB;
 #pragma unroll
 					for (int c = 0; c < CH; ++c) {
 						const float2 v0 = outRing[((rb*BS + i0)*CH + c)*kVocOutPitch + row], v1 = outRing[((rb*BS + i0 + 1)*CH + c)*kVocOutPitch + row];
 						if (ok) {
-							float2 *dst = ((t.rel & 1) ? a.OUT[1] : a.OUT[0]) + rowOf(d, s, row, c) + b;
+							float2 *dst = (rel ? outS[1] : outS[0]) + ((row*CH + c)*Mp + b); // (a row's offset within its stream: 32 bits)
 							dst[0] = v0;
 							dst[1] = v1;
 						}
 					}
 				}
 				asm volatile("" ::: "memory");
-				if ((n & 15) == 15) { // every 16 blocks: the stores so far have reached memory -- what the producer of row 0 waits for before it reads them back
-					asyncWait<0>();
-					if (k == 0) ldsPost(&sync[NB + 3], n + 1);
-				}
-				if (k == 0) ldsPost(&sync[NB + 2], n + 1);
+				// What the producer of row 0 needs before it reads these rows back: how far the stores have COMPLETED.  This wave issues nothing
+				// but stores to memory (at most 4 passes x CH x 2 per block) and stores complete in order, so "all but the youngest 3 blocks'
+				// worth" is a wait by count that never stalls in practice.  (The first form drained them all -- s_waitcnt vmcnt(0) -- every 16
+				// blocks: a few microseconds in which the recurrence ran into the writer's two-block ring, +11 % on the whole kernel.)
+				asyncWait<3*4*CH*2>();
+				if (k == 0) { ldsPost(&sync[NB + 2], n + 1); if ((n & 15) == 15) ldsPost(&sync[NB + 3], n - 2); }
+				if (++mm0 == P) { mm0 = 0; ++rel0; }
 			}
 			return;
 		}

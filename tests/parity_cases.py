@@ -1093,7 +1093,7 @@ def case_synth_emit_equals_two_kernels(lib, monkeypatch, presets=(("cheaper", 48
 def case_continuous_equals_tiled(lib, monkeypatch, geometry=dict(block=1920, interval=480), channel_counts=(2, 1), streams=3, ratios=(1.5, 1.0),
                                  seconds=None):
     """The recurrence as ONE wavefront through all tiles of a call (kVocoderCont: lane r takes hops r, r + 64, ... without draining,
-    a launch finishes tile t-1 and begins tile t) against the tile-by-tile kernel (SMST_NO_CONTINUOUS=1): same records, same
+    a launch finishes tile t-1 and begins tile t; SMST_CONTINUOUS=1) against the tile-by-tile kernel (the default): same records, same
     arithmetic, so outputs AND the state a call leaves behind must be bit-identical -- over three calls (the second and third start
     from the state the continuous form handed over; the third is short: one tile, the tile form on both sides), with ragged stream
     lengths (a stream whose last tile is not the call's last), at 1.5x (every hop re-analyses its previous spectrum) and at 1.0x
@@ -1119,9 +1119,9 @@ def case_continuous_equals_tiled(lib, monkeypatch, geometry=dict(block=1920, int
             outs, states = [], []
             for tiled in (False, True):
                 if tiled:
-                    monkeypatch.setenv("SMST_NO_CONTINUOUS", "1")
+                    monkeypatch.delenv("SMST_CONTINUOUS", raising=False)
                 else:
-                    monkeypatch.delenv("SMST_NO_CONTINUOUS", raising=False)
+                    monkeypatch.setenv("SMST_CONTINUOUS", "1")
                 before = pkg.launch_count("vocoder_continuous", lib), pkg.launch_count("vocoder_aligned", lib)
                 b = pkg.StretchBatch(streams, C, lib=lib, **(geometry if "block" in geometry else dict(sample_rate=sr, **geometry)))
                 assert b.intervalSamples() == I
@@ -1137,7 +1137,7 @@ def case_continuous_equals_tiled(lib, monkeypatch, geometry=dict(block=1920, int
                 assert (grew[0] == 0 and grew[1] > 0) if tiled else (grew[0] >= 3 + 3), (tiled, grew)  # (the first call's first tile holds the hop after the reset, with random time factors: tile by tile)
                 outs.append((y1, y2, y3))
                 states.append((st1, st3))
-            monkeypatch.delenv("SMST_NO_CONTINUOUS", raising=False)
+            monkeypatch.delenv("SMST_CONTINUOUS", raising=False)
             assert float(np.abs(outs[0][0]).max()) > 0.05
             for i, (p, q) in enumerate(zip(outs[0], outs[1])):
                 assert np.array_equal(p, q), (C, ratio, "call", i, float(np.abs(p - q).max()), np.argwhere(p != q)[:4].tolist())
