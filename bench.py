@@ -345,6 +345,48 @@ def self_launch_command(gpus, oversubscribe, visible_devices, argv, environ):
     return cmd, env
 
 
+def other_measurements():
+    """Short runs of BASELINE configs 3 / 4b / 5 (2 timed steps each) and 300 quanta of the real-time calling pattern at 4096 streams, each
+    in a fresh process (this script / tools/bench_realtime.py).  Then tools/bench_dropin.cpp: 64 reference-style objects against the batch API.
+    Returns (other_configs, realtime, dropin); a run that fails is reported as such."""
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ)
+    others = {}
+    for cfg in ("3", "4b", "5"):
+        cmd = [sys.executable, os.path.abspath(__file__), "--config", cfg, "--steps", "2", "--warmup", "2", "--no-cpu-baseline", "--no-serial-pass", "--no-other-configs"]
+        t0 = time.perf_counter()
+        try:
+            r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=240)
+            d = json.loads(r.stdout.strip().splitlines()[-1])
+            rl = d.get("roofline") or {}
+            sc = d.get("self_check") or {}
+            others[cfg] = dict(workload=d["config"]["workload"], value=d["value"], unit=d["unit"], ms_per_step=d["ms_per_step"], steps=d["steps"], frac=rl.get("frac"),
+                               realtime_x=d.get("realtime_x"), traffic=rl.get("traffic"), recurrence_ms_per_launch=(rl.get("dominant_kernel") or {}).get("avg_launch_ms"),
+                               self_check={k: sc.get(k) for k in ("checked", "ok", "rel_rms", "bound", "level_ratio") if k in sc}, run_seconds=round(time.perf_counter() - t0, 1))
+        except Exception as e:
+            others[cfg] = dict(error=str(e)[:300], run_seconds=round(time.perf_counter() - t0, 1))
+    realtime = None
+    t0 = time.perf_counter()
+    try:
+        r = subprocess.run([sys.executable, os.path.join(here, "tools", "bench_realtime.py"), "--streams", "4096", "--quanta", "300"], env=env, capture_output=True, text=True, timeout=240)
+        d = json.loads(r.stdout.strip().splitlines()[-1])
+        realtime = dict(pattern=d["pattern"], quanta_timed=d["quanta_timed"], **d["rows"][0], run_seconds=round(time.perf_counter() - t0, 1))
+    except Exception as e:
+        realtime = dict(error=str(e)[:300], run_seconds=round(time.perf_counter() - t0, 1))
+    dropin = None
+    t0 = time.perf_counter()
+    try:
+        exe = os.path.join(here, "signalsmith-stretch_amd", "bench_dropin")
+        r = subprocess.run([exe, "64", "1", "6"], env=env, capture_output=True, text=True, timeout=240)
+        dropin = json.loads(r.stdout.strip().splitlines()[-1])
+        dropin["what"] = ("64 independent SignalsmithStretch<float> objects (the reference's class through the drop-in header: one single-stream engine per object, host "
+                          "buffers, synchronous copies per call) called from one thread, against the same 64 streams through smst_batch_* with host buffers")
+        dropin["run_seconds"] = round(time.perf_counter() - t0, 1)
+    except Exception as e:
+        dropin = dict(error=str(e)[:300], run_seconds=round(time.perf_counter() - t0, 1))
+    return others, realtime, dropin
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -364,6 +406,8 @@ def main():
     ap.add_argument("--dump-output", default=None, help="write rank-local output of the first streams to this .npy prefix (oversubscribe cross-check)")
     ap.add_argument("--no-numa-pinning", action="store_true", help="with --gpus > 1: leave every rank's CPU affinity as the launcher set it (default: pin each rank's host scheduler to the CPUs of its GPU's NUMA node, and FAIL if that node cannot be read)")
     ap.add_argument("--half-state", action="store_true", help="BASELINE config 5 'fp16 internal': carried state and overlap-add sums stored in fp16 (SMST_FLAG_HALF_STATE)")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the short runs of configs 3 / 4b / 5 and of the real-time pattern that the default (config 2, one GPU) "
+                    "invocation appends to its line under `other_configs` / `realtime` (each in a process of its own, AFTER the timed region)")
     ap.add_argument("--config", default="2", choices=["2", "3", "4", "4b", "5"],
                     help="BASELINE.json config (default 2 = the one the headline metric is quoted on; the others are "
                          "reported in DESIGN.md, they are not the bench line)")
@@ -485,9 +529,14 @@ def main():
     t0 = time.perf_counter()
     # inputs are complete (synchronised above) and the outputs are only looked at after batch.synchronize(): no per-call
     # ordering against torch's stream, so the host scheduling of step n+1 overlaps the kernels of step n
+    host_wall = 0.0
+    host_cpu0 = time.thread_time()
     for i in range(args.steps):
+        tc = time.perf_counter()
         batch.process(x, n_out, out=y, ordered=False)
+        host_wall += time.perf_counter() - tc
         stamp(i + 1)
+    host_cpu = time.thread_time() - host_cpu0
     batch.synchronize()
     torch.cuda.synchronize()
     barrier()
@@ -514,6 +563,7 @@ def main():
         samples_per_step = samples_local
     value = samples_per_step*args.steps/elapsed/1e6
     B, I, M = batch.blockSamples(), batch.intervalSamples(), batch.bands()
+    fft_samples = batch.fftSamples()
     hops_per_stream = -(-(total_out//S)//I)
     bytes_per_chop = algorithmic_bytes_per_channel_hop(B, I, M, args.stretch)
     own = own_algorithmic_bytes(B, I, M, args.stretch)
@@ -585,6 +635,14 @@ def main():
                      "figure (whole-path bytes over one kernel's time), kept for continuity -- it is not a statement about this kernel",
                 traffic=(traffic.get("kernels", {}).get(names[dom]) if traffic else None)),
             kernels=per_class, kernel_ms_per_step_alone={k: round(v, 3) for k, v in ms.items()}, library_sha16=sha)
+    others, realtime, dropin = None, None, None
+    if rank == 0 and world == 1 and args.config == "2" and explicit_streams is None and not args.no_other_configs:
+        # The other BASELINE configs and the real-time calling pattern under the same clock as the headline: short runs, each in a process
+        # of its own, after the timed region (the headline's batch is released first).  Reported, never part of `value`.
+        batch.close()
+        del x, y
+        torch.cuda.empty_cache()
+        others, realtime, dropin = other_measurements()
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         try:
@@ -623,10 +681,15 @@ def main():
                                     "%.0f s input per stream per step, device-resident I/O" % (S, args.stretch, args.seconds))
                        if args.config == "2" else "BASELINE config %s (not the headline): %d streams x %d ch per GPU, %d Hz, preset %s, %.0f s per step"
                        % (args.config, S, C, sr_cfg, preset, args.seconds),
-                       "streams_total": world*S, "channels": C, "block": B, "interval": I, "fft": batch.fftSamples(),
+                       "streams_total": world*S, "channels": C, "block": B, "interval": I, "fft": fft_samples,
                        "hops_per_stream_per_step": hops_per_stream, "sharding": sharding,
                        "ranks": placements},
             "realtime_x": world*S*args.seconds*args.steps/elapsed,
+            "host_ms_per_step": {"in_process_call": host_wall/args.steps*1e3, "cpu": host_cpu/args.steps*1e3, "threads": 1,
+                                 "note": "wall time the calling thread spends inside process() per step (the per-stream block scheduler, the table uploads, and the one "
+                                         "host synchronisation of a call: the silence gate's 64-byte-per-stream readback) and the CPU time of that thread; the kernels "
+                                         "run asynchronously beside it.  One such thread per rank: 8 ranks need 8 x this much host time per step, on cores of their own"},
+            "other_configs": others, "realtime": realtime, "dropin_objects_vs_batch": dropin,
             "channels": C,
             "output_finite_nonzero": ok, "self_check": check,
             "roofline": roofline, "cpu_baseline": cpu,

@@ -559,7 +559,7 @@ __global__ __launch_bounds__(64*kVocWaves) __attribute__((amdgpu_waves_per_eu(4,
 	const int s = ACROSS ? blockIdx.x*acrossRows : blockIdx.x, sg = sBase + s;
 	const int nh = ACROSS ? min(acrossRows, acrossStreams - s) : d.nHops[s];
 	if (nh <= 0) return;
-	const int wave = threadIdx.x >> 6, k = threadIdx.x & 63;
+	const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), k = threadIdx.x & 63; // (scalar: what depends on the wave and the block number alone runs on the scalar unit)
 	const int M = d.M;
 	const int steps = M + lag*(nh - 1);
 	const int chunks = (steps + 63) >> 6;
