@@ -530,6 +530,7 @@ def main():
     # inputs are complete (synchronised above) and the outputs are only looked at after batch.synchronize(): no per-call
     # ordering against torch's stream, so the host scheduling of step n+1 overlaps the kernels of step n
     host_wall = 0.0
+    batch.takeHostTimes()  # (zero the engine's own host clock)
     host_cpu0 = time.thread_time()
     for i in range(args.steps):
         tc = time.perf_counter()
@@ -537,6 +538,7 @@ def main():
         host_wall += time.perf_counter() - tc
         stamp(i + 1)
     host_cpu = time.thread_time() - host_cpu0
+    host_engine = batch.takeHostTimes()
     batch.synchronize()
     torch.cuda.synchronize()
     barrier()
@@ -685,10 +687,14 @@ def main():
                        "hops_per_stream_per_step": hops_per_stream, "sharding": sharding,
                        "ranks": placements},
             "realtime_x": world*S*args.seconds*args.steps/elapsed,
-            "host_ms_per_step": {"in_process_call": host_wall/args.steps*1e3, "cpu": host_cpu/args.steps*1e3, "threads": 1,
-                                 "note": "wall time the calling thread spends inside process() per step (the per-stream block scheduler, the table uploads, and the one "
-                                         "host synchronisation of a call: the silence gate's 64-byte-per-stream readback) and the CPU time of that thread; the kernels "
-                                         "run asynchronously beside it.  One such thread per rank: 8 ranks need 8 x this much host time per step, on cores of their own"},
+            "host_ms_per_step": {"work": host_engine["work_ms"]/args.steps, "waiting_for_the_device": (host_engine["wait_tables_ms"] + host_engine["wait_gate_ms"])/args.steps,
+                                 "of_which_silence_gate_readback": host_engine["wait_gate_ms"]/args.steps,
+                                 "in_process_call": host_wall/args.steps*1e3, "cpu": host_cpu/args.steps*1e3, "threads": 1,
+                                 "note": "per step, on the ONE host thread of this rank: `work` = the engine's own host work inside process() (the per-stream block scheduler, "
+                                         "table fills, uploads and kernel enqueues: smst_batch_take_host_times); `waiting_for_the_device` = back-pressure (the host runs at most "
+                                         "two calls ahead of the device) plus the silence gate's 64-byte-per-stream readback -- HIP spins while it waits, so this shows up as "
+                                         "CPU time without being work; in_process_call / cpu = wall and CPU time of the calling thread inside the Python call.  `work` is what "
+                                         "must stay below ms_per_step; 8 ranks need 8 such threads on cores of their own (bench.py pins each to its GPU's NUMA node)"},
             "other_configs": others, "realtime": realtime, "dropin_objects_vs_batch": dropin,
             "channels": C,
             "output_finite_nonzero": ok, "self_check": check,

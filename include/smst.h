@@ -206,6 +206,11 @@ int smst_batch_signal_stream(smst_batch *b, void *hipStream);
  * place on its own stream while the other streams keep overlapping it (ms[7], launches[5]).  0: off. */
 int smst_batch_enable_profiling(smst_batch *b, int mode);
 int smst_batch_take_timings(smst_batch *b, double ms[8], long long launches[6]);
+/* Host time of smst_batch_process since the last take (always counted, no mode): ms[0] wall time inside the calls, of which ms[1] was spent
+ * waiting for the call before the previous one to finish (two sets of per-call tables: the host runs at most two calls ahead of the device --
+ * back-pressure, not work) and ms[2] waiting for the silence gate's readback; ms[0] - ms[1] - ms[2] is the host's own work (block scheduler,
+ * table fills, enqueues).  *calls (may be null): the number of calls.  One host thread per batch: its work must stay below the device's step. */
+int smst_batch_take_host_times(smst_batch *b, double ms[3], long long *calls);
 
 /* test hooks (tests/ only): per-stream state rows.  which: 0 Band.input, 1 Band.prevInput, 2 Band.output
  * (interleaved re,im: 2*channels*bands floats), 3 Prediction.energy (channels*bands floats). */

@@ -98,6 +98,7 @@ _SIGNATURES = {
     "smst_batch_hip_stream": (C.c_void_p, [C.c_void_p]),
     "smst_batch_enable_profiling": (C.c_int, [C.c_void_p, C.c_int]),
     "smst_batch_take_timings": (C.c_int, [C.c_void_p, _dp, C.POINTER(_ll)]),
+    "smst_batch_take_host_times": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(_ll)]),
     "smst_batch_debug_get_state": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _fp]),
     "smst_batch_debug_get_carry": (C.c_int, [C.c_void_p, C.c_int, _fp, _fp]),
     "smst_batch_debug_set_state": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _fp]),
@@ -285,6 +286,13 @@ class StretchBatch:
         self._inflight = inflight
 
     def enableProfiling(self, mode=1): _check(self.lib, self.lib.smst_batch_enable_profiling(self.h, int(mode)))
+
+    def takeHostTimes(self):
+        """Host time of process() since the last take: dict(call_ms, wait_tables_ms, wait_gate_ms, work_ms, calls) -- see include/smst.h"""
+        ms = (C.c_double*3)()
+        n = _ll(0)
+        _check(self.lib, self.lib.smst_batch_take_host_times(self.h, ms, C.byref(n)))
+        return dict(call_ms=ms[0], wait_tables_ms=ms[1], wait_gate_ms=ms[2], work_ms=ms[0] - ms[1] - ms[2], calls=int(n.value))
 
     def takeTimings(self):
         ms = (C.c_double*8)()

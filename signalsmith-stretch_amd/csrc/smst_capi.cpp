@@ -142,6 +142,13 @@ int smst_batch_take_timings(smst_batch *b, double ms[8], long long launches[6]) 
 		ms[7] = t.chainLiveMs; launches[5] = t.chainLiveLaunches;
 	})
 }
+int smst_batch_take_host_times(smst_batch *b, double ms[3], long long *calls) {
+	BATCH_CALL({
+		const smst::Batch::HostTimes t = b->engine->takeHostTimes();
+		ms[0] = t.callMs; ms[1] = t.waitTablesMs; ms[2] = t.waitGateMs;
+		if (calls) *calls = t.calls;
+	})
+}
 int smst_batch_debug_get_state(smst_batch *b, int stream, int which, float *dst) { BATCH_CALL(b->engine->debugGetState(stream, which, dst)) }
 int smst_batch_debug_get_carry(smst_batch *b, int stream, float *sums, float *products) { BATCH_CALL(b->engine->debugGetCarry(stream, sums, products)) }
 int smst_batch_debug_set_state(smst_batch *b, int stream, int which, const float *src) { BATCH_CALL(b->engine->debugSetState(stream, which, src)) }

@@ -3,6 +3,7 @@
 #include "smst_switches.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <complex>
 #include <cstdlib>
@@ -1181,6 +1182,8 @@ void Batch::runTilesContinuous(const TileRun &run, int tile0, int tile1, int car
 void Batch::process(const float *in, long long inSS, long long inCS, const int *inSamples,
                     float *out, long long outSS, long long outCS, const int *outSamples, const unsigned char *active) {
 	SMST_HIP(hipSetDevice(dev));
+	const auto hostT0 = std::chrono::steady_clock::now();
+	auto msSince = [](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count(); };
 	uploadParams();
 	// This call's tables go into the set that the call before the previous one used (its kernels must have finished);
 	// everything up to the first tile launch runs on `stGate`, so the host-side scheduling of this call overlaps the
@@ -1188,7 +1191,7 @@ void Batch::process(const float *in, long long inSS, long long inCS, const int *
 	// uploads are asynchronous and the ONLY host synchronisation of a call is the silence-gate readback.
 	callCur ^= 1;
 	CallSet &cs = callSets[callCur];
-	if (cs.used) SMST_HIP(hipEventSynchronize(cs.done));
+	if (cs.used) { const auto t = std::chrono::steady_clock::now(); SMST_HIP(hipEventSynchronize(cs.done)); hostTimes.waitTablesMs += msSince(t); }
 	dInSamples = cs.inSamples; dOutSamples = cs.outSamples; dFlags = cs.flags;
 	const int T = d.T;
 	int *nIn = cs.hInSamples, *nOut = cs.hOutSamples;
@@ -1208,7 +1211,7 @@ void Batch::process(const float *in, long long inSS, long long inCS, const int *
 	// K5: silence gate needs the input energy on the host (one 64-byte-per-stream readback per call)
 	launchEnergy(d, io, 0, S, maxIn, dEnergy, stGate);
 	SMST_HIP(hipMemcpyAsync(cs.hEnergy, dEnergy, (size_t)S*kEnergyParts*sizeof(float), hipMemcpyDeviceToHost, stGate));
-	SMST_HIP(hipStreamSynchronize(stGate));
+	{ const auto t = std::chrono::steady_clock::now(); SMST_HIP(hipStreamSynchronize(stGate)); hostTimes.waitGateMs += msSince(t); }
 
 	// K0, pass 1: silence gate (signalsmith-stretch.h:231-278) and the number of hops each stream fires in this call
 	int *passFlags = cs.hFlags;
@@ -1505,6 +1508,8 @@ void Batch::process(const float *in, long long inSS, long long inCS, const int *
 	SMST_HIP(hipEventRecord(cs.done, st));
 	cs.used = true;
 	SMST_HIP(hipGetLastError());
+	hostTimes.callMs += msSince(hostT0);
+	++hostTimes.calls;
 }
 
 // ---- seek -------------------------------------------------------------------------------------------------

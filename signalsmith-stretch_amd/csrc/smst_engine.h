@@ -93,6 +93,11 @@ public:
 	void growLivePool(size_t pairs);
 	void enableProfiling(int mode); // 1: every kernel class, serialised; 2: recurrence kernel in place (timing events come from a pool created here, not inside process())
 	BatchTimings takeTimings();
+	// Host time of process() since the last take: wall time inside the calls, the part of it spent WAITING for the device (the call before the
+	// previous one to finish -- there are two sets of per-call tables -- and the silence gate's readback), and the number of calls.  What is
+	// left is the host's own work: the per-stream block scheduler, the table fills and the enqueues.
+	struct HostTimes { double callMs = 0, waitTablesMs = 0, waitGateMs = 0; long calls = 0; };
+	HostTimes takeHostTimes() { HostTimes t = hostTimes; hostTimes = HostTimes(); return t; }
 	size_t workspaceBytes() const { return wsBytes; }
 	long allocationEvents() const { return allocEvents; } // test hook: must not move across steady-state process() calls
 	// order the batch's work after everything already enqueued on `other` / make `other` wait for the batch's work so far
@@ -191,6 +196,7 @@ private:
 	std::vector<std::pair<hipEvent_t, hipEvent_t>> liveEvents; // pairs recorded since the last takeTimings()
 	std::vector<std::pair<hipEvent_t, hipEvent_t>> livePool;   // every pair ever created; [0, liveEvents.size()) are in use
 	BatchTimings timings;
+	HostTimes hostTimes;
 
 	std::vector<void *> allocations;
 	float *dEnergy = nullptr;
