@@ -228,6 +228,12 @@ long long smst_batch_debug_allocation_events(const smst_batch *b);
 /* output map of the stream's newest hop (2*bands floats: inputBin, freqGrad per bin; signalsmith-stretch.h:587-590,
  * :882-917).  Returns 1 if that hop had a frequency map, 0 if not (dst untouched), negative on error. */
 int smst_batch_debug_get_map(smst_batch *b, int stream, float *dst);
+/* the formant stage of the stream's newest hop (signalsmith-stretch.h:972-1036): ratio[bands] = the per-bin energy ratio applied to every channel's
+ * inputEnergy (:1026-1033), envelope[bands] = formantMetric after its eight max-decay / min-grow passes (:984-1006), *freqEstimate = the pitch
+ * estimate in bins the envelope was built with (:980-981, :929-966).  Available only in a batch created with SMST_NO_FEED_FUSION=1 (the separate
+ * envelope kernel writes them; the default form keeps them in LDS and is bit-identical to it: test_feed_fusion_equals_separate).  Returns 1, or 0
+ * if that hop had no formant processing / the batch runs the fused kernels (destinations untouched), negative on error. */
+int smst_batch_debug_get_formants(smst_batch *b, int stream, float *ratio, float *envelope, float *freqEstimate);
 /* the kernels' packed complex helpers (csrc/smst_complex.h, gfx950 inline assembly) evaluated on the device: in = n x
  * (a.re, a.im, b.re, b.im, c.re, c.im, fraction), out = n x (a*b, a*conj(b), a*b + c, a + (b - a)*fraction) as 8 floats. */
 int smst_debug_complex_selftest(int device, const float *in, float *out, int n);

@@ -104,6 +104,7 @@ _SIGNATURES = {
     "smst_batch_debug_set_state": (C.c_int, [C.c_void_p, C.c_int, C.c_int, _fp]),
     "smst_batch_debug_set_carry": (C.c_int, [C.c_void_p, C.c_int, _fp, _fp]),
     "smst_batch_debug_get_map": (C.c_int, [C.c_void_p, C.c_int, _fp]),
+    "smst_batch_debug_get_formants": (C.c_int, [C.c_void_p, C.c_int, _fp, _fp, _fp]),
     "smst_batch_debug_allocation_events": (_ll, [C.c_void_p]),
     "smst_batch_wait_for_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
     "smst_batch_signal_stream": (C.c_int, [C.c_void_p, C.c_void_p]),
@@ -417,6 +418,15 @@ class StretchBatch:
         if rc < 0:
             _check(self.lib, rc)
         return a if rc == 1 else None
+
+    def debug_formants(self, stream):
+        """(ratio[bands], envelope[bands], freqEstimate in bins) of the stream's newest hop, or None (no formant processing in that hop, or a
+        batch that was not created with SMST_NO_FEED_FUSION=1)."""
+        ratio, env, fe = np.zeros(self.bands(), np.float32), np.zeros(self.bands(), np.float32), np.zeros(1, np.float32)
+        rc = self.lib.smst_batch_debug_get_formants(self.h, stream, ratio.ctypes.data_as(_fp), env.ctypes.data_as(_fp), fe.ctypes.data_as(_fp))
+        if rc < 0:
+            _check(self.lib, rc)
+        return (ratio, env, float(fe[0])) if rc == 1 else None
 
     def allocation_events(self):
         return int(self.lib.smst_batch_debug_allocation_events(self.h))

@@ -173,6 +173,13 @@ int smst_debug_complex_selftest(int device, const float *in, float *out, int n) 
 	SMST_CATCH
 }
 long long smst_debug_launch_count(const char *name) { return smst::launchCount(name); }
+int smst_batch_debug_get_formants(smst_batch *b, int stream, float *ratio, float *envelope, float *freqEstimate) {
+	if (!b || !b->engine) return fail("null batch");
+	if (!ratio || !envelope || !freqEstimate) return fail("null destination");
+	SMST_TRY
+	return b->engine->debugGetFormants(stream, ratio, envelope, freqEstimate) ? 1 : 0;
+	SMST_CATCH
+}
 int smst_batch_debug_get_map(smst_batch *b, int stream, float *dst) {
 	if (!b || !b->engine) return fail("null batch");
 	SMST_TRY

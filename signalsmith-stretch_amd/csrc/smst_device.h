@@ -74,6 +74,8 @@ struct DevBatch {
 	float4 *REC;    // skewed per-step records of the bin recurrence [subS][recSteps][chunks][64 lanes]
 	float2 *map;    // [subS][T][M]
 	float *ratio;   // [subS][T][M]
+	float *envelope; // [subS][T][M] test hook: the formant envelope (formantMetric after its eight passes, :984-1006) of every hop -- written only by the
+	                 // separate envelope kernel (SMST_NO_FEED_FUSION=1), null otherwise (smst_batch_debug_get_formants)
 	float *energyT, *smoothT; // [subS][M][64 hops]: feed scratch, hop index fastest
 	float2 *peaksT;           // [subS][M/2 + 2][64 hops]
 	float *est;     // [subS][T][2]

@@ -507,6 +507,7 @@ void Batch::allocateWorkspace() {
 				w.dump = devAlloc<float2>((size_t)subS*C*64);
 				w.map = devAlloc<float2>((size_t)subS*d.T*M);
 				w.ratio = devAlloc<float>((size_t)subS*d.T*M);
+				if (d.noFeedFusion) w.envelope = devAlloc<float>((size_t)subS*d.T*M); // (test hook: smst_batch_debug_get_formants)
 				if (d.feedSerial) {
 					w.energyT = devAlloc<float>((size_t)subS*M*64);
 					w.smoothT = devAlloc<float>((size_t)subS*M*64);
@@ -870,6 +871,7 @@ void Batch::runPendingBlocks(const int *synthChannels) {
 		lh.local = 0;
 		lh.subLocal = sl;
 		lh.mapped = (pb.flags & HOP_MAPPED) != 0;
+		lh.formants = (pb.flags & HOP_FORMANTS) != 0;
 	}
 	SMST_HIP(hipMemcpyAsync(ps.hops, ps.hHops, S*sizeof(HopDesc), hipMemcpyHostToDevice, st));
 	SMST_HIP(hipMemcpyAsync(ps.emit, ps.hEmit, S*sizeof(EmitDesc), hipMemcpyHostToDevice, st));
@@ -973,7 +975,7 @@ void Batch::runTilesRange(const TileRun &run, int tile0, int tile1, int carryFir
 			const TileBuffers &w = slots[slot];
 			DevBatch dd = d;
 			dd.Xcur = w.Xcur; dd.Xprev = w.Xprev; dd.PE = w.PE; dd.OUT = w.OUT; dd.REC = w.REC; dd.dump = w.dump;
-			dd.map = w.map; dd.ratio = w.ratio; dd.energyT = w.energyT; dd.smoothT = w.smoothT; dd.peaksT = w.peaksT; dd.est = w.est; dd.freqEst = w.freqEst; dd.frames = w.frames;
+			dd.map = w.map; dd.ratio = w.ratio; dd.envelope = w.envelope; dd.energyT = w.energyT; dd.smoothT = w.smoothT; dd.peaksT = w.peaksT; dd.est = w.est; dd.freqEst = w.freqEst; dd.frames = w.frames;
 			dd.carryCur = (carryFirst + t) & 1;
 			dd.nHops = run.dTileInfo + ((size_t)(sub*nTiles + t)*2)*subS;
 			dd.lastNewHop = dd.nHops + subS;
@@ -1456,6 +1458,7 @@ void Batch::process(const float *in, long long inSS, long long inCS, const int *
 				lh.local = cnt - 1;
 				lh.subLocal = sl;
 				lh.mapped = (list[h1 - 1].flags & HOP_MAPPED) != 0;
+				lh.formants = (list[h1 - 1].flags & HOP_FORMANTS) != 0;
 			}
 			int &span = maxSpanV[(size_t)sub*nTiles + t];
 			span = std::max(span, ed.nHi - ed.nLo);
@@ -1821,6 +1824,18 @@ bool Batch::debugGetMap(int stream, float *dst) {
 	SMST_HIP(hipSetDevice(dev));
 	SMST_HIP(hipStreamSynchronize(st));
 	SMST_HIP(hipMemcpy(dst, slots[lh.slot].map + ((size_t)lh.subLocal*d.T + lh.local)*M, (size_t)M*sizeof(float2), hipMemcpyDeviceToHost));
+	return true;
+}
+bool Batch::debugGetFormants(int stream, float *ratio, float *envelope, float *freqEstimate) {
+	if (stream < 0 || stream >= S) throw Error("debugGetFormants: bad stream");
+	const LastHop &lh = lastHop[stream];
+	if (lh.slot < 0 || !lh.formants || !slots[lh.slot].envelope) return false;
+	SMST_HIP(hipSetDevice(dev));
+	SMST_HIP(hipStreamSynchronize(st));
+	const size_t row = (size_t)lh.subLocal*d.T + lh.local;
+	SMST_HIP(hipMemcpy(ratio, slots[lh.slot].ratio + row*M, (size_t)M*sizeof(float), hipMemcpyDeviceToHost));
+	SMST_HIP(hipMemcpy(envelope, slots[lh.slot].envelope + row*M, (size_t)M*sizeof(float), hipMemcpyDeviceToHost));
+	SMST_HIP(hipMemcpy(freqEstimate, slots[lh.slot].freqEst + row, sizeof(float), hipMemcpyDeviceToHost));
 	return true;
 }
 void Batch::debugGetCarry(int stream, float *sums, float *products) {

@@ -123,6 +123,9 @@ public:
 	// output map (inputBin, freqGrad per bin, signalsmith-stretch.h:587-590) of the stream's last hop of the last process()
 	// call; false if that hop had no frequency map
 	bool debugGetMap(int stream, float *dst);
+	// formant stage of the stream's newest hop of the last process() call (separate feed kernels only): energy ratio per bin, envelope per bin,
+	// the pitch estimate in bins; false if that hop had no formant processing or the batch runs the fused feed kernels
+	bool debugGetFormants(int stream, float *ratio, float *envelope, float *freqEstimate);
 
 private:
 	int S, C, B, I, N, M, L;
@@ -146,7 +149,7 @@ private:
 	} callSets[2]{};
 	int callCur = 0;
 	hipEvent_t evStart = nullptr, evFeed[3] = {nullptr, nullptr, nullptr}, evChain[3] = {nullptr, nullptr, nullptr}, evOut[3] = {nullptr, nullptr, nullptr}, evSynth[3] = {nullptr, nullptr, nullptr}; // (the third set: the continuous wavefront's tile pipeline is one stage deeper)
-	struct TileBuffers { float2 *Xcur, *Xprev, *OUT, *dump, *map, *peaksT; float4 *REC; PredEntry *PE; float *ratio, *energyT, *smoothT, *est, *freqEst, *frames; } slots[3]{}; // [2]: only what a plain tile touches, only where the continuous wavefront applies (allocateWorkspace)
+	struct TileBuffers { float2 *Xcur, *Xprev, *OUT, *dump, *map, *peaksT; float4 *REC; PredEntry *PE; float *ratio, *envelope, *energyT, *smoothT, *est, *freqEst, *frames; } slots[3]{}; // [2]: only what a plain tile touches, only where the continuous wavefront applies (allocateWorkspace)
 	bool overlap = true, noFuse = false, noSingleHop = false, noAcross = false, carriedEmit = true, continuous = false; // (smst_switches.h)
 	float2 *dContSave = nullptr; // kVocoderCont: the recurrence wave's history between two launches, [S][8*C*64]
 	double workspaceGiB = 0;
@@ -160,7 +163,7 @@ private:
 	DevBatch d{};
 	std::vector<StreamSched> sched;
 	unsigned lcgHopJump = 1; // 16807^(2M - 2) mod (2^31 - 1): what one randomised hop advances a stream's engine by
-	struct LastHop { int slot = -1, local = -1, subLocal = 0; bool mapped = false; };
+	struct LastHop { int slot = -1, local = -1, subLocal = 0; bool mapped = false, formants = false; };
 	std::vector<LastHop> lastHop; // where each stream's newest hop sits in the tile workspaces (debugGetMap)
 	std::vector<StreamParams> params;
 	bool paramsDirty = true;

@@ -123,7 +123,7 @@ __global__ __launch_bounds__(64) void kFeedSerial(DevBatch d, int sBase, int hop
 					inRun = false;
 					const float avgBand = bandSum/energySum;
 					const float avgFreq = (avgBand + 0.5f)/Nf;
-					if (mapped) pk[(size_t)nPeaks*64] = make_float2(avgBand, mapFreqDev(d, prm, sg, avgFreq)*Nf - 0.5f);
+					if (mapped) pk[(size_t)nPeaks*64] = make_float2(avgBand, freqToBandDev(mapFreqDev(d, prm, sg, avgFreq), Nf));
 					++nPeaks;
 				}
 			}
@@ -208,7 +208,7 @@ __global__ __launch_bounds__(64) void kFeedSerial(DevBatch d, int sBase, int hop
 				d.est[((size_t)s*d.T + k)*2 + 1] = ww;
 			}
 		}
-		float freqEstimate = prmF0.formantBaseFreq*Nf - 0.5f; // freqToBand, :982
+		float freqEstimate = freqToBandDev(prmF0.formantBaseFreq, Nf); // freqToBand, :982
 		if (__any(autoBase)) { // :962-965 -- the estimate is smoothed from hop to hop: replay the hops of the tile in order
 			float w = d.stFreq[2*sg], wt = d.stFreq[2*sg + 1];
 			float mine = 0;
@@ -249,10 +249,10 @@ __global__ __launch_bounds__(64) void kFeedSerial(DevBatch d, int sBase, int hop
 				float inputF = (b + 0.5f)/Nf;
 				float outputF = prmF2.formantCompensation ? mapFreqDev(d, prmF2, sg, inputF) : inputF;
 				// invMapFormant, :920-925
-				if (outputF*prmF2.invFormantMultiplier > prmF2.freqTonalityLimit) outputF = outputF + (1 - prmF2.formantMultiplier)*prmF2.freqTonalityLimit;
+				if (outputF*prmF2.invFormantMultiplier > prmF2.freqTonalityLimit) outputF = mulAdd2(1 - prmF2.formantMultiplier, prmF2.freqTonalityLimit, outputF);
 				else outputF = outputF*prmF2.invFormantMultiplier;
 				const float inputE = sT[(size_t)b*64];
-				float band = outputF*Nf - 0.5f;
+				float band = freqToBandDev(outputF, Nf);
 				float targetE = 0;
 				if (!(band < 0)) { // getFormant, :1009-1016 (entries M and M+1 of the metric are zero)
 					band = fminf(band, float(M));
@@ -508,7 +508,7 @@ __global__ __launch_bounds__(256) void kFeedScanA(DevBatch d, int sBase, int hop
 				}
 				const float avgBand = bandSum/energySum;
 				const float avgFreq = (avgBand + 0.5f)/Nf;
-				pk[idx++] = make_float2(avgBand, mapFreqDev(d, prm, sg, avgFreq)*Nf - 0.5f);
+				pk[idx++] = make_float2(avgBand, freqToBandDev(mapFreqDev(d, prm, sg, avgFreq), Nf));
 			}
 		}
 		__syncthreads();
@@ -646,7 +646,7 @@ __global__ __launch_bounds__(64) void kFeedFreq(DevBatch d, int sBase, int nStre
 	float w = d.stFreq[2*sg], wt = d.stFreq[2*sg + 1];
 	for (int j = 0; j < nh; ++j) {
 		const HopDesc hj = d.hops[(size_t)sg*d.hopStride + hopBase + j];
-		float fe = prm.formantBaseFreq*Nf - 0.5f; // freqToBand, :982
+		float fe = freqToBandDev(prm.formantBaseFreq, Nf); // freqToBand, :982
 		if ((hj.flags & HOP_FORMANTS) && prm.formantBaseFreq <= 0) {
 			w += (d.est[((size_t)s*d.T + j)*2] - w)*0.25f;
 			wt += (d.est[((size_t)s*d.T + j)*2 + 1] - wt)*0.25f;
@@ -730,10 +730,10 @@ __global__ __launch_bounds__(256) void kFeedScanC(DevBatch d, int sBase, int hop
 	for (int b = t; b < M; b += 256) {
 		float inputF = (b + 0.5f)/Nf;
 		float outputF = prm.formantCompensation ? mapFreqDev(d, prm, sg, inputF) : inputF;
-		if (outputF*prm.invFormantMultiplier > prm.freqTonalityLimit) outputF = outputF + (1 - prm.formantMultiplier)*prm.freqTonalityLimit; // invMapFormant, :920-925
+		if (outputF*prm.invFormantMultiplier > prm.freqTonalityLimit) outputF = mulAdd2(1 - prm.formantMultiplier, prm.freqTonalityLimit, outputF); // invMapFormant, :920-925
 		else outputF = outputF*prm.invFormantMultiplier;
 		const float inputE = sm[b];
-		float band = outputF*Nf - 0.5f;
+		float band = freqToBandDev(outputF, Nf);
 		float targetE = 0;
 		if (!(band < 0)) { // getFormant, :1009-1016 (entries M and M+1 of the metric are zero)
 			band = fminf(band, float(M));
@@ -743,7 +743,7 @@ __global__ __launch_bounds__(256) void kFeedScanC(DevBatch d, int sBase, int hop
 			targetE = low + (high - low)*fr;
 		}
 		if constexpr (FUSE_PE) en[b] = targetE/(inputE + 1e-30f); // the energies are dead: the ratios take their place in LDS
-		else ratio[b] = targetE/(inputE + 1e-30f);
+		else { ratio[b] = targetE/(inputE + 1e-30f); if (d.envelope) d.envelope[((size_t)s*d.T + k)*M + b] = inputE; }
 	}
 	if constexpr (FUSE_PE) {
 		__syncthreads();

@@ -17,18 +17,24 @@ __device__ __forceinline__ const float2 *prevRow(const DevBatch &d, const HopDes
 	return (hd.prevSrc >= 0 || hd.prevSrc == SRC_REANALYSED) ? fromTile : d.stPrev + stateRow(d, sGlobal, c);
 }
 
+// freqToBand (f * fftSamples - 0.5, signalsmith-stretch.h:519-522 through stft.freqToBin) and the two frequency maps with the reference's
+// roundings: a product and a sum, each rounded.  Written as one expression they contract to a fused multiply-add on the device
+// (-ffp-contract=on), which is MORE accurate -- and moves an interpolation position near bin 3000 by an ulp of 2.4e-4 bins against the x86
+// build of the reference: on a steep formant envelope (a chirp's) that was 1e-4 of the energy ratio (round 6: case_formant_stages).
+__device__ __forceinline__ float freqToBandDev(float freq, float Nf) { return __fadd_rn(__fmul_rn(freq, Nf), -0.5f); }
+__device__ __forceinline__ float mulAdd2(float a, float b, float c) { return __fadd_rn(__fmul_rn(a, b), c); } // a*b + c, two roundings
 __device__ __forceinline__ float mapFreqDev(const DevBatch &d, const StreamParams &p, int sGlobal, float freq) { // :850-856
 	if (p.hasCustomMap) {
 		const float *t = d.mapTable + ((size_t)sGlobal*kMapSlots + p.mapSlot)*d.mapTableLen; // row pitch: the longest table of the batch
 		const int n = p.mapLen;                                      // this stream's own knots
-		float pos = freq*2*float(n) - 0.5f;
-		if (pos <= 0) return t[0] + (t[1] - t[0])*pos;
-		if (pos >= n - 1) return t[n - 1] + (t[n - 1] - t[n - 2])*(pos - (n - 1));
+		float pos = __fadd_rn(__fmul_rn(__fmul_rn(freq, 2.0f), float(n)), -0.5f);
+		if (pos <= 0) return mulAdd2(t[1] - t[0], pos, t[0]);
+		if (pos >= n - 1) return mulAdd2(t[n - 1] - t[n - 2], pos - (n - 1), t[n - 1]);
 		int lo = (int)floorf(pos);
 		float fr = pos - lo;
-		return t[lo] + (t[lo + 1] - t[lo])*fr;
+		return mulAdd2(t[lo + 1] - t[lo], fr, t[lo]);
 	}
-	if (freq > p.freqTonalityLimit) return freq + (p.freqMultiplier - 1)*p.freqTonalityLimit;
+	if (freq > p.freqTonalityLimit) return mulAdd2(p.freqMultiplier - 1, p.freqTonalityLimit, freq);
 	return freq*p.freqMultiplier;
 }
 

@@ -235,3 +235,7 @@ def test_split_freq_map_mid_interval_emu(emu, ref):
 
 def test_continuous_equals_tiled_emu(emu, monkeypatch):
     print(pc.case_continuous_equals_tiled(emu, monkeypatch))
+
+
+def test_formant_stages_emu(emu, ref, monkeypatch):
+    print(pc.case_formant_stages(emu, ref, monkeypatch, pc.SMALL, hops=14))

@@ -120,8 +120,9 @@ def test_config4_subset(hip, ref):
 
 
 def test_config5_subset(hip, ref):
-    """config 5 flavour: 8-channel streams, 96 kHz, presetCheaper (split), per-stream random stretch and transpose; 2 s as the bench."""
-    S, n = 4, 192000
+    """config 5 flavour: 8-channel streams, 96 kHz, presetCheaper (split), per-stream random stretch and transpose; 2 s as the bench.
+    Nine streams: three of every signal type (round 5 had four: horizons 24 / 12 / 0 / 24)."""
+    S, n = 9, 192000
     g = np.random.Generator(np.random.PCG64(5))
     stretch = g.uniform(0.75, 1.5, S)
     semis = g.uniform(-12, 12, S)
@@ -721,3 +722,10 @@ def test_continuous_equals_tiled(hip, monkeypatch, variant):
     else:
         monkeypatch.setenv("SMST_ALIGN_ALL", "1")
         _report("continuous_equals_tiled/default96_mono", pc.case_continuous_equals_tiled(hip, monkeypatch, geometry=dict(preset="default", interval=2880, sr=96000), channel_counts=(1,), ratios=(1.5,)))
+
+
+def test_formant_stages(hip, ref, monkeypatch):
+    """the formant stage itself -- envelope, pitch estimate, energy ratio per hop against oracle/_ref's private members,
+    bound 1e-4 -- at presetDefault / 48 kHz on two streams of every signal type, for config 4b's parameters, an estimated base frequency
+    and a formant shift."""
+    _report("formant_stages/D48", pc.case_formant_stages(hip, ref, monkeypatch, D48, hops=30, streams=tuple(range(6))))

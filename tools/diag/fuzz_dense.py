@@ -9,16 +9,8 @@ import importlib
 pkg = importlib.import_module("signalsmith-stretch_amd")
 import ref_oracle, parity_cases as pc
 from conftest import synth_input
-lib = pkg.bind(ctypes.CDLL(os.environ.get("SMST_EMU_LIBRARY", os.path.join(ROOT, "tests", "emu", "libsmst_emu.so")))) if os.environ.get("SMST_FUZZ_EMU") else pkg.load_library()
-lo, hi, split = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3] in ("split", "cheaper48")
-cfg = dict(preset="cheaper", sample_rate=48000.0) if sys.argv[3] == "cheaper48" else (pc.SMALL_SPLIT if split else pc.SMALL)  # cheaper48: presetCheaper at 48 kHz (split computation, interval 1920)
-q = 15 if sys.argv[3] == "cheaper48" else 1  # sample counts are written for an interval of 128
-sr = 48000
-bad, ties = [], []
-for seed in range(lo, hi):
-    C = 1 + seed % 3
-    formants = seed % 4 == 3
-    x = synth_input(seed, C, 30000*q, sr) + 0.4*synth_input(seed + 7, C, 30000*q, sr)
+def make_play(seed, q=1, formants=False, sr=48000):
+    """The walk of seed `seed` as a function play(obj, x) -> concatenated output (q: sample counts are written for an interval of 128)."""
     def play(o, xx, seed=seed, formants=formants):
         rng = np.random.default_rng(5000 + seed)
         pos, outs = 0, []
@@ -45,21 +37,41 @@ for seed in range(lo, hi):
                 n = int(rng.integers(1, 150))*q + int(rng.integers(0, q)); outs.append(o.process(xx[:, pos:pos + n], max(1, int(n*ratio)))); pos += n
         outs.append(o.process(xx[:, pos:pos + 1500*q], 1800*q))
         return np.concatenate([np.asarray(v) for v in outs], axis=1)
-    try:
-        pc.check_scenario(lib, ref_oracle, cfg, x, play, "dense walk %d" % seed, cap=pc.CAP_FORMANT if formants else pc.CAP_TONAL)
-    except AssertionError as e:
-        if "informative" in str(e): print("seed", seed, "uninformative"); continue
-        # A peak boundary of the frequency map is a comparison energy[b] > smoothedEnergy[b] (signalsmith-stretch.h:864-867); the product's
-        # smoothing passes are scans, the reference's a bin-by-bin recursion -- the same values to the last bit or two, and once in some
-        # ten thousand boundaries the reference's two sides are EQUAL (walk 1270: bin 59 of the first mapped hop after a flush), so the
-        # last bit decides where a peak ends and the whole map moves by a tenth of a bin.  SMST_FEED_SERIAL=1 runs the reference's
-        # recursion bit for bit: a walk that passes with it failed on such a tie, not on the algorithm.
-        os.environ["SMST_FEED_SERIAL"] = "1"
+    return play
+
+
+def main():
+    lib = pkg.bind(ctypes.CDLL(os.environ.get("SMST_EMU_LIBRARY", os.path.join(ROOT, "tests", "emu", "libsmst_emu.so")))) if os.environ.get("SMST_FUZZ_EMU") else pkg.load_library()
+    lo, hi, split = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3] in ("split", "cheaper48")
+    cfg = dict(preset="cheaper", sample_rate=48000.0) if sys.argv[3] == "cheaper48" else (pc.SMALL_SPLIT if split else pc.SMALL)  # cheaper48: presetCheaper at 48 kHz (split computation, interval 1920)
+    q = 15 if sys.argv[3] == "cheaper48" else 1  # sample counts are written for an interval of 128
+    sr = 48000
+    bad, ties = [], []
+    for seed in range(lo, hi):
+        C = 1 + seed % 3
+        formants = seed % 4 == 3
+        x = synth_input(seed, C, 30000*q, sr) + 0.4*synth_input(seed + 7, C, 30000*q, sr)
+        play = make_play(seed, q, formants, sr)
         try:
-            pc.check_scenario(lib, ref_oracle, cfg, x, play, "dense walk %d (serial feed)" % seed, cap=pc.CAP_FORMANT if formants else pc.CAP_TONAL)
-            ties.append(seed); print("seed", seed, "rounding tie at a peak boundary (passes with the reference's bin-by-bin smoothing):", str(e)[:160])
-        except AssertionError as e2:
-            bad.append(seed); print("seed", seed, "FAILED", str(e)[:300], "| serial feed:", str(e2)[:200])
-        finally:
-            del os.environ["SMST_FEED_SERIAL"]
-print("walks", hi - lo, "split" if split else "plain", "failed", bad, "peak-boundary ties", ties)
+            pc.check_scenario(lib, ref_oracle, cfg, x, play, "dense walk %d" % seed, cap=pc.CAP_FORMANT if formants else pc.CAP_TONAL)
+        except AssertionError as e:
+            if "informative" in str(e): print("seed", seed, "uninformative"); continue
+            # A peak boundary of the frequency map is a comparison energy[b] > smoothedEnergy[b] (signalsmith-stretch.h:864-867); the product's
+            # smoothing passes are scans, the reference's a bin-by-bin recursion -- the same values to the last bit or two, and once in some
+            # ten thousand boundaries the reference's two sides are EQUAL (walk 1270: bin 59 of the first mapped hop after a flush), so the
+            # last bit decides where a peak ends and the whole map moves by a tenth of a bin.  SMST_FEED_SERIAL=1 runs the reference's
+            # recursion bit for bit: a walk that passes with it failed on such a tie, not on the algorithm.
+            os.environ["SMST_FEED_SERIAL"] = "1"
+            try:
+                pc.check_scenario(lib, ref_oracle, cfg, x, play, "dense walk %d (serial feed)" % seed, cap=pc.CAP_FORMANT if formants else pc.CAP_TONAL)
+                ties.append(seed); print("seed", seed, "rounding tie at a peak boundary (passes with the reference's bin-by-bin smoothing):", str(e)[:160])
+            except AssertionError as e2:
+                bad.append(seed); print("seed", seed, "FAILED", str(e)[:300], "| serial feed:", str(e2)[:200])
+            finally:
+                del os.environ["SMST_FEED_SERIAL"]
+    print("walks", hi - lo, "split" if split else "plain", "failed", bad, "peak-boundary ties", ties)
+
+
+
+if __name__ == "__main__":
+    main()
