@@ -24,10 +24,11 @@
  *
  * Limits the reference does not have (signalsmith-stretch.h:71-94 accepts any channel count and block size); configure / create
  * return SMST_ERR_INVALID with the limit in smst_last_error() beyond them:
- *   - 1 ... 8 channels per stream (the bin recurrence keeps one lane's channels in registers / one LDS ring per channel);
- *   - fftSamples/2 = 2^k * {1, 3, 5} bands (the reference's own fast sizes) with bands*16 bytes <= 150 KiB, i.e. <= 9600 bands:
- *     a frame's FFT runs inside one CU's LDS (the presets fit up to 96 kHz -- presetDefault there has 6144 bands; at 192 kHz they would
- *     need 10240 / 12288 bands and are refused);
+ *   - 1 ... 16 channels per stream (the recurrence kernels size their per-lane channel arrays at compile time: 1-2 channels and 3-8 channels
+ *     keep the per-bin records in LDS, 9-16 channels take the un-fused kernel pair with records through HBM -- slower, the same arithmetic);
+ *   - fftSamples/2 = 2^k * {1, 3, 5} bands (the reference's own fast sizes), at most 19200: one FFT buffer of bands*8 bytes has to fit a
+ *     CU's LDS.  Up to 9600 bands (every preset up to 96 kHz: presetDefault there has 6144) both ping-pong buffers do; beyond that --
+ *     the presets at 176.4 / 192 kHz: 10240 / 12288 bands -- the second buffer lives in memory (slower per frame, the same arithmetic);
  *   - interval >= fftSamples/62 (the vertical step of the phase prediction, round(fftSamples/interval), has to fit the wavefront's
  *     skew); interval <= block.
  *   - Sample = float arithmetic only (the C++ drop-in accepts double buffers and converts at the boundary).

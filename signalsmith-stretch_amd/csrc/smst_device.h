@@ -81,6 +81,7 @@ struct DevBatch {
 	float *est;     // [subS][T][2]
 	float *freqEst; // [subS][T]: pitch estimate (in bins) each hop's formant envelope uses
 	float *frames;  // [subS][T][C][B]
+	float2 *fftScratch; // [subS][T][C][Mp]: second FFT buffer of the synthesis frames where two buffers do not fit LDS (fftNeedsScratch); null otherwise
 	const int *nHops;      // [subS] hops of this tile
 	const int *lastNewHop; // [subS] tile-local index of the last hop with a new spectrum, or -1
 };
@@ -115,6 +116,11 @@ struct IoArgs {
 // `windowPad` samples on either side of the window, which the table's zero weights cancel -- so a frame is its to take only if
 // that wider span lies in this call's input too.  (First form: one compare + select per element and half: analysis 4.4 -> 6.8 ms per
 // step at 44.1 kHz, slower than the per-frame kernel it was to replace.)
+// The generic FFT kernels ping-pong between two buffers of `bands` complex values: in LDS while both fit (150 KiB), else one of them in memory
+// (kAnalyse<true> / kSynth<true>: presetDefault / presetCheaper at 176.4 / 192 kHz).  One buffer must still fit.
+__host__ __device__ inline bool fftNeedsScratch(int bands) { return (size_t)bands*16 > (size_t)150*1024; }
+constexpr int kMaxBands = 150*1024/8; // 19200
+
 struct WindowPad { int lo, hi; };
 __host__ __device__ inline WindowPad windowPad(int B, int M) {
 	const int halfB = B/2, MA = M/16;

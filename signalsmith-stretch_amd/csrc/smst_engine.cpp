@@ -109,16 +109,19 @@ Batch::Batch(int streams, int channels, int block, int interval, bool splitCompu
 	: S(streams), C(channels), B(block), I(interval), split(splitComputation), halfState(halfPrecisionState), dev(device) {
 	// geometry first: nothing below may throw before the HIP objects exist, and everything after is covered by the
 	// clean-up in the catch block (a throwing constructor does not run the destructor)
-	if (S < 1 || C < 1 || C > kMaxChannels || B < 4 || I < 1 || I > B) throw Error("invalid configuration (need 1..8 channels, interval <= block)");
+	if (S < 1 || C < 1 || C > kMaxChannels || B < 4 || I < 1 || I > B) throw Error("invalid configuration (need 1.." + std::to_string(kMaxChannels) + " channels, interval <= block)");
 	N = 2*fastSizeAbove((B + 1)/2);
 	M = N/2;
-	if ((size_t)M*sizeof(float2)*2 > 150*1024) throw Error("block too long for the LDS-resident FFT (bands*16 bytes must fit 150 KiB)");
+	if (M > kMaxBands) throw Error("block too long: " + std::to_string(M) + " bands, at most " + std::to_string(kMaxBands) + " (one FFT buffer of bands*8 bytes must fit a CU's LDS; up to 9600 bands both buffers do, beyond that the second one lives in memory)");
 	L = int(std::round(float(N)/float(I))); // longVerticalStep, signalsmith-stretch.h:636-637
 	if (L < 1) L = 1;
 	{
 		int ring = 4;
 		while (ring < L + 2) ring *= 2;
 		if (ring > 64) throw Error("interval too small relative to the FFT size (vertical step too long)");
+		// (9-16 channels, or a vertical step the fused kernels do not take: kChain keeps a ring of `ring` bins per channel and lane in LDS)
+		if (C > kMaxFusedChannels && ((size_t)C*ring*64 + (size_t)C*128)*sizeof(float2) > (size_t)160*1024)
+			throw Error("more than 8 channels need interval >= fftSamples/13 (the un-fused recurrence keeps a history ring per channel in LDS)");
 	}
 	const FftPlan plan = makePlan(M, N);
 	try {
@@ -516,6 +519,7 @@ void Batch::allocateWorkspace() {
 				w.est = devAlloc<float>((size_t)subS*d.T*2);
 				w.freqEst = devAlloc<float>((size_t)subS*d.T);
 				w.frames = devAlloc<float>((size_t)subS*d.T*C*B);
+				if (fftNeedsScratch(M)) w.fftScratch = devAlloc<float2>(rows); // (the synthesis frames' second FFT buffer: smst_device.h)
 			}
 			// The continuous wavefront (kVocoderCont) finishes tile t in launch t+1, so tile t+1's analysis needs a third place to write to:
 			// the spectra, the results and the frames of a PLAIN tile only, and only where that form can run at all (one sub-batch)
@@ -527,6 +531,7 @@ void Batch::allocateWorkspace() {
 				w.Xprev = devAlloc<float2>(rows);
 				w.OUT = devAlloc<float2>(rows);
 				w.frames = devAlloc<float>((size_t)subS*d.T*C*B);
+				if (fftNeedsScratch(M)) w.fftScratch = devAlloc<float2>(rows);
 				dContSave = devAlloc<float2>((size_t)S*8*C*64);
 			}
 			break;
@@ -975,7 +980,7 @@ void Batch::runTilesRange(const TileRun &run, int tile0, int tile1, int carryFir
 			const TileBuffers &w = slots[slot];
 			DevBatch dd = d;
 			dd.Xcur = w.Xcur; dd.Xprev = w.Xprev; dd.PE = w.PE; dd.OUT = w.OUT; dd.REC = w.REC; dd.dump = w.dump;
-			dd.map = w.map; dd.ratio = w.ratio; dd.envelope = w.envelope; dd.energyT = w.energyT; dd.smoothT = w.smoothT; dd.peaksT = w.peaksT; dd.est = w.est; dd.freqEst = w.freqEst; dd.frames = w.frames;
+			dd.map = w.map; dd.ratio = w.ratio; dd.envelope = w.envelope; dd.energyT = w.energyT; dd.smoothT = w.smoothT; dd.peaksT = w.peaksT; dd.est = w.est; dd.freqEst = w.freqEst; dd.frames = w.frames; dd.fftScratch = w.fftScratch;
 			dd.carryCur = (carryFirst + t) & 1;
 			dd.nHops = run.dTileInfo + ((size_t)(sub*nTiles + t)*2)*subS;
 			dd.lastNewHop = dd.nHops + subS;
@@ -1096,7 +1101,7 @@ void Batch::runTilesContinuous(const TileRun &run, int tile0, int tile1, int car
 	auto tileView = [&](int t) {
 		const TileBuffers &w = slots[t%3];
 		DevBatch dd = d;
-		dd.Xcur = w.Xcur; dd.Xprev = w.Xprev; dd.OUT = w.OUT; dd.frames = w.frames;
+		dd.Xcur = w.Xcur; dd.Xprev = w.Xprev; dd.OUT = w.OUT; dd.frames = w.frames; dd.fftScratch = w.fftScratch;
 		dd.PE = nullptr; dd.REC = nullptr; dd.map = nullptr; dd.ratio = nullptr; // (plain tiles: never touched)
 		dd.carryCur = (carryFirst + t) & 1;
 		dd.nHops = run.dTileInfo + ((size_t)t*2)*subS;

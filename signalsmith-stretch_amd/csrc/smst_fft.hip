@@ -863,6 +863,10 @@ __global__ __launch_bounds__(256) void kEnergy(DevBatch d, IoArgs io, int sBase,
 // sequence of the half-bin-shifted real FFT, Stockham FFT in LDS, write the M = N/2 bins.
 // Replaces stft.analyseStep at signalsmith-stretch.h:337,:359 (+ the copies :344-350,:366-372).
 // ------------------------------------------------------------------------------------------------------
+// BIG (blocks whose two ping-pong buffers do not fit a CU's LDS: presetDefault / presetCheaper at 176.4 / 192 kHz, 12288 / 10240 bins): one buffer
+// in LDS, the other in memory -- the frame's own output row, which nobody reads before the kernel has finished.  The Stockham passes then
+// alternate between LDS and HBM (L2 in practice: 96 KB per workgroup): slower than the LDS-resident form, the same arithmetic in the same order.
+template <bool BIG>
 __global__ __launch_bounds__(256) void kAnalyse(DevBatch d, IoArgs io, int sBase, int hopBase) {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smemRaw[];
 	float2 *bufA = reinterpret_cast<float2 *>(smemRaw);
@@ -882,6 +886,8 @@ __global__ __launch_bounds__(256) void kAnalyse(DevBatch d, IoArgs io, int sBase
 	const float *x = io.in + (size_t)(sBase + s)*io.inStreamStride + (size_t)c*io.inChannelStride;
 	const float *hist = d.hist + ((size_t)(sBase + s)*d.C + c)*(size_t)d.histPitch + d.histBase[d.histCur][sBase + s];
 	const float *__restrict__ win = d.window;
+	float2 *dst = (which ? d.Xprev : d.Xcur) + rowOf(d, s, k, c);
+	if (BIG) bufB = dst;
 
 	for (int m = threadIdx.x; m < H; m += blockDim.x) {
 		float re = 0, im = 0;
@@ -901,8 +907,11 @@ __global__ __launch_bounds__(256) void kAnalyse(DevBatch d, IoArgs io, int sBase
 	}
 	__syncthreads();
 	float2 *res = fftLds<-1>(bufA, bufB, d.plan, d.twH);
-
-	float2 *dst = (which ? d.Xprev : d.Xcur) + rowOf(d, s, k, c);
+	if (BIG && res == dst) { // the last pass ended in the output row: through LDS once more, the final order is a permutation of it
+		for (int j = threadIdx.x; j < H; j += blockDim.x) bufA[j] = dst[j];
+		__syncthreads();
+		res = bufA;
+	}
 	const int N = d.N;
 	for (int j = threadIdx.x; j < H; j += blockDim.x) {
 		float2 u = res[j];
@@ -917,11 +926,13 @@ __global__ __launch_bounds__(256) void kAnalyse(DevBatch d, IoArgs io, int sBase
 // multiply by the synthesis window, store the B-sample frame.  Replaces the copy at
 // signalsmith-stretch.h:384-394 + stft.synthesiseStep (:397-399).
 // ------------------------------------------------------------------------------------------------------
+template <bool BIG> // BIG: the second buffer in memory (DevBatch::fftScratch, a row per frame), see kAnalyse
 __global__ __launch_bounds__(256) void kSynth(DevBatch d, int sBase, int hopBase) {
 	extern __shared__ __attribute__((aligned(16))) unsigned char smemRaw[];
 	float2 *bufA = reinterpret_cast<float2 *>(smemRaw);
 	float2 *bufB = bufA + d.M;
 	const int k = blockIdx.x, c = blockIdx.y, s = blockIdx.z;
+	if (BIG) bufB = d.fftScratch + rowOf(d, s, k, c);
 	const HopDesc hd = d.hops[(size_t)(sBase + s)*d.hopStride + hopBase + k];
 	if (!(hd.flags & HOP_ACTIVE)) return;
 	const int B = d.B, H = d.M, N = d.N, halfB = B/2;
@@ -1099,7 +1110,8 @@ void launchAnalyse(const DevBatch &d, const IoArgs &io, int sBase, int nStreams,
 		if (d.M == 256*24) { if (d.fftLean) hipLaunchKernelGGL((kAnalyseFast<24, true>), grid, dim3(384), fastLds, st, d, io, sBase, hopBase, lateOnly); else hipLaunchKernelGGL((kAnalyseFast<24, false>), grid, dim3(384), fastLds, st, d, io, sBase, hopBase, lateOnly); return; }
 	}
 	size_t lds = 2*(size_t)d.M*sizeof(float2);
-	hipLaunchKernelGGL(kAnalyse, grid, dim3(256), lds, st, d, io, sBase, hopBase);
+	if (fftNeedsScratch(d.M)) hipLaunchKernelGGL(kAnalyse<true>, grid, dim3(256), lds/2, st, d, io, sBase, hopBase);
+	else hipLaunchKernelGGL(kAnalyse<false>, grid, dim3(256), lds, st, d, io, sBase, hopBase);
 }
 void launchSynth(const DevBatch &d, int sBase, int nStreams, int hopBase, int tileHops, hipStream_t st) {
 	const dim3 grid(tileHops, d.C, nStreams);
@@ -1121,7 +1133,8 @@ void launchSynth(const DevBatch &d, int sBase, int nStreams, int hopBase, int ti
 		if (d.M == 256*24) { if (d.fftLean) hipLaunchKernelGGL((kSynthFast<24, true>), grid, dim3(384), fastLds, st, d, sBase, hopBase); else hipLaunchKernelGGL((kSynthFast<24, false>), grid, dim3(384), fastLds, st, d, sBase, hopBase); return; }
 	}
 	size_t lds = 2*(size_t)d.M*sizeof(float2);
-	hipLaunchKernelGGL(kSynth, grid, dim3(256), lds, st, d, sBase, hopBase);
+	if (fftNeedsScratch(d.M)) hipLaunchKernelGGL(kSynth<true>, grid, dim3(256), lds/2, st, d, sBase, hopBase);
+	else hipLaunchKernelGGL(kSynth<false>, grid, dim3(256), lds, st, d, sBase, hopBase);
 }
 bool synthEmitApplies(const DevBatch &d, int nStreams, int tileHops) {
 	if (d.noFastFft || !d.fftTeams || d.fftLean || !d.synthEmit || !(d.M == 256*10 || d.M == 256*12)) return false;

@@ -5,7 +5,9 @@
 namespace smst {
 
 constexpr int kTileHops = 64;   // hops per tile = lanes of the wave that runs the bin recurrence
-constexpr int kMaxChannels = 8; // compile-time bound of the chain kernel's per-lane channel arrays
+constexpr int kMaxChannels = 16; // per-lane channel arrays of the recurrence kernels are sized at compile time: 1-2 channels kVocoder, 3-8 kVocoderN (records in LDS),
+                                // 9-16 the un-fused pair kPredictB + kChain (records through HBM: slower, the same arithmetic)
+constexpr int kMaxFusedChannels = 8;
 constexpr int kMaxFftPasses = 12;
 constexpr int kTileHasStride = 12; // per-tile summary bytes of the host scheduler: any hop / mapped / formants / new spectrum / random time factor / analysis window in the call / reaching into the history / a start bin / a pre-analysed hop
 constexpr int kEnergyParts = 16; // partial sums per stream in the silence-gate reduction

@@ -864,7 +864,7 @@ static void launchVocoderT(const DevBatch &d, int sBase, int nStreams, int hopBa
 	}
 }
 bool fusedSupported(const DevBatch &d) {
-	return d.lag == d.L + 1 && d.L >= 2 && d.L <= (d.C <= 2 ? 7 : 5); // other geometries: kPredictB + kChain (records through HBM)
+	return d.C <= kMaxFusedChannels && d.lag == d.L + 1 && d.L >= 2 && d.L <= (d.C <= 2 ? 7 : 5); // other geometries / more channels: kPredictB + kChain (records through HBM)
 }
 void launchVocoder(const DevBatch &d, int sBase, int nStreams, int hopBase, bool plain, bool bounded, hipStream_t st) {
 	switch (d.C) {

@@ -218,7 +218,7 @@ __global__ __launch_bounds__(64*kVocWaves) __attribute__((amdgpu_waves_per_eu(4,
 	constexpr int NF = 9 + 3*CH, NCH = (NF + 3)/4, BS = kVocNBlockSteps, NB = kVocNBlocks, R = kVocNRing, Rm = R - 1;
 	constexpr int NP = kVocWaves - 2;
 	constexpr int lag = L + 1;
-	static_assert(CH >= 3 && CH <= kMaxChannels && L >= 1 && L + BS < R, "ring depth: a slot is rewritten R bins later, the oldest tap is L bins back");
+	static_assert(CH >= 3 && CH <= kMaxFusedChannels && L >= 1 && L + BS < R, "ring depth: a slot is rewritten R bins later, the oldest tap is L bins back");
 	static_assert(NB == 2, "the wide producer passes fill both blocks of the ring");
 	extern __shared__ __attribute__((aligned(16))) unsigned char smemRaw[];
 	float4 *recs = reinterpret_cast<float4 *>(smemRaw);                  // [(slot*BS + st)*NCH + j][64 lanes]
@@ -626,7 +626,7 @@ static void launchVocoderOneT(const DevBatch &d, int sBase, int nStreams, int ho
 	}
 }
 // single-hop tiles (every stream fires at most one hop): see kVocoderOne.  Same geometries as the fused 3-8 channel kernel.
-bool singleHopSupported(const DevBatch &d) { return d.lag == d.L + 1 && d.L >= 2 && d.L <= 5; }
+bool singleHopSupported(const DevBatch &d) { return d.C <= kMaxFusedChannels && d.lag == d.L + 1 && d.L >= 2 && d.L <= 5; }
 void launchVocoderOne(const DevBatch &d, int sBase, int nStreams, int hopBase, bool plain, hipStream_t st) {
 	countLaunch(LK_VOC_ONE);
 	switch (d.C) {
@@ -649,7 +649,15 @@ void launchPredict(const DevBatch &d, int sBase, int nStreams, int hopBase, int 
 	case 5: launchPredictT<5>(d, sBase, nStreams, hopBase, tileHops, plain, passADone, st); break;
 	case 6: launchPredictT<6>(d, sBase, nStreams, hopBase, tileHops, plain, passADone, st); break;
 	case 7: launchPredictT<7>(d, sBase, nStreams, hopBase, tileHops, plain, passADone, st); break;
-	default: launchPredictT<8>(d, sBase, nStreams, hopBase, tileHops, plain, passADone, st); break;
+	case 8: launchPredictT<8>(d, sBase, nStreams, hopBase, tileHops, plain, passADone, st); break;
+	case 9: launchPredictT<9>(d, sBase, nStreams, hopBase, tileHops, plain, passADone, st); break;
+	case 10: launchPredictT<10>(d, sBase, nStreams, hopBase, tileHops, plain, passADone, st); break;
+	case 11: launchPredictT<11>(d, sBase, nStreams, hopBase, tileHops, plain, passADone, st); break;
+	case 12: launchPredictT<12>(d, sBase, nStreams, hopBase, tileHops, plain, passADone, st); break;
+	case 13: launchPredictT<13>(d, sBase, nStreams, hopBase, tileHops, plain, passADone, st); break;
+	case 14: launchPredictT<14>(d, sBase, nStreams, hopBase, tileHops, plain, passADone, st); break;
+	case 15: launchPredictT<15>(d, sBase, nStreams, hopBase, tileHops, plain, passADone, st); break;
+	default: launchPredictT<16>(d, sBase, nStreams, hopBase, tileHops, plain, passADone, st); break;
 	}
 }
 template <int CH>
@@ -667,7 +675,15 @@ void launchChain(const DevBatch &d, int sBase, int nStreams, int hopBase, hipStr
 	case 5: launchChainT<5>(d, sBase, nStreams, hopBase, st); break;
 	case 6: launchChainT<6>(d, sBase, nStreams, hopBase, st); break;
 	case 7: launchChainT<7>(d, sBase, nStreams, hopBase, st); break;
-	default: launchChainT<8>(d, sBase, nStreams, hopBase, st); break;
+	case 8: launchChainT<8>(d, sBase, nStreams, hopBase, st); break;
+	case 9: launchChainT<9>(d, sBase, nStreams, hopBase, st); break;
+	case 10: launchChainT<10>(d, sBase, nStreams, hopBase, st); break;
+	case 11: launchChainT<11>(d, sBase, nStreams, hopBase, st); break;
+	case 12: launchChainT<12>(d, sBase, nStreams, hopBase, st); break;
+	case 13: launchChainT<13>(d, sBase, nStreams, hopBase, st); break;
+	case 14: launchChainT<14>(d, sBase, nStreams, hopBase, st); break;
+	case 15: launchChainT<15>(d, sBase, nStreams, hopBase, st); break;
+	default: launchChainT<16>(d, sBase, nStreams, hopBase, st); break;
 	}
 }
 void launchVocoderMany(const DevBatch &d, int sBase, int nStreams, int hopBase, bool plain, hipStream_t st) {

@@ -59,6 +59,12 @@ def main():
     x96 = synth_input(0, 2, 28800, 96000) + 0.5*synth_input(1, 2, 28800, 96000)
     case("default_96k_stereo", x96, [dict(op="setTransposeSemitones", args=[-3, 0]),
                                      dict(op="process", inStart=0, inLen=28800, outLen=28800)], sample_rate=96000)
+    # (round 6) the presets at 192 kHz: 12288 / 10240 bins, beyond what two FFT buffers fit in a CU's LDS (the product's second buffer lives in
+    # memory there).  Mono and short: eight hops of presetDefault (interval 5760), six of presetCheaper (interval 7680, split computation)
+    x192 = synth_input(0, 1, 46080, 192000) + 0.5*synth_input(1, 1, 46080, 192000)
+    case("default_192k_mono", x192, [dict(op="process", inStart=0, inLen=46080, outLen=int(46080*1.25))], sample_rate=192000)
+    case("cheaper_192k_mono", x192, [dict(op="setTransposeSemitones", args=[4, 0]),
+                                     dict(op="process", inStart=0, inLen=46080, outLen=46080)], preset="cheaper", sample_rate=192000)
     # 8 channels (a sine, a chirp and a noise stream among them), 48 kHz presetDefault, 1.5x: the channel lock over 8 channels
     x8 = np.concatenate([synth_input(0, 3, n, sr), synth_input(1, 3, n, sr)*0.7, synth_input(2, 2, n, sr)], axis=0)
     case("eight_channels_1p5", x8, [dict(op="process", inStart=0, inLen=n, outLen=int(n*1.5))])

@@ -22,6 +22,8 @@ GOLDEN_TOL = {
     "cheaper_48k_stereo": 1e-3,
     "default_96k_stereo": 1e-3,
     "eight_channels_1p5": 1e-3,
+    "default_192k_mono": 1e-3,
+    "cheaper_192k_mono": 1e-3,
 }
 
 

@@ -7,7 +7,7 @@ import scenarios
 
 
 @pytest.mark.parametrize("name", ["identity_mono_44k", "stretch_1p5_stereo", "pitch_p12_stereo", "cheaper_96k_3ch",
-                                  "flush_short_stereo", "cheaper_48k_stereo", "eight_channels_1p5"])
+                                  "flush_short_stereo", "cheaper_48k_stereo", "eight_channels_1p5", "default_192k_mono", "cheaper_192k_mono"])
 def test_golden(emu, ref, name):
     pc.case_golden(emu, ref, name)
 
@@ -34,6 +34,7 @@ def test_silence(emu, ref):
 
 def test_channels(emu, ref):
     pc.case_channels(emu, ref)
+    pc.case_channels(emu, ref, channel_counts=(9, 12))  # beyond the fused kernels' eight: kPredictB + kChain
 
 
 def test_batch_ragged(emu, ref):

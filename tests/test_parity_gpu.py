@@ -48,6 +48,7 @@ def test_silence(hip, ref):
 
 def test_channels(hip, ref):
     pc.case_channels(hip, ref, channel_counts=(1, 2, 3, 4, 5, 6, 7, 8))
+    pc.case_channels(hip, ref, channel_counts=(9, 12, 16))  # beyond the fused kernels' eight channels: kPredictB + kChain, records through HBM
 
 
 def test_batch_ragged(hip, ref):
@@ -737,3 +738,12 @@ def test_formant_stages(hip, ref, monkeypatch):
     bound 1e-4 -- at presetDefault / 48 kHz on two streams of every signal type, for config 4b's parameters, an estimated base frequency
     and a formant shift."""
     _report("formant_stages/D48", pc.case_formant_stages(hip, ref, monkeypatch, D48, hops=30, streams=tuple(range(6))))
+
+
+@pytest.mark.parametrize("preset", ["default", "cheaper"])
+def test_presets_at_192k(hip, ref, preset):
+    """signalsmith-stretch.h:63-68 at 192 kHz: 12288 / 10240 bins -- two FFT buffers do not fit a CU's LDS, the generic kernels keep the second
+    one in memory (kAnalyse<true> / kSynth<true>).  Three stereo streams (sine, chirp, noise), 0.5 s, 1.25x, against the checker with the
+    horizon-aware bound; the WASM fixtures of the same geometries run in test_golden."""
+    n = 96000
+    _batch_vs_ref(hip, ref, 3, 2, 192000, n, int(n*1.25), dict(preset=preset, sample_rate=192000.0), preset, "%s @ 192 kHz" % preset)
