@@ -545,7 +545,8 @@ def main():
     elapsed = time.perf_counter() - t0
     live_ms, live_launches = batch.takeTimings()
     batch.enableProfiling(0)
-    step_ms = sorted(stamps[i].elapsed_time(stamps[i + 1]) for i in range(args.steps))
+    step_periods = [stamps[i].elapsed_time(stamps[i + 1]) for i in range(args.steps)]  # in order: a slow FIRST step is a warm-up artefact, a slow one in the middle is jitter
+    step_ms = sorted(step_periods)
     if use_dist:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=red_device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -624,7 +625,7 @@ def main():
             achieved=pipeline_achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=(pipeline_achieved/HBM_PEAK_GBS if pipeline_achieved else None),
             traffic=((traffic.get("bytes_per_step")*(S/float(traffic["streams"]) if traffic.get("streams") else 1.0)) if traffic else None), traffic_source=traffic_source,
             algorithmic_bytes_per_channel_hop=bytes_per_chop, channel_hops_per_step=chops_per_step,
-            step_ms=dict(mean_wall=step_mean_ms, median=step_ms[len(step_ms)//2], min=step_ms[0], max=step_ms[-1], n=len(step_ms),
+            step_ms=dict(mean_wall=step_mean_ms, median=step_ms[len(step_ms)//2], min=step_ms[0], max=step_ms[-1], n=len(step_ms), in_order=[round(v, 3) for v in step_periods],
                          note="mean_wall = host clock around the K steps / K (the figure `value` uses); median/min/max = device-side period of each step (event stamps)"),
             pipeline_frac=(pipeline_achieved/HBM_PEAK_GBS if pipeline_achieved else None),
             dominant_kernel=dict(

@@ -342,8 +342,11 @@ class StretchBatch:
             raise StretchError("input and output must live in the same memory space")
         if on < max_out or int(nin.max()) > n:
             raise StretchError("buffer shorter than the requested sample count")
-        if mem == MEM_DEVICE:
-            self._order_after_torch(x, out, wait=ordered)
+        if mem == MEM_DEVICE and ordered:
+            self._order_after_torch(x, out)
+        # (ordered=False: the caller's contract -- inputs complete, outputs untouched and both tensors ALIVE until it synchronises the batch -- so
+        # nothing is tracked here.  Until round 6 the tensors were still put on the in-flight list, whose every 17th entry synchronises the batch:
+        # one pipeline drain per 16 calls, 2.4 ms of the bench's 17th step -- bench.py's per-step periods showed it, roofline.step_ms.in_order)
         _check(self.lib, self.lib.smst_batch_process(self.h, ptr, ss, cs, pin, optr, oss, ocs, pout, mem))
         if mem == MEM_DEVICE and ordered:  # torch ops on `out` issued from here on are ordered after our kernels (no host sync either)
             import torch

@@ -99,6 +99,7 @@ struct ContArgs {
 	int n0, n1;          // global block range; both even
 	int period;          // blocks per tile and row: M/8 + 2 (a zero line between two hops of a row: see the kernel)
 	float2 *save;        // [S][8*C*64]: the recurrence wave's last eight outputs per lane, from one launch to the next
+	int writerWave;      // which wave drains the results: 4 (the recurrence wave's SIMD, as in kVocoder) or 11 (the SIMD that holds two producers)
 };
 
 struct IoArgs {

@@ -158,7 +158,7 @@ void Batch::construct(const FftPlan &plan, long seed) {
 	}
 	// the cross-check switches: one struct, one table, read once (smst_switches.h)
 	const Switches sw = Switches::fromEnvironment();
-	overlap = sw.overlap; noFuse = sw.noFuse; noSingleHop = sw.noSingleHop; noAcross = sw.noAcross; carriedEmit = sw.carriedEmit != 0; checkLaunches = sw.checkLaunches; continuous = sw.continuous;
+	overlap = sw.overlap; noFuse = sw.noFuse; noSingleHop = sw.noSingleHop; noAcross = sw.noAcross; carriedEmit = sw.carriedEmit != 0; checkLaunches = sw.checkLaunches; continuous = sw.continuous; contWriterWave = sw.contWriterWave;
 	workspaceGiB = sw.workspaceGiB;
 	subStreamsAsked = sw.subStreams;
 
@@ -1161,6 +1161,7 @@ void Batch::runTilesContinuous(const TileRun &run, int tile0, int tile1, int car
 		a.n0 = P*a.tile;
 		a.n1 = (t == tile1 - 1) ? P*(a.tile + 1) + 62 : P*(a.tile + 1); // the last launch runs until row 63 of the last tile is through
 		a.save = dContSave;
+		a.writerWave = contWriterWave;
 		hipEvent_t liveA = nullptr, liveB = nullptr;
 		if (liveTiming && !serial) {
 			if (liveEvents.size() == livePool.size()) growLivePool(livePool.size() + 64);

@@ -151,6 +151,7 @@ private:
 	hipEvent_t evStart = nullptr, evFeed[3] = {nullptr, nullptr, nullptr}, evChain[3] = {nullptr, nullptr, nullptr}, evOut[3] = {nullptr, nullptr, nullptr}, evSynth[3] = {nullptr, nullptr, nullptr}; // (the third set: the continuous wavefront's tile pipeline is one stage deeper)
 	struct TileBuffers { float2 *Xcur, *Xprev, *OUT, *dump, *map, *peaksT; float4 *REC; PredEntry *PE; float *ratio, *envelope, *energyT, *smoothT, *est, *freqEst, *frames; float2 *fftScratch; } slots[3]{}; // [2]: only what a plain tile touches, only where the continuous wavefront applies (allocateWorkspace)
 	bool overlap = true, noFuse = false, noSingleHop = false, noAcross = false, carriedEmit = true, continuous = false; // (smst_switches.h)
+	int contWriterWave = 4;
 	float2 *dContSave = nullptr; // kVocoderCont: the recurrence wave's history between two launches, [S][8*C*64]
 	double workspaceGiB = 0;
 	int subStreamsAsked = 0;

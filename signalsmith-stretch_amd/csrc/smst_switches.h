@@ -37,6 +37,7 @@ struct Switches {
 	bool overlap = true, noFuse = false, noSingleHop = false, noAcross = false, checkLaunches = false;
 	int noFeedFusion = 0, fftTeams = 1, synthEmit = 1, debugMode = 0, vocNWide = 1, carriedEmit = 1;
 	bool noStage = false, noAlign = false, alignAll = false, noFastFft = false, fftLean = false, feedSerial = false, continuous = false;
+	int contWriterWave = 4;
 	double workspaceGiB = 0; // 0: automatic
 	int subStreams = 0;      // 0: automatic
 
@@ -57,6 +58,7 @@ struct Switches {
 		s.noAlign = set("SMST_NO_ALIGN");
 		s.alignAll = set("SMST_ALIGN_ALL");
 		s.continuous = set("SMST_CONTINUOUS");
+		s.contWriterWave = num("SMST_CONT_WRITER_WAVE", 4) == 11 ? 11 : 4;
 		s.noFastFft = set("SMST_NO_FAST_FFT");
 		if (const char *env = std::getenv("SMST_FFT_TABLES")) s.fftLean = std::string(env) == "lean";
 		s.feedSerial = set("SMST_FEED_SERIAL");

@@ -384,7 +384,7 @@ __global__ __launch_bounds__(64*kContWaves) __attribute__((amdgpu_waves_per_eu(3
 	__syncthreads();
 
 	if (wave > 0) {
-		if (wave == 4) {
+		if (wave == a.writerWave) {
 			// ---------------- writer: whole aligned 128-byte lines of OUT, as kVocoder's (lag 8: rows of one parity complete a line per block) ----------------
 			const int g8 = k & 7, part = k >> 3;
 			// which of this lane's rows hold a hop, per tile of the launch: bit rel*8 + pass*2 + par for row 2*(8*pass + g8) + par
@@ -439,7 +439,7 @@ __global__ __launch_bounds__(64*kContWaves) __attribute__((amdgpu_waves_per_eu(3
 		// the producers' placement of the tile form: 8 waves on three SIMDs (1,5,9 / 2,6,10 / 3,7), the recurrence wave's SIMD left to it and
 		// the writer; the wave with rows 0..7 (carried taps, FOLD0: the heaviest) on the SIMD that holds two producers
 		int pIndex = wave - 1 - (wave > 4);
-		pIndex = (wave & 3) ? ((wave < 8) ? pIndex : ((wave == 9) ? 6 : ((wave == 10) ? 7 : NP))) : NP;
+		pIndex = ((wave & 3) && wave != 11) ? ((wave < 8) ? pIndex : ((wave == 9) ? 6 : ((wave == 10) ? 7 : NP))) : NP;
 		if (pIndex < NP) pIndex = (pIndex == 0) ? 2 : ((pIndex == 2) ? 0 : pIndex);
 		if (pIndex >= NP) return;
 		float2 *sbuf = lines + (size_t)pIndex*G::PER_PRODUCER;

@@ -6,7 +6,7 @@ ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-CMD="python $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-serial-pass ${BENCH_ARGS:-}"
+CMD="python $ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-serial-pass --no-other-configs ${BENCH_ARGS:-}"
 timeout 300 rocprofv3 --kernel-trace --stats -d $OUT/trace -o t -f csv -- $CMD > $OUT/trace.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/fetch -o f -f csv -- $CMD > $OUT/fetch.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/write -o w -f csv -- $CMD > $OUT/write.log 2>&1
