@@ -16,6 +16,7 @@
 //   SMST_ALIGN_ALL         unset    set: the line-aligned producers for every geometry they are valid for (default: L = 4 only)
 //   SMST_CONTINUOUS        unset    set: runs of plain stereo / mono tiles through ONE wavefront across the tiles (kVocoderCont) instead of tile by tile (kVocoder):
 //                                   bit-identical, measured equal in speed (EXPERIMENTS.md 6.1), kept as a cross-check of the tile form
+//   SMST_CONT_WRITER_WAVE  4        11: kVocoderCont's result writer on the SIMD that holds two producers instead of the recurrence wave's (measured: no difference, EXPERIMENTS.md 6.2)
 //   SMST_NO_FAST_FFT       unset    set: the generic radix-4/2/3/5 ladder even where a register-blocked FFT exists
 //   SMST_FFT_TABLES        full     lean: the smaller FFT tables (one more rounding per element: opt-in, see smst_engine.cpp)
 //   SMST_FEED_SERIAL       unset    set: bin-by-bin feed recurrences (kFeedSerial) instead of the scan form

@@ -559,7 +559,10 @@ __global__ __launch_bounds__(64*kVocWaves) __attribute__((amdgpu_waves_per_eu(4,
 	const int s = ACROSS ? blockIdx.x*acrossRows : blockIdx.x, sg = sBase + s;
 	const int nh = ACROSS ? min(acrossRows, acrossStreams - s) : d.nHops[s];
 	if (nh <= 0) return;
-	const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), k = threadIdx.x & 63; // (scalar: what depends on the wave and the block number alone runs on the scalar unit)
+	// (The wave index as a scalar -- what depends on the wave and the block number alone then runs on the scalar unit -- for the line-aligned
+	// producers only: 251 -> 244 vector instructions per block there.  The staged producers' loop came out SLOWER with it -- presetCheaper
+	// 65.5 -> 55.8 Gsamples/s, presetDefault at 44.1 kHz 38.2 -> 33.1, profiles/r6_presets_scalar_wave_regression.json: found by the preset table)
+	const int wave = ALIGNED ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : int(threadIdx.x >> 6), k = threadIdx.x & 63;
 	const int M = d.M;
 	const int steps = M + lag*(nh - 1);
 	const int chunks = (steps + 63) >> 6;

@@ -13,14 +13,15 @@
 //   * records of the 16 gap bins are all-zero, which gives exactly zero outputs: a lane enters its next hop with a zero history, as the
 //     reference's bins below 0 are (:748, :756);
 //   * lane k-1 runs 8 virtual bins ahead of lane k as before (DPP wave_shr:1); lane 0's previous hop is lane 63's hop of the tile
-//     before, finished P - 8*63/8 - ... blocks earlier: its taps are folded into its records by the producer (FOLD0) from the OUT rows
-//     in memory -- written by this workgroup's own writer wave at least ~300 blocks before (the writer publishes how far its stores
-//     have COMPLETED, `flushed`), or by the launch before.
+//     before, which that lane finished P - 63 blocks before lane 0 needs the same bins: its taps are folded into lane 0's records by the
+//     producer (FOLD0) from the OUT rows in memory -- written by this workgroup's own writer wave at least P - 67 blocks earlier (the
+//     writer publishes how far its stores have COMPLETED, sync word NB + 3), or by the launch before.
 // A launch covers the global blocks [n0, n1) = one period (the last launch of a call: until the last row has finished): the analysis of
 // tile t+1 and the synthesis of tile t-1 still overlap it tile by tile.  Between two launches the recurrence wave's last eight outputs
 // per lane travel through `save` (they are its history registers AND the result-ring block the writer still needs); the producers
 // warm their line buffers up over the four blocks in front of n0.  Tile t is complete when launch t+1 has run.
-// 8*M + 8*63 + ... steps per 8 tiles instead of 8*(M + 8*63): -12 % recurrence steps on a 500-hop call.
+// 3150 blocks instead of 3576 on a 500-hop call -- and, measured, the same 6.4 ms per step: a block of a tile's ramp costs in proportion to
+// the producer waves that are active in it, so the tile form never paid for its idle lanes (EXPERIMENTS.md 6.1).  Opt-in: SMST_CONTINUOUS=1.
 #include "smst_vocoder_common.h"
 
 namespace smst {
