@@ -19,7 +19,9 @@ def main():
     pkg = importlib.import_module("signalsmith-stretch_amd")
     S, C, steps, warm = 256, 2, 4, 2
     rows = []
-    table = (("default", 48000, 10.0), ("cheaper", 48000, 10.0), ("default", 96000, 5.0), ("cheaper", 96000, 5.0), ("default", 44100, 10.0))
+    table = (("default", 48000, 10.0), ("cheaper", 48000, 10.0), ("default", 96000, 5.0), ("cheaper", 96000, 5.0), ("default", 44100, 10.0),
+             # (round 6) 192 kHz: 12288 / 10240 bands, the generic FFT ladder with its second buffer in memory -- the only form there (both columns are it)
+             ("default", 192000, 2.5), ("cheaper", 192000, 2.5))
     only = [a for a in sys.argv[1:] if not a.startswith("-")]  # e.g. `bench_presets.py default48000 cheaper48000`: a subset
     fast_only = "--fast-only" in sys.argv
     for preset, sr, seconds in table:
