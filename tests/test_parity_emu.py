@@ -72,7 +72,7 @@ def test_hop_magnitudes_small(emu, ref):
 
 
 def test_fused_equals_unfused(emu, monkeypatch):
-    pc.case_fused_equals_unfused(emu, monkeypatch, channel_counts=(2, 3, 5))
+    pc.case_fused_equals_unfused(emu, monkeypatch, channel_counts=(2, 5))  # (3 .. 8 channels on the device: test_parity_gpu.py)
 
 
 def test_feed_fusion_equals_separate(emu, monkeypatch):
