@@ -2,32 +2,100 @@
 // Runs each workgroup's threads as ucontext fibers, round-robin between barriers.
 #include <hip/hip_runtime.h>
 #include <ucontext.h>
+#include <cstdint>
 #include <vector>
 #include <stdexcept>
 
 EmuIdx threadIdx, blockIdx, blockDim, gridDim;
 namespace smst { alignas(16) unsigned char smemRaw[160*1024]; }
 
+// Context switches: a workgroup of 1024 fibers yields at every barrier, poll and s_sleep -- tens of millions of switches per test run.  glibc's
+// swapcontext() makes a signal-mask system call per switch (the CPU suite spent 4 min 54 s of 8 min 23 s in the kernel); the switch below saves
+// and restores the callee-saved registers and the stack pointer, nothing else (x86-64 System V).  The sanitizer build keeps swapcontext(), which
+// AddressSanitizer intercepts and understands.
+#if defined(__x86_64__) && !defined(__SANITIZE_ADDRESS__)
+#define EMU_FAST_SWITCH 1
+extern "C" void emuSwitch(void **saveSp, void *newSp);
+asm(R"(
+.text
+.globl emuSwitch
+.type emuSwitch,@function
+emuSwitch:
+	pushq %rbp
+	pushq %rbx
+	pushq %r12
+	pushq %r13
+	pushq %r14
+	pushq %r15
+	movq %rsp, (%rdi)
+	movq %rsi, %rsp
+	popq %r15
+	popq %r14
+	popq %r13
+	popq %r12
+	popq %rbx
+	popq %rbp
+	ret
+.size emuSwitch, .-emuSwitch
+)");
+#endif
+
 namespace {
 struct Fiber {
+#ifdef EMU_FAST_SWITCH
+	void *sp = nullptr;
+#else
 	ucontext_t ctx;
+#endif
 	std::vector<unsigned char> stack;
 	bool done = false;
 	EmuIdx tid;
 };
+#ifdef EMU_FAST_SWITCH
+void *schedulerSp = nullptr;
+#else
 ucontext_t schedulerCtx;
+#endif
 Fiber *current = nullptr;
 const std::function<void()> *currentBody = nullptr;
 
+void toScheduler() {
+#ifdef EMU_FAST_SWITCH
+	emuSwitch(&current->sp, schedulerSp);
+#else
+	swapcontext(&current->ctx, &schedulerCtx);
+#endif
+}
 void fiberEntry() {
 	(*currentBody)();
 	current->done = true;
-	swapcontext(&current->ctx, &schedulerCtx);
+	toScheduler();
 }
+#ifdef EMU_FAST_SWITCH
+extern "C" void emuFiberStart() { fiberEntry(); __builtin_trap(); } // (a finished fiber is never resumed)
+void prepare(Fiber &f) {
+	// the first switch into the fiber pops six registers and returns into emuFiberStart with the stack aligned as after a call
+	uintptr_t top = (reinterpret_cast<uintptr_t>(f.stack.data()) + f.stack.size()) & ~uintptr_t(15);
+	void **sp = reinterpret_cast<void **>(top - 8);
+	*--sp = reinterpret_cast<void *>(&emuFiberStart);
+	for (int i = 0; i < 6; ++i) *--sp = nullptr;
+	f.sp = sp;
+}
+void resume(Fiber &f) { emuSwitch(&schedulerSp, f.sp); }
+#else
+void prepare(Fiber &f) {
+	getcontext(&f.ctx);
+	f.ctx.uc_stack.ss_sp = f.stack.data();
+	f.ctx.uc_stack.ss_size = f.stack.size();
+	f.ctx.uc_link = &schedulerCtx;
+	makecontext(&f.ctx, fiberEntry, 0);
+}
+void resume(Fiber &f) { swapcontext(&schedulerCtx, &f.ctx); }
+#endif
 }
 
 void emuSyncThreads() {
-	swapcontext(&current->ctx, &schedulerCtx);
+	toScheduler();
 }
 
 void emuLaunch(dim3 grid, dim3 block, size_t ldsBytes, const std::function<void()> &body) {
@@ -44,11 +112,7 @@ void emuLaunch(dim3 grid, dim3 block, size_t ldsBytes, const std::function<void(
 			Fiber &f = fibers[i];
 			f.done = false;
 			f.tid = {i%block.x, (i/block.x)%block.y, i/(block.x*block.y)};
-			getcontext(&f.ctx);
-			f.ctx.uc_stack.ss_sp = f.stack.data();
-			f.ctx.uc_stack.ss_size = f.stack.size();
-			f.ctx.uc_link = &schedulerCtx;
-			makecontext(&f.ctx, fiberEntry, 0);
+			prepare(f);
 		}
 		bool anyAlive = true;
 		while (anyAlive) {
@@ -59,7 +123,7 @@ void emuLaunch(dim3 grid, dim3 block, size_t ldsBytes, const std::function<void(
 				current = &f;
 				threadIdx = f.tid;
 				blockIdx = {bx, by, bz};
-				swapcontext(&schedulerCtx, &f.ctx);
+				resume(f);
 				if (!f.done) anyAlive = true;
 			}
 		}

@@ -34,7 +34,7 @@ def test_silence(emu, ref):
 
 def test_channels(emu, ref):
     pc.case_channels(emu, ref)
-    pc.case_channels(emu, ref, channel_counts=(9,))  # beyond the fused kernels' eight: kPredictB + kChain (12 and 16 on the device)
+    pc.case_channels(emu, ref, channel_counts=(9, 12))  # beyond the fused kernels' eight: kPredictB + kChain (16 on the device too)
 
 
 def test_batch_ragged(emu, ref):
@@ -72,7 +72,7 @@ def test_hop_magnitudes_small(emu, ref):
 
 
 def test_fused_equals_unfused(emu, monkeypatch):
-    pc.case_fused_equals_unfused(emu, monkeypatch, channel_counts=(2, 5))  # (3 .. 8 channels on the device: test_parity_gpu.py)
+    pc.case_fused_equals_unfused(emu, monkeypatch, channel_counts=(2, 3, 5))
 
 
 def test_feed_fusion_equals_separate(emu, monkeypatch):
@@ -235,9 +235,7 @@ def test_split_freq_map_mid_interval_emu(emu, ref):
 
 
 def test_continuous_equals_tiled_emu(emu, monkeypatch):
-    # (two of the four combinations here -- the CPU suite's minutes; all four and two more geometries on the device: test_parity_gpu.py)
-    print(pc.case_continuous_equals_tiled(emu, monkeypatch, channel_counts=(2,), ratios=(1.5,)))
-    print(pc.case_continuous_equals_tiled(emu, monkeypatch, channel_counts=(1,), ratios=(1.0,)))
+    print(pc.case_continuous_equals_tiled(emu, monkeypatch))
 
 
 def test_formant_stages_emu(emu, ref, monkeypatch):
