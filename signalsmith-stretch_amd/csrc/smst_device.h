@@ -19,7 +19,8 @@ struct DevBatch {
 	int mapTableLen;
 	int histCur, carryCur;        // which half of the double buffers is current
 	int debugMode;                // always 0 in the product; builds with -DSMST_EXPERIMENTS read SMST_DEBUG_MODE (timing experiments)
-	int noFeedFusion;             // SMST_NO_FEED_FUSION=1: pass A stays its own kernel (kPredictA) -- cross-check of the folded form
+	int noFeedFusion;             // SMST_NO_FEED_FUSION=1: pass A stays its own kernel (kPredictA) -- cross-check of the folded forms; =2: formant tiles in two passes over the spectra
+	                              // (kFeedScanA + kFeedFreq + kFeedScanC with pass A folded) even where the one-pass form applies
 	int feedSerial;               // SMST_FEED_SERIAL: bin-by-bin feed recurrences (kFeedSerial) instead of the scan form
 	int halfState;                // carried Band.output / Prediction.energy / overlap-add sums stored in fp16 (BASELINE config 5 "fp16 internal")
 	int fftLean;                  // SMST_FFT_TABLES=lean: register-blocked FFT kernels with the smaller tables (opt-in experiment, see smst_engine.cpp)
@@ -142,13 +143,13 @@ __host__ __device__ inline bool analysisWindowInCall(int B, int M, int I, int in
 // form" tests assert through these that BOTH forms really ran.
 enum LaunchKind {
 	LK_VOC_ALIGNED, LK_VOC_STAGED, LK_VOC_GATHER, LK_VOC_N, LK_VOC_ONE, LK_VOC_ACROSS, LK_VOC_CONT, LK_CHAIN_UNFUSED,
-	LK_ANALYSE_TEAMS, LK_ANALYSE_FAST, LK_ANALYSE_GENERIC, LK_SYNTH_TEAMS, LK_SYNTH_FAST, LK_SYNTH_GENERIC, LK_SYNTH_EMIT, LK_EMIT_CARRIED, LK_COUNT
+	LK_ANALYSE_TEAMS, LK_ANALYSE_FAST, LK_ANALYSE_GENERIC, LK_SYNTH_TEAMS, LK_SYNTH_FAST, LK_SYNTH_GENERIC, LK_SYNTH_EMIT, LK_EMIT_CARRIED, LK_FEED_ONE_PASS, LK_COUNT
 };
 long long launchCount(const char *name); // -1: unknown name
 
 void launchEnergy(const DevBatch &d, const IoArgs &io, int sBase, int nStreams, int maxSamples, float *energyOut, hipStream_t st);
 void launchAnalyse(const DevBatch &d, const IoArgs &io, int sBase, int nStreams, int hopBase, int tileHops, bool anyInCall, bool anyLate, hipStream_t st);
-bool launchFeed(const DevBatch &d, int sBase, int nStreams, int hopBase, int tileHops, bool anyFormants, hipStream_t st); // true: pass A done too
+bool launchFeed(const DevBatch &d, int sBase, int nStreams, int hopBase, int tileHops, bool anyFormants, bool anyEstimatedBase, hipStream_t st); // true: pass A done too
 void launchPredict(const DevBatch &d, int sBase, int nStreams, int hopBase, int tileHops, bool plain, bool passADone, hipStream_t st);
 void launchChain(const DevBatch &d, int sBase, int nStreams, int hopBase, hipStream_t st);
 void launchPredictFused(const DevBatch &d, int sBase, int nStreams, int hopBase, int tileHops, bool plain, bool passADone, hipStream_t st);

@@ -865,7 +865,7 @@ void Batch::runPendingBlocks(const int *synthChannels) {
 		unsigned char *th = pendTileHas.data() + (size_t)sub*kTileHasStride;
 		th[0] = 1;
 		if (pb.flags & HOP_MAPPED) th[1] = 1;
-		if (pb.flags & HOP_FORMANTS) th[2] = 1;
+		if (pb.flags & HOP_FORMANTS) { th[2] = 1; th[10] = 1; } // (a block in flight may carry latched parameters: the three-kernel form decides per stream)
 		if (pb.flags & HOP_RANDOM_TF) th[4] = 1;
 		if (pb.startBin > 0) th[7] = 1;
 		th[8] = 1;
@@ -993,7 +993,7 @@ void Batch::runTilesRange(const TileRun &run, int tile0, int tile1, int carryFir
 				if (th[8]) timed(timings.otherMs, [&] { launchPendingToTile(dd, sBase, ns, dPendIn, dPendPrev, sF); }); // blocks that began in an earlier call: their spectra are waiting
 				if (th[3]) timed(timings.analyseMs, [&] { launchAnalyse(dd, io, sBase, ns, hopBase, tileHops, th[5] != 0, th[6] != 0, sF); if (profiling) ++timings.analyseLaunches; });
 				bool passADone = false;
-				if (th[1] || th[2]) timed(timings.feedMs, [&] { passADone = launchFeed(dd, sBase, ns, hopBase, tileHops, th[2] != 0, sF); });
+				if (th[1] || th[2]) timed(timings.feedMs, [&] { passADone = launchFeed(dd, sBase, ns, hopBase, tileHops, th[2] != 0, th[10] != 0, sF); });
 				timed(timings.predictMs, [&] {
 					if (fused) launchPredictFused(dd, sBase, ns, hopBase, tileHops, plain, passADone, sF);
 					else launchPredict(dd, sBase, ns, hopBase, tileHops, plain, passADone, sF);
@@ -1454,7 +1454,7 @@ void Batch::process(const float *in, long long inSS, long long inCS, const int *
 				th[0] = 1;
 				if (!(f & HOP_NEW_SPECTRUM)) th[9] = 1; // (a hop that re-uses the spectrum before it: the continuous wavefront asks for a new one per hop)
 				if (f & HOP_MAPPED) th[1] = 1;
-				if (f & HOP_FORMANTS) th[2] = 1;
+				if (f & HOP_FORMANTS) { th[2] = 1; if ((f & HOP_PREANALYSED) || params[s].formantBaseFreq <= 0) th[10] = 1; } // [10]: a stream that estimates its base frequency (:929-966)
 				if (f & HOP_RANDOM_TF) th[4] = 1;
 			}
 			info[subS + sl] = lastNewLocal;

@@ -402,6 +402,81 @@ __device__ __forceinline__ void feedEnergyToLds(const DevBatch &d, const HopDesc
 	}
 }
 
+// The formant envelope of one hop (2 x (down, up) max-decay, 2 x (down, up) min-grow over the channel-summed energies in `en`, :987-1006) and the
+// per-bin energy ratio (:1018-1033) -- into `en` in place of the energies (RATIO_TO_LDS: pass A follows in the same kernel) or to the tile's
+// ratio rows.  One workgroup of 256 threads; `sm` and `maps` are scratch.  Shared by kFeedScanC and the one-pass form of kFeedScanA.
+template <int NMAX, bool FUSE_PE>
+__device__ __forceinline__ void formantEnvelopeAndRatio(const DevBatch &d, const StreamParams &prm, int s, int sg, int k, float freqEstimate, float *en, float *sm, ScanMap *maps) {
+	const int M = d.M, t = threadIdx.x;
+	const float Nf = float(d.N);
+	float decay = 1 - 1/(freqEstimate*0.5f + 1);
+	float e = 0;
+	auto ident = [](float x) { return x; };
+	if constexpr (NMAX > 0) {
+		const int n = (M + 255)/256, cnt = min(max(M - t*n, 0), n);
+		float v[NMAX];
+#pragma unroll
+		for (int i = 0; i < NMAX; ++i) v[i] = (i < cnt) ? en[t*n + i] : 0.0f;
+		{
+			const float dk = decay;
+			auto maxDecay = [dk](float acc, float x) { return fmaxf(x, acc*dk); };
+			e = scanPassReg<1, true>(v, cnt, e, dk, ident, maxDecay, maps);
+			e = scanPassReg<1, false>(v, cnt, e, dk, ident, maxDecay, maps + 4);
+			e = scanPassReg<1, true>(v, cnt, e, dk, ident, maxDecay, maps);
+			e = scanPassReg<1, false>(v, cnt, e, dk, ident, maxDecay, maps + 4);
+		}
+		decay = 1/decay;
+		{
+			const float dk = decay;
+			auto minGrow = [dk](float acc, float x) { return fminf(x, acc*dk); };
+			for (int rep = 0; rep < 2; ++rep) {
+				e = scanPassReg<2, true>(v, cnt, e, dk, ident, minGrow, maps);
+				e = scanPassReg<2, false>(v, cnt, e, dk, ident, minGrow, maps + 4);
+			}
+		}
+#pragma unroll
+		for (int i = 0; i < NMAX; ++i) if (i < cnt) sm[t*n + i] = v[i];
+		__syncthreads();
+	} else {
+		{
+			const float dk = decay;
+			auto maxDecay = [dk](float acc, float x) { return fmaxf(x, acc*dk); };
+			e = scanPass<1, true>(en, sm, M, e, dk, ident, maxDecay, maps);
+			e = scanPass<1, false>(sm, sm, M, e, dk, ident, maxDecay, maps);
+			e = scanPass<1, true>(sm, sm, M, e, dk, ident, maxDecay, maps);
+			e = scanPass<1, false>(sm, sm, M, e, dk, ident, maxDecay, maps);
+		}
+		decay = 1/decay;
+		{
+			const float dk = decay;
+			auto minGrow = [dk](float acc, float x) { return fminf(x, acc*dk); };
+			for (int rep = 0; rep < 2; ++rep) {
+				e = scanPass<2, true>(sm, sm, M, e, dk, ident, minGrow, maps);
+				e = scanPass<2, false>(sm, sm, M, e, dk, ident, minGrow, maps);
+			}
+		}
+	}
+	float *ratio = d.ratio + ((size_t)s*d.T + k)*M;
+	for (int b = t; b < M; b += 256) {
+		float inputF = (b + 0.5f)/Nf;
+		float outputF = prm.formantCompensation ? mapFreqDev(d, prm, sg, inputF) : inputF;
+		if (outputF*prm.invFormantMultiplier > prm.freqTonalityLimit) outputF = mulAdd2(1 - prm.formantMultiplier, prm.freqTonalityLimit, outputF); // invMapFormant, :920-925
+		else outputF = outputF*prm.invFormantMultiplier;
+		const float inputE = sm[b];
+		float band = freqToBandDev(outputF, Nf);
+		float targetE = 0;
+		if (!(band < 0)) { // getFormant, :1009-1016 (entries M and M+1 of the metric are zero)
+			band = fminf(band, float(M));
+			const int fl = (int)floorf(band);
+			const float fr = band - fl;
+			const float low = (fl < M) ? sm[fl] : 0.0f, high = (fl + 1 < M) ? sm[fl + 1] : 0.0f;
+			targetE = low + (high - low)*fr;
+		}
+		if constexpr (FUSE_PE) en[b] = targetE/(inputE + 1e-30f); // the energies are dead: the ratios take their place in LDS
+		else { ratio[b] = targetE/(inputE + 1e-30f); if (d.envelope) d.envelope[((size_t)s*d.T + k)*M + b] = inputE; }
+	}
+}
+
 // Pass A (Prediction.input / .energy rows, kPredictA below) for one hop, folded into the feed kernel when no hop of the tile has
 // formant processing: the thread that has just computed the map entry of a bin forms the bin's (P, E) at once -- the map row is
 // not read back (8 B per bin) and the input rows, which this workgroup read a moment ago for the energies, come out of L2
@@ -413,16 +488,22 @@ template <typename MapAt>
 __device__ __forceinline__ void feedPredictionRows(const DevBatch &d, const HopDesc &hd, int s, int sg, int k, bool mapped, MapAt mapAt, bool storeMap, const float *ratioLds);
 
 // energy, smoothing, peaks, output map, raw pitch estimate: one workgroup per (hop, stream)
-template <int NMAX, bool FUSE_PE = false> // NMAX: bins per thread held in registers during the smoothing passes; 0: through LDS (any M)
+// FUSE_FORM (tiles WITH formant processing in which no stream estimates its base frequency -- BASELINE config 4 gives 200 Hz): the formant
+// envelope, the energy ratio and pass A follow in the SAME kernel, from the channel-summed energies that are still in LDS.  The pitch
+// estimate is what forces three kernels otherwise (it is smoothed from hop to hop: a serial walk over the tile's hops, kFeedFreq, between the
+// energies and the envelope); with a given base frequency the spectra are read once instead of twice.  Same code (formantEnvelopeAndRatio,
+// feedPredictionRows), same values: bit-identical to kFeedScanA + kFeedFreq + kFeedScanC.
+template <int NMAX, bool FUSE_PE = false, bool FUSE_FORM = false> // NMAX: bins per thread held in registers during the smoothing passes; 0: through LDS (any M)
 __global__ __launch_bounds__(256) void kFeedScanA(DevBatch d, int sBase, int hopBase) {
 	static_assert(!FUSE_PE || NMAX > 0, "pass A is folded into the register form only");
+	static_assert(!(FUSE_PE && FUSE_FORM), "FUSE_PE: tiles without formant processing; FUSE_FORM: tiles with it");
 	extern __shared__ __attribute__((aligned(16))) unsigned char smemRaw[];
 	const int k = blockIdx.x, s = blockIdx.y, sg = sBase + s;
 	if (k >= d.nHops[s]) return;
 	const HopDesc hd = d.hops[(size_t)sg*d.hopStride + hopBase + k];
 	const bool mapped = hd.flags & HOP_MAPPED, formants = hd.flags & HOP_FORMANTS;
 	if (!mapped && !formants) {
-		if constexpr (FUSE_PE) feedPredictionRows(d, hd, s, sg, k, false, [](int bb) { return make_float2(float(bb), 1.0f); }, false, nullptr);
+		if constexpr (FUSE_PE || FUSE_FORM) feedPredictionRows(d, hd, s, sg, k, false, [](int bb) { return make_float2(float(bb), 1.0f); }, false, nullptr);
 		return;
 	}
 	const int M = d.M, C = d.C, t = threadIdx.x;
@@ -600,6 +681,17 @@ __global__ __launch_bounds__(256) void kFeedScanA(DevBatch d, int sBase, int hop
 			}
 		}
 	}
+	if constexpr (FUSE_FORM) {
+		// (every stream of the tile has a base frequency: the host's condition for this form)
+		__syncthreads(); // the map row is complete (its stores are visible to the workgroup behind the barrier); `sm` / `cover` and the peaks are dead
+		if (formants) {
+			formantEnvelopeAndRatio<NMAX, true>(d, d.paramsForm2[sg], s, sg, k, freqToBandDev(d.paramsForm0[sg].formantBaseFreq, Nf), en, sm, maps);
+			__syncthreads();
+		}
+		const float2 *mapRowIn = d.map + ((size_t)s*d.T + k)*M;
+		feedPredictionRows(d, hd, s, sg, k, mapped, [&](int bb) { return mapRowIn[bb]; }, false, formants ? en : nullptr);
+		return;
+	}
 	if (formants && d.paramsForm0[sg].formantBaseFreq <= 0) {
 		// estimateFrequency() raw part, :929-960: the three highest local maxima of the metric (= the channel-summed
 		// energy), ties to the earlier bin, three copies of bin 0 as the initial entries -- a serial walk by one thread
@@ -678,73 +770,7 @@ __global__ __launch_bounds__(256) void kFeedScanC(DevBatch d, int sBase, int hop
 	const StreamParams prm = d.paramsForm2[sg];
 	feedEnergyToLds(d, hd, s, sg, en);
 	__syncthreads();
-	const float freqEstimate = d.freqEst[(size_t)s*d.T + k];
-	float decay = 1 - 1/(freqEstimate*0.5f + 1);
-	float e = 0;
-	auto ident = [](float x) { return x; };
-	if constexpr (NMAX > 0) {
-		const int n = (M + 255)/256, cnt = min(max(M - t*n, 0), n);
-		float v[NMAX];
-#pragma unroll
-		for (int i = 0; i < NMAX; ++i) v[i] = (i < cnt) ? en[t*n + i] : 0.0f;
-		{
-			const float dk = decay;
-			auto maxDecay = [dk](float acc, float x) { return fmaxf(x, acc*dk); };
-			e = scanPassReg<1, true>(v, cnt, e, dk, ident, maxDecay, maps);
-			e = scanPassReg<1, false>(v, cnt, e, dk, ident, maxDecay, maps + 4);
-			e = scanPassReg<1, true>(v, cnt, e, dk, ident, maxDecay, maps);
-			e = scanPassReg<1, false>(v, cnt, e, dk, ident, maxDecay, maps + 4);
-		}
-		decay = 1/decay;
-		{
-			const float dk = decay;
-			auto minGrow = [dk](float acc, float x) { return fminf(x, acc*dk); };
-			for (int rep = 0; rep < 2; ++rep) {
-				e = scanPassReg<2, true>(v, cnt, e, dk, ident, minGrow, maps);
-				e = scanPassReg<2, false>(v, cnt, e, dk, ident, minGrow, maps + 4);
-			}
-		}
-#pragma unroll
-		for (int i = 0; i < NMAX; ++i) if (i < cnt) sm[t*n + i] = v[i];
-		__syncthreads();
-	} else {
-		{
-			const float dk = decay;
-			auto maxDecay = [dk](float acc, float x) { return fmaxf(x, acc*dk); };
-			e = scanPass<1, true>(en, sm, M, e, dk, ident, maxDecay, maps);
-			e = scanPass<1, false>(sm, sm, M, e, dk, ident, maxDecay, maps);
-			e = scanPass<1, true>(sm, sm, M, e, dk, ident, maxDecay, maps);
-			e = scanPass<1, false>(sm, sm, M, e, dk, ident, maxDecay, maps);
-		}
-		decay = 1/decay;
-		{
-			const float dk = decay;
-			auto minGrow = [dk](float acc, float x) { return fminf(x, acc*dk); };
-			for (int rep = 0; rep < 2; ++rep) {
-				e = scanPass<2, true>(sm, sm, M, e, dk, ident, minGrow, maps);
-				e = scanPass<2, false>(sm, sm, M, e, dk, ident, minGrow, maps);
-			}
-		}
-	}
-	float *ratio = d.ratio + ((size_t)s*d.T + k)*M;
-	for (int b = t; b < M; b += 256) {
-		float inputF = (b + 0.5f)/Nf;
-		float outputF = prm.formantCompensation ? mapFreqDev(d, prm, sg, inputF) : inputF;
-		if (outputF*prm.invFormantMultiplier > prm.freqTonalityLimit) outputF = mulAdd2(1 - prm.formantMultiplier, prm.freqTonalityLimit, outputF); // invMapFormant, :920-925
-		else outputF = outputF*prm.invFormantMultiplier;
-		const float inputE = sm[b];
-		float band = freqToBandDev(outputF, Nf);
-		float targetE = 0;
-		if (!(band < 0)) { // getFormant, :1009-1016 (entries M and M+1 of the metric are zero)
-			band = fminf(band, float(M));
-			const int fl = (int)floorf(band);
-			const float fr = band - fl;
-			const float low = (fl < M) ? sm[fl] : 0.0f, high = (fl + 1 < M) ? sm[fl + 1] : 0.0f;
-			targetE = low + (high - low)*fr;
-		}
-		if constexpr (FUSE_PE) en[b] = targetE/(inputE + 1e-30f); // the energies are dead: the ratios take their place in LDS
-		else { ratio[b] = targetE/(inputE + 1e-30f); if (d.envelope) d.envelope[((size_t)s*d.T + k)*M + b] = inputE; }
-	}
+	formantEnvelopeAndRatio<NMAX, FUSE_PE>(d, prm, s, sg, k, d.freqEst[(size_t)s*d.T + k], en, sm, maps);
 	if constexpr (FUSE_PE) {
 		__syncthreads();
 		const float2 *mapRowIn = d.map + ((size_t)s*d.T + k)*M;
@@ -756,7 +782,7 @@ __global__ __launch_bounds__(256) void kFeedScanC(DevBatch d, int sBase, int hop
 // host-side launcher
 // ------------------------------------------------------------------------------------------------------
 // returns true if pass A (the (P, E) rows) has been done here: tiles without formant processing, presets' plan sizes
-bool launchFeed(const DevBatch &d, int sBase, int nStreams, int hopBase, int tileHops, bool anyFormants, hipStream_t st) {
+bool launchFeed(const DevBatch &d, int sBase, int nStreams, int hopBase, int tileHops, bool anyFormants, bool anyEstimatedBase, hipStream_t st) {
 	if (d.feedSerial) { // bin-by-bin evaluation (SMST_FEED_SERIAL=1)
 		hipLaunchKernelGGL(kFeedEnergy, dim3(divUp(d.M, 64), nStreams), dim3(256), 64*65*sizeof(float), st, d, sBase, hopBase);
 		hipLaunchKernelGGL(kFeedSerial, dim3(nStreams), dim3(64), 0, st, d, sBase, hopBase);
@@ -765,10 +791,16 @@ bool launchFeed(const DevBatch &d, int sBase, int nStreams, int hopBase, int til
 	const size_t ldsA = (size_t)2*d.M*sizeof(float) + (size_t)(d.M/2 + 2)*sizeof(float2) + 264*sizeof(ScanMap) + 264*sizeof(int);
 	const size_t ldsC = (size_t)2*d.M*sizeof(float) + 264*sizeof(ScanMap);
 	const int perThread = divUp(d.M, 256); // bins per thread: in registers up to 24 (M <= 6144), through LDS beyond
-	const bool fusePassA = !anyFormants && perThread <= 24 && !d.noFeedFusion;
+	const bool fusePassA = !anyFormants && perThread <= 24 && d.noFeedFusion != 1;
 	if (fusePassA) {
 		if (perThread <= 16) hipLaunchKernelGGL((kFeedScanA<16, true>), dim3(tileHops, nStreams), dim3(256), ldsA, st, d, sBase, hopBase);
 		else hipLaunchKernelGGL((kFeedScanA<24, true>), dim3(tileHops, nStreams), dim3(256), ldsA, st, d, sBase, hopBase);
+		return true;
+	}
+	if (anyFormants && !anyEstimatedBase && perThread <= 24 && d.noFeedFusion == 0) { // formant tiles, every base frequency given: ONE pass over the spectra
+		if (perThread <= 16) hipLaunchKernelGGL((kFeedScanA<16, false, true>), dim3(tileHops, nStreams), dim3(256), ldsA, st, d, sBase, hopBase);
+		else hipLaunchKernelGGL((kFeedScanA<24, false, true>), dim3(tileHops, nStreams), dim3(256), ldsA, st, d, sBase, hopBase);
+		countLaunch(LK_FEED_ONE_PASS);
 		return true;
 	}
 	if (perThread <= 16) hipLaunchKernelGGL(kFeedScanA<16>, dim3(tileHops, nStreams), dim3(256), ldsA, st, d, sBase, hopBase);
@@ -776,7 +808,7 @@ bool launchFeed(const DevBatch &d, int sBase, int nStreams, int hopBase, int til
 	else hipLaunchKernelGGL(kFeedScanA<0>, dim3(tileHops, nStreams), dim3(256), ldsA, st, d, sBase, hopBase);
 	if (anyFormants) {
 		hipLaunchKernelGGL(kFeedFreq, dim3(divUp(nStreams, 64)), dim3(64), 0, st, d, sBase, nStreams, hopBase);
-		if (!d.noFeedFusion) { // tiles with formant processing: pass A at the end of the envelope kernel, the ratios still in LDS
+		if (d.noFeedFusion != 1) { // tiles with formant processing: pass A at the end of the envelope kernel, the ratios still in LDS (SMST_NO_FEED_FUSION=2: this form even where one pass would do)
 			if (perThread <= 16) hipLaunchKernelGGL((kFeedScanC<16, true>), dim3(tileHops, nStreams), dim3(256), ldsC, st, d, sBase, hopBase);
 			else if (perThread <= 24) hipLaunchKernelGGL((kFeedScanC<24, true>), dim3(tileHops, nStreams), dim3(256), ldsC, st, d, sBase, hopBase);
 			else hipLaunchKernelGGL((kFeedScanC<0, true>), dim3(tileHops, nStreams), dim3(256), ldsC, st, d, sBase, hopBase);

@@ -221,7 +221,7 @@ void launchComplexSelfTest(const float *in, float *out, int n, hipStream_t st) {
 static std::atomic<long long> gLaunchCounts[LK_COUNT];
 static const char *const kLaunchNames[LK_COUNT] = {
 	"vocoder_aligned", "vocoder_staged", "vocoder_gather", "vocoder_n", "vocoder_one", "vocoder_across", "vocoder_continuous", "chain_unfused",
-	"analyse_teams", "analyse_fast", "analyse_generic", "synth_teams", "synth_fast", "synth_generic", "synth_emit", "emit_carried"};
+	"analyse_teams", "analyse_fast", "analyse_generic", "synth_teams", "synth_fast", "synth_generic", "synth_emit", "emit_carried", "feed_one_pass"};
 void countLaunch(LaunchKind k) { gLaunchCounts[k].fetch_add(1, std::memory_order_relaxed); }
 long long launchCount(const char *name) {
 	for (int i = 0; i < LK_COUNT; ++i) if (name && std::strcmp(name, kLaunchNames[i]) == 0) return gLaunchCounts[i].load(std::memory_order_relaxed);

@@ -10,7 +10,8 @@
 //   SMST_NO_SINGLE_HOP     unset    set: one-hop tiles through the wavefront kernels instead of kVocoderOne / ACROSS
 //   SMST_NO_ACROSS         unset    set: one-hop tiles one chain per stream (kVocoderOne) instead of lanes across streams
 //   SMST_CHECK_LAUNCHES    0        1: hipGetLastError() after every launch group of process(), not only at its end
-//   SMST_NO_FEED_FUSION    0        1: pass A (the (P, E) rows) as its own kernel (kPredictA) instead of folded into the feed kernels
+//   SMST_NO_FEED_FUSION    0        1: pass A (the (P, E) rows) as its own kernel (kPredictA) instead of folded into the feed kernels; 2: formant tiles in two passes over
+//                                   the spectra (round 5's form) even where every base frequency is given and one pass does (round 6)
 //   SMST_NO_STAGE          unset    set: the fused kernel's producers gather from HBM where staging applies
 //   SMST_NO_ALIGN          unset    set: staged producers with per-row windows and lag L + 1 instead of the line-aligned form
 //   SMST_ALIGN_ALL         unset    set: the line-aligned producers for every geometry they are valid for (default: L = 4 only)

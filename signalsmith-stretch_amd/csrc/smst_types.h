@@ -9,7 +9,7 @@ constexpr int kMaxChannels = 16; // per-lane channel arrays of the recurrence ke
                                 // 9-16 the un-fused pair kPredictB + kChain (records through HBM: slower, the same arithmetic)
 constexpr int kMaxFusedChannels = 8;
 constexpr int kMaxFftPasses = 12;
-constexpr int kTileHasStride = 12; // per-tile summary bytes of the host scheduler: any hop / mapped / formants / new spectrum / random time factor / analysis window in the call / reaching into the history / a start bin / a pre-analysed hop
+constexpr int kTileHasStride = 12; // per-tile summary bytes of the host scheduler: any hop / mapped / formants / new spectrum / random time factor / analysis window in the call / reaching into the history / a start bin / a pre-analysed hop / a hop without a new spectrum / a formant hop that estimates its base frequency
 constexpr int kEnergyParts = 16; // partial sums per stream in the silence-gate reduction
 
 // Hop flags (reference: signalsmith-stretch.h:299-313)

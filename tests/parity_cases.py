@@ -323,34 +323,42 @@ def case_fused_equals_unfused(lib, monkeypatch, channel_counts=(3, 8), geometry=
         assert np.array_equal(outs[0], outs[1]), (C, float(np.abs(outs[0] - outs[1]).max()))
 
 
-def case_feed_fusion_equals_separate(lib, monkeypatch, channel_counts=(2, 3), geometry=None, n=9000, formants=False):
+def case_feed_fusion_equals_separate(lib, monkeypatch, channel_counts=(2, 3), geometry=None, n=9000, formants=False, bases_given=False):
     """Pass A folded into the feed kernel (tiles with a pitch map and no formant processing) against the separate kPredictA
     (SMST_NO_FEED_FUSION=1): the same arithmetic on the same operands, so bit-identical -- mapped and unmapped streams side
-    by side, two calls."""
+    by side, two calls.  `formants`: tiles with formant processing fold pass A into the envelope kernel (the ratios stay in LDS);
+    `bases_given`: every formant stream has a base frequency, so the whole feed stage is ONE kernel (kFeedScanA<.., FUSE_FORM>, round 6) --
+    compared with the two-pass form (SMST_NO_FEED_FUSION=2) and the separate kernels (=1); the launch counter proves which ran."""
     pkg = package()
     geometry = geometry or dict(block=512, interval=128, split=False)
     for C in channel_counts:
         xs = np.stack([synth_input(s, C, n, 48000)*(1 + 0.2*np.arange(C))[:, None].astype(np.float32) for s in range(4)])
         outs = []
-        for separate in (False, True):
-            if separate:
-                monkeypatch.setenv("SMST_NO_FEED_FUSION", "1")
+        for mode in ((None, "2", "1") if bases_given else (None, "1")):
+            if mode:
+                monkeypatch.setenv("SMST_NO_FEED_FUSION", mode)
             else:
                 monkeypatch.delenv("SMST_NO_FEED_FUSION", raising=False)
+            before = pkg.launch_count("feed_one_pass", lib)
             b = pkg.StretchBatch(4, C, lib=lib, **geometry)
             b.setTransposeSemitones(5.0, 0.2, stream=0)
             b.setTransposeSemitones(-7.0, 0.0, stream=2)
-            if formants:  # formant tiles fold pass A into the envelope kernel instead (ratios in LDS)
+            if formants:
                 b.setFormantFactor(1.0, True, stream=0)
                 b.setFormantBase(200/48000, stream=0)
-                b.setFormantSemitones(3.0, False, stream=3)
+                b.setFormantSemitones(3.0, False, stream=3)   # (formant processing without a pitch map; streams 1 and 2 have none)
+                if bases_given:
+                    b.setFormantBase(150/48000, stream=3)
             y1 = np.array(b.process(xs[:, :, :n//3], int(n//3*0.9)), copy=True)
             y2 = np.array(b.process(xs[:, :, n//3:], int((n - n//3)*0.9)), copy=True)
             b.close()
+            grew = pkg.launch_count("feed_one_pass", lib) - before
+            assert (grew > 0) == (bases_given and mode is None), (mode, grew)
             outs.append(np.concatenate([y1, y2], axis=2))
         monkeypatch.delenv("SMST_NO_FEED_FUSION", raising=False)
         assert np.abs(outs[0]).max() > 0.05
-        assert np.array_equal(outs[0], outs[1]), (C, float(np.abs(outs[0] - outs[1]).max()))
+        for other in outs[1:]:
+            assert np.array_equal(outs[0], other), (C, float(np.abs(outs[0] - other).max()))
 
 
 def case_single_hop_chunks(lib, geometry=None, channel_counts=(1, 2, 3), hops=15, setup=None):

@@ -78,6 +78,7 @@ def test_fused_equals_unfused(emu, monkeypatch):
 def test_feed_fusion_equals_separate(emu, monkeypatch):
     pc.case_feed_fusion_equals_separate(emu, monkeypatch)
     pc.case_feed_fusion_equals_separate(emu, monkeypatch, channel_counts=(2,), formants=True)
+    pc.case_feed_fusion_equals_separate(emu, monkeypatch, channel_counts=(2, 3), formants=True, bases_given=True)  # the one-pass form (round 6)
 
 
 def test_single_hop_chunks(emu):

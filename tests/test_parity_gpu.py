@@ -524,6 +524,8 @@ def test_feed_fusion_equals_separate(hip, monkeypatch):
     pc.case_feed_fusion_equals_separate(hip, monkeypatch, channel_counts=(2,), geometry=dict(preset="default", sample_rate=48000.0), n=40000)
     pc.case_feed_fusion_equals_separate(hip, monkeypatch, channel_counts=(1, 2, 8), formants=True)
     pc.case_feed_fusion_equals_separate(hip, monkeypatch, channel_counts=(2,), geometry=dict(preset="default", sample_rate=48000.0), n=40000, formants=True)
+    pc.case_feed_fusion_equals_separate(hip, monkeypatch, channel_counts=(1, 2, 8), formants=True, bases_given=True)  # every base frequency given: the feed stage is ONE kernel
+    pc.case_feed_fusion_equals_separate(hip, monkeypatch, channel_counts=(2,), geometry=dict(preset="default", sample_rate=48000.0), n=40000, formants=True, bases_given=True)
 
 
 def test_fused_equals_unfused(hip, monkeypatch):
