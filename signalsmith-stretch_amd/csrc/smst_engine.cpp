@@ -477,7 +477,7 @@ void Batch::allocateWorkspace() {
 	}
 	if (workspaceGiB > 0) budgetGiB = std::max(0.0005, workspaceGiB); // SMST_WORKSPACE_GIB (smst_switches.h)
 	const bool needRecords = !fusedSupported(d) || noFuse; // the fused recurrence keeps its records in LDS
-	const size_t recChunks = (9 + 3*(size_t)C + 3)/4;
+	const size_t recChunks = (size_t(recordFloats(C)) + 3)/4;
 	d.recSteps = ((M + d.lag*(d.T - 1) + 63)/64)*64 + 8;
 	d.recPitch = int(recChunks*64 + 16);
 	d.Mp = (M + 32 + 15) & ~15; // rows start on 128-byte lines (the recurrence's writer stores aligned 64-byte groups)

@@ -90,8 +90,7 @@ __device__ __forceinline__ float2 rotAt(const float2 *rot, int M, int idx, bool 
 }
 
 
-// Per-channel fields of a record (floats 9..).  Any channel count but two: {P_c, sqrt(E_c)} per channel, the recurrence forms
-// the lock  makeOutput(out_m * P_c conj(P_m), P_c, sqrt(E_c))  itself (:791-800).  STEREO: the one locked channel's
+// Per-channel fields of a record (floats 9..).  Mono: {P, sqrt(E)}.  3 and more channels: see the branch below.  STEREO: the one locked channel's
 // makeOutput is folded into the record -- |out_m|^2 = E_m by construction (:602), so the norm of the lock's phase is
 // E_m |P_o conj(P_m)|^2 and the producer can scale the twist itself:
 //   9..11  Fb = P_m * sqrt(E_m) / sqrt(|P_m|^2 + 1e-15), sqrt(E_m)   (the maximum channel's own makeOutput: Fb is what it returns when
@@ -102,7 +101,7 @@ __device__ __forceinline__ float2 rotAt(const float2 *rot, int M, int idx, bool 
 // compare, a reciprocal square root and four selects ON THE SERIAL PATH -- 77 of the 563 clock cycles a step took (cycle
 // trace, tools/probes/voc_trace.py).  The norm is E_m |T|^2 instead of |out_m T|^2: equal up to rounding (1e-7 relative).
 template <int CH, int NFLOATS>
-__device__ __forceinline__ void recordChannelFields(float (&f)[NFLOATS], const float2 (&p)[CH], const float (&e)[CH], int mc) {
+__device__ __forceinline__ void recordChannelFields(float (&f)[NFLOATS], const float2 (&p)[CH], const float (&e)[CH], int mc, float2 PmN = float2{0.f, 0.f}, float eMN = 0.0f) {
 	if constexpr (CH == 2) {
 		const float2 Pm = mc ? p[1] : p[0], Po = mc ? p[0] : p[1];
 		const float eM = mc ? e[1] : e[0], eO = mc ? e[0] : e[1];
@@ -115,10 +114,43 @@ __device__ __forceinline__ void recordChannelFields(float (&f)[NFLOATS], const f
 		f[9] = Fb.x; f[10] = Fb.y; f[11] = sM;
 		f[12] = weak ? 0.0f : T.x*g; f[13] = weak ? 0.0f : T.y*g;
 		f[14] = weak ? Po.x*g : 0.0f; f[15] = weak ? Po.y*g : 0.0f;
+	} else if constexpr (CH == 1) {
+		f[9] = p[0].x; f[10] = p[0].y; f[11] = __builtin_amdgcn_sqrtf(e[0]); // 1-ulp hardware square root
 	} else {
+		// 3 and more channels (round 6): the stereo record's idea for EVERY locked channel.  9..11 as there (the maximum channel's fallback output
+		// and sqrt(E_m)); per channel c two floats X_c = the lock's twist P_c conj(P_m) scaled to sqrt(E_c) / sqrt(E_m |P_c conj(P_m)|^2) -- or, where that
+		// norm is below the noise floor (:598-601), the channel's own input scaled to sqrt(E_c), flagged in bit 8 + c of the word that carries the
+		// maximum channel.  The recurrence wave then forms  out_c = weak_c ? X_c : out_m X_c : one complex multiply and a select per channel instead
+		// of two multiplies, two norms, a reciprocal square root and four selects (~450 -> ~200 instructions per step at 8 channels, on the one wave
+		// whose chain is the kernel's serial path).  The norm is E_m |T|^2 instead of |out_m T|^2, as in the stereo record.
+		// (PmN, eMN = p[mc], e[mc] as the caller's arg-max loop tracked them: a second chain of selects over the arrays here is turned into a
+		// dynamically indexed private array by the compiler -- scratch memory.  Callers with 1 or 2 channels leave them out.)
+		const float2 Pm = PmN;
+		const float eM = eMN;
+		const float sM = __builtin_amdgcn_sqrtf(eM);
+		const float2 Fb = cscale(Pm, sM*__builtin_amdgcn_rsqf(cnorm(Pm) + 1e-15f));
+		f[9] = Fb.x; f[10] = Fb.y; f[11] = sM;
+		unsigned word = unsigned(mc);
 #pragma unroll
-		for (int c = 0; c < CH; ++c) { f[9 + 3*c] = p[c].x; f[10 + 3*c] = p[c].y; f[11 + 3*c] = __builtin_amdgcn_sqrtf(e[c]); } // 1-ulp hardware square root
+		for (int c = 0; c < CH; ++c) {
+			const float2 T = cmulc(p[c], Pm);
+			const float nT = eM*cnorm(T);
+			const bool weak = nT <= 1e-15f;
+			const float g = __builtin_amdgcn_sqrtf(e[c])*__builtin_amdgcn_rsqf(weak ? cnorm(p[c]) + 1e-15f : nT);
+			f[12 + 2*c] = (weak ? p[c].x : T.x)*g;
+			f[13 + 2*c] = (weak ? p[c].y : T.y)*g;
+			if (weak) word |= 256u << c;
+		}
+		f[8] = __int_as_float(int(word));
 	}
+}
+// 3 and more channels: channel c's output from the maximum channel's (see recordChannelFields); `word` = the record's float 8 as an integer
+template <int NFLOATS>
+__device__ __forceinline__ float2 lockedOutputN(float2 om, const float (&f)[NFLOATS], int c, unsigned word) {
+	const float2 X = make_float2(f[12 + 2*c], f[13 + 2*c]);
+	const float2 t = cmul(om, X);
+	const bool weak = (word >> (8 + c)) & 1u;
+	return make_float2(weak ? X.x : t.x, weak ? X.y : t.y);
 }
 // stereo: the locked channel's output from the maximum channel's (see recordChannelFields)
 template <int NFLOATS>
@@ -392,7 +424,7 @@ __device__ __forceinline__ void computeRecord(const DevBatch &d, const HopDesc &
 	f[0] = A.x; f[1] = A.y; f[2] = B.x; f[3] = B.y; f[4] = Cc.x; f[5] = Cc.y; f[6] = Dc.x; f[7] = Dc.y;
 	f[8] = __int_as_float(mc);
 	static_assert(!LOCK, "the separate lock-twist fields are gone: stereo records carry the scaled twist (recordChannelFields)");
-	recordChannelFields<CH>(f, p, e, mc);
+	recordChannelFields<CH>(f, p, e, mc, Pm, eMax);
 }
 
 // ------------------------------------------------------------------------------------------------------

@@ -8,6 +8,8 @@ constexpr int kTileHops = 64;   // hops per tile = lanes of the wave that runs t
 constexpr int kMaxChannels = 16; // per-lane channel arrays of the recurrence kernels are sized at compile time: 1-2 channels kVocoder, 3-8 kVocoderN (records in LDS),
                                 // 9-16 the un-fused pair kPredictB + kChain (records through HBM: slower, the same arithmetic)
 constexpr int kMaxFusedChannels = 8;
+// floats of one record of the bin recurrence (smst_recurrence.h: computeRecord / recordChannelFields): four twists, the maximum channel, then per-channel fields
+constexpr int recordFloats(int channels) { return channels <= 2 ? 9 + 3*channels : 12 + 2*channels; }
 constexpr int kMaxFftPasses = 12;
 constexpr int kTileHasStride = 12; // per-tile summary bytes of the host scheduler: any hop / mapped / formants / new spectrum / random time factor / analysis window in the call / reaching into the history / a start bin / a pre-analysed hop / a hop without a new spectrum / a formant hop that estimates its base frequency
 constexpr int kEnergyParts = 16; // partial sums per stream in the silence-gate reduction

@@ -41,7 +41,7 @@ __global__ __launch_bounds__(256) void kPredictA(DevBatch d, int sBase, int hopB
 // (Used for more than 2 channels; mono/stereo use the fused kVocoder below, which never writes records to HBM.)
 template <int CH, bool PLAIN>
 __global__ __launch_bounds__(256) void kPredictB(DevBatch d, int sBase, int hopBase) {
-	constexpr int NF = 9 + 3*CH, NCH = (NF + 3)/4;
+	constexpr int NF = recordFloats(CH), NCH = (NF + 3)/4;
 	extern __shared__ __attribute__((aligned(16))) unsigned char smemRaw[];
 	float4 *tile = reinterpret_cast<float4 *>(smemRaw); // [(st*NCH + j)*65 + k]
 	const int s = blockIdx.y, sg = sBase + s;
@@ -79,7 +79,7 @@ __global__ __launch_bounds__(256) void kPredictB(DevBatch d, int sBase, int hopB
 
 template <int CH>
 __global__ __launch_bounds__(64) void kChain(DevBatch d, int sBase, int hopBase) {
-	constexpr int NF = 9 + 3*CH, NCH = (NF + 3)/4;
+	constexpr int NF = recordFloats(CH), NCH = (NF + 3)/4;
 	constexpr int PD = 4; // prefetch depth (one wave per SIMD slot: the register file is not the limit)
 	extern __shared__ __attribute__((aligned(16))) unsigned char smemRaw[];
 	const int R = d.ringSlots, Rm = R - 1;
@@ -147,16 +147,15 @@ __global__ __launch_bounds__(64) void kChain(DevBatch d, int sBase, int hopBase)
 				for (int j = 0; j < NCH; ++j) { f[4*j] = q[u][j].x; f[4*j + 1] = q[u][j].y; f[4*j + 2] = q[u][j].z; f[4*j + 3] = q[u][j].w; }
 				const int b = t - lag*k;
 				const bool valid = active && b >= 0 && b < M;
-				int mc = __float_as_int(f[8]);
-				mc = (mc < 0) ? 0 : ((mc > CH - 1) ? CH - 1 : mc); // records of out-of-range steps are not initialised
-				float2 o1 = own1[0], pm = make_float2(f[9], f[10]);
-				float sm = f[11];
+				const unsigned word = unsigned(__float_as_int(f[8])); // the maximum channel; 3+ channels: bits 8.. flag the channels whose lock falls back to their input
+				int mc = int(word & 255u);
+				mc = (mc > CH - 1) ? CH - 1 : mc; // records of out-of-range steps are not initialised
+				float2 o1 = own1[0];
+				const float2 pm = make_float2(f[9], f[10]); // mono: the input; 2+ channels: the maximum channel's fallback output (recordChannelFields)
+				const float sm = f[11];
 #pragma unroll
 				for (int c = 1; c < CH; ++c) {
-					if (c == mc) {
-						o1 = own1[c];
-						if (CH != 2) { pm = make_float2(f[9 + 3*c], f[10 + 3*c]); sm = f[11 + 3*c]; } // stereo records lead with the maximum channel
-					}
+					if (c == mc) o1 = own1[c];
 				}
 				const int ringRow = mc*R;
 				const float2 oL = lds[(ringRow + ((b - L) & Rm))*64 + k];
@@ -167,17 +166,14 @@ __global__ __launch_bounds__(64) void kChain(DevBatch d, int sBase, int hopBase)
 				float2 phi = prevHopTerms(p1, make_float2(f[4], f[5]), pL, make_float2(f[6], f[7])); // previous hop's part first (what FOLD0 records pre-compute)
 				phi = cfma(oL, make_float2(f[2], f[3]), phi);
 				phi = cfma(o1, make_float2(f[0], f[1]), phi); // the newest operand last: two dependent instructions behind it
-				const float2 om = (CH == 2) ? makeOutputFb(phi, pm, sm) : makeOutput(phi, pm, sm); // :788 (stereo records carry the fallback output in pm's place)
+				const float2 om = (CH >= 2) ? makeOutputFb(phi, pm, sm) : makeOutput(phi, pm, sm); // :788 (records of 2+ channels carry the fallback output in pm's place)
 				const float2 olock = (CH == 2) ? lockedOutput(om, f) : om; // stereo: see recordChannelFields
 #pragma unroll
 				for (int c = 0; c < CH; ++c) {
 					float2 oc;
-					if constexpr (CH == 2) {
-						oc = olock;
-					} else {
-						const float2 pc = make_float2(f[9 + 3*c], f[10 + 3*c]);
-						oc = makeOutput(cmul(om, cmulc(pc, pm)), pc, f[11 + 3*c]); // channel lock, :791-800
-					}
+					if constexpr (CH == 2) oc = olock;
+					else if constexpr (CH == 1) oc = om;
+					else oc = lockedOutputN(om, f, c, word); // channel lock, :791-800, pre-scaled by the record's producer
 					if (c == mc) oc = om;
 					if (!valid) oc = make_float2(0.f, 0.f);
 					own1[c] = oc;
@@ -201,7 +197,7 @@ __global__ __launch_bounds__(64) void kChain(DevBatch d, int sBase, int hopBase)
 // K3 fused, 3-8 channels (signalsmith-stretch.h:722-803 for any channel count).  Same organisation as kVocoder -- producer
 // waves compute the records into an LDS ring, wave 0 runs the skewed wavefront, wave 4 drains the results with
 // row-coalesced stores -- with three differences that the channel count forces:
-//   * a record is 9 + 3*CH floats (36 for 8 channels), so a block is 4 steps instead of 8 (2 x 4 x 9 KiB of LDS);
+//   * a record is 12 + 2*CH floats (28 for 8 channels; 9 + 3*CH = 33 until round 6), so a block is 4 steps instead of 8 (2 x 4 x 7 KiB of LDS);
 //   * the consumer's history cannot live in registers (8 steps x CH complex values): each lane keeps its last output per
 //     channel in registers (the b-1 tap) and everything else in an LDS ring [CH][16 bins][64 lanes] indexed by the bin,
 //     which the next lane (the b+1 / b+L taps of the previous hop) and the writer read as well -- so there is no
@@ -215,7 +211,7 @@ constexpr int kVocNBlockSteps = 4, kVocNBlocks = 2, kVocNRing = 16;
 
 template <int CH, bool PLAIN, int L>
 __global__ __launch_bounds__(64*kVocWaves) __attribute__((amdgpu_waves_per_eu(4, 4))) void kVocoderN(DevBatch d, int sBase, int hopBase) {
-	constexpr int NF = 9 + 3*CH, NCH = (NF + 3)/4, BS = kVocNBlockSteps, NB = kVocNBlocks, R = kVocNRing, Rm = R - 1;
+	constexpr int NF = recordFloats(CH), NCH = (NF + 3)/4, BS = kVocNBlockSteps, NB = kVocNBlocks, R = kVocNRing, Rm = R - 1;
 	constexpr int NP = kVocWaves - 2;
 	constexpr int lag = L + 1;
 	static_assert(CH >= 3 && CH <= kMaxFusedChannels && L >= 1 && L + BS < R, "ring depth: a slot is rewritten R bins later, the oldest tap is L bins back");
@@ -384,13 +380,15 @@ __global__ __launch_bounds__(64*kVocWaves) __attribute__((amdgpu_waves_per_eu(4,
 					f[4*j] = q.x; f[4*j + 1] = q.y; f[4*j + 2] = q.z; f[4*j + 3] = q.w;
 				}
 				const int b = t - kLag;
-				int mc = __float_as_int(f[8]);
-				mc = (mc < 0) ? 0 : ((mc > CH - 1) ? CH - 1 : mc);
-				float2 o1 = own1[0], pm = make_float2(f[9], f[10]);
-				float sm = f[11];
+				const unsigned word = unsigned(__float_as_int(f[8])); // the maximum channel; bits 8..: channels whose lock falls back to their own input
+				int mc = int(word & 255u);
+				mc = (mc > CH - 1) ? CH - 1 : mc;
+				float2 o1 = own1[0];
+				const float2 pm = make_float2(f[9], f[10]); // the maximum channel's fallback output (recordChannelFields)
+				const float sm = f[11];
 #pragma unroll
 				for (int c = 1; c < CH; ++c) {
-					if (c == mc) { o1 = own1[c]; pm = make_float2(f[9 + 3*c], f[10 + 3*c]); sm = f[11 + 3*c]; }
+					if (c == mc) o1 = own1[c];
 				}
 				const int ringRow = mc*R;
 				const float2 oL = ring[(ringRow + ((b - L) & Rm))*64 + k];
@@ -399,11 +397,10 @@ __global__ __launch_bounds__(64*kVocWaves) __attribute__((amdgpu_waves_per_eu(4,
 				float2 phi = prevHopTerms(p1, make_float2(f[4], f[5]), pL, make_float2(f[6], f[7])); // previous hop's part first (what FOLD0 records pre-compute)
 				phi = cfma(oL, make_float2(f[2], f[3]), phi);
 				phi = cfma(o1, make_float2(f[0], f[1]), phi); // the newest operand last: two dependent instructions behind it
-				const float2 om = makeOutput(phi, pm, sm); // :788
+				const float2 om = makeOutputFb(phi, pm, sm); // :788
 #pragma unroll
 				for (int c = 0; c < CH; ++c) {
-					const float2 pc = make_float2(f[9 + 3*c], f[10 + 3*c]);
-					float2 oc = makeOutput(cmul(om, cmulc(pc, pm)), pc, f[11 + 3*c]); // channel lock, :791-800
+					float2 oc = lockedOutputN(om, f, c, word); // channel lock, :791-800: one complex multiply, its normalisation is the producer's (recordChannelFields)
 					if (c == mc) oc = om;
 					// cells outside the tile (inactive hop, bin outside [0, M)) have all-zero records, which give exactly zero here
 					own1[c] = oc;
@@ -433,7 +430,7 @@ constexpr int kVocOneBlock = 64;
 
 template <int CH, bool PLAIN, int L>
 __global__ __launch_bounds__(128) void kVocoderOne(DevBatch d, int sBase, int hopBase) {
-	constexpr int NF = 9 + 3*CH, NCH = (NF + 3)/4, BS = kVocOneBlock, NB = 2;
+	constexpr int NF = recordFloats(CH), NCH = (NF + 3)/4, BS = kVocOneBlock, NB = 2;
 	extern __shared__ __attribute__((aligned(16))) unsigned char smemRaw[];
 	float4 *recs = reinterpret_cast<float4 *>(smemRaw);                  // [slot][step][NCH]
 	float2 *outRing = reinterpret_cast<float2 *>(recs + NB*BS*NCH);      // [2 blocks][CH][BS]: results on their way to HBM
@@ -532,34 +529,29 @@ __global__ __launch_bounds__(128) void kVocoderOne(DevBatch d, int sBase, int ho
 					const float4 q = blockRecs[step*NCH + j];
 					f[4*j] = q.x; f[4*j + 1] = q.y; f[4*j + 2] = q.z; f[4*j + 3] = q.w;
 				}
-				int mc = __float_as_int(f[8]);
-				mc = (mc < 0) ? 0 : ((mc > CH - 1) ? CH - 1 : mc);
+				const unsigned word = unsigned(__float_as_int(f[8])); // the maximum channel; 3+ channels: bits 8.. flag the channels whose lock falls back to their input
+				int mc = int(word & 255u);
+				mc = (mc > CH - 1) ? CH - 1 : mc;
 				float2 o1 = h[(i + 7) & 7][0], oL = h[(i + 8 - L) & 7][0];
 				float2 p1 = stage[(b + 1) & 127], pL = stage[(b + L) & 127];
-				float2 pm = make_float2(f[9], f[10]);
-				float sm = f[11];
+				const float2 pm = make_float2(f[9], f[10]); // mono: the input; 2+ channels: the maximum channel's fallback output
+				const float sm = f[11];
 #pragma unroll
 				for (int c = 1; c < CH; ++c) {
 					const float2 p1c = stage[c*128 + ((b + 1) & 127)], pLc = stage[c*128 + ((b + L) & 127)];
-					if (c == mc) {
-						o1 = h[(i + 7) & 7][c]; oL = h[(i + 8 - L) & 7][c]; p1 = p1c; pL = pLc;
-						if (CH != 2) { pm = make_float2(f[9 + 3*c], f[10 + 3*c]); sm = f[11 + 3*c]; } // stereo records lead with the maximum channel
-					}
+					if (c == mc) { o1 = h[(i + 7) & 7][c]; oL = h[(i + 8 - L) & 7][c]; p1 = p1c; pL = pLc; }
 				}
 				float2 phi = prevHopTerms(p1, make_float2(f[4], f[5]), pL, make_float2(f[6], f[7])); // previous hop's part first (what FOLD0 records pre-compute)
 				phi = cfma(oL, make_float2(f[2], f[3]), phi);
 				phi = cfma(o1, make_float2(f[0], f[1]), phi); // the newest operand last: two dependent instructions behind it
-				const float2 om = (CH == 2) ? makeOutputFb(phi, pm, sm) : makeOutput(phi, pm, sm); // :788 (stereo records carry the fallback output in pm's place)
+				const float2 om = (CH >= 2) ? makeOutputFb(phi, pm, sm) : makeOutput(phi, pm, sm); // :788 (records of 2+ channels carry the fallback output in pm's place)
 				const float2 olock = (CH == 2) ? lockedOutput(om, f) : om; // stereo: see recordChannelFields
 #pragma unroll
 				for (int c = 0; c < CH; ++c) {
 					float2 oc;
-					if constexpr (CH == 2) {
-						oc = olock;
-					} else {
-						const float2 pc = make_float2(f[9 + 3*c], f[10 + 3*c]);
-						oc = makeOutput(cmul(om, cmulc(pc, pm)), pc, f[11 + 3*c]); // channel lock, :791-800
-					}
+					if constexpr (CH == 2) oc = olock;
+					else if constexpr (CH == 1) oc = om;
+					else oc = lockedOutputN(om, f, c, word); // channel lock, :791-800, pre-scaled by the record's producer
 					if (c == mc) oc = om;
 					if (b < startBin) oc = make_float2(0.f, 0.f);
 					h[i][c] = oc; // bins past the last one have all-zero records, which give exactly zero
@@ -580,7 +572,7 @@ __global__ __launch_bounds__(128) void kVocoderOne(DevBatch d, int sBase, int ho
 template <int CH>
 static void launchPredictT(const DevBatch &d, int sBase, int nStreams, int hopBase, int tileHops, bool plain, bool passADone, hipStream_t st) {
 	const dim3 grid(divUp(d.M + d.lag*(d.T - 1), 8), nStreams);
-	const size_t lds = (size_t)8*((9 + 3*CH + 3)/4)*65*sizeof(float4);
+	const size_t lds = (size_t)8*((recordFloats(CH) + 3)/4)*65*sizeof(float4);
 	if (plain) {
 		hipLaunchKernelGGL((kPredictB<CH, true>), grid, dim3(256), lds, st, d, sBase, hopBase);
 	} else {
@@ -594,7 +586,7 @@ void launchPredictFused(const DevBatch &d, int sBase, int nStreams, int hopBase,
 }
 template <int CH, int L>
 static void launchVocoderNL(const DevBatch &d, int sBase, int nStreams, int hopBase, bool plain, hipStream_t st) {
-	constexpr int NCH = (9 + 3*CH + 3)/4;
+	constexpr int NCH = (recordFloats(CH) + 3)/4;
 	const size_t lds = (size_t)kVocNBlocks*kVocNBlockSteps*NCH*64*sizeof(float4) + (size_t)CH*kVocNRing*64*sizeof(float2)
 	                   + (size_t)CH*128*sizeof(float2) + 64 + 64*sizeof(HopDesc);
 	if (plain) hipLaunchKernelGGL((kVocoderN<CH, true, L>), dim3(nStreams), dim3(64*kVocWaves), lds, st, d, sBase, hopBase);
@@ -611,7 +603,7 @@ static void launchVocoderN(const DevBatch &d, int sBase, int nStreams, int hopBa
 }
 template <int CH, int L>
 static void launchVocoderOneL(const DevBatch &d, int sBase, int nStreams, int hopBase, bool plain, hipStream_t st) {
-	constexpr int NCH = (9 + 3*CH + 3)/4;
+	constexpr int NCH = (recordFloats(CH) + 3)/4;
 	const size_t lds = (size_t)2*kVocOneBlock*NCH*sizeof(float4) + (size_t)2*CH*kVocOneBlock*sizeof(float2) + (size_t)CH*128*sizeof(float2) + 16 + sizeof(HopDesc);
 	if (plain) hipLaunchKernelGGL((kVocoderOne<CH, true, L>), dim3(nStreams), dim3(128), lds, st, d, sBase, hopBase);
 	else hipLaunchKernelGGL((kVocoderOne<CH, false, L>), dim3(nStreams), dim3(128), lds, st, d, sBase, hopBase);
