@@ -373,7 +373,11 @@ __device__ __forceinline__ void computeRecord(const DevBatch &d, const HopDesc &
 		mp1 = make_float2(float(min(b + 1, M - 1)), 1.0f);
 	} else {
 		const int ci = min(b, M - 2);
-		const float4 pr = *reinterpret_cast<const float4 *>(d.map + ((size_t)s*d.T + k)*M + ci);
+		float4 pr = *reinterpret_cast<const float4 *>(d.map + ((size_t)s*d.T + k)*M + ci);
+		// (only the positions are used here; with the gradients dead the compiler loads the two positions as two separate dwords -- two gather
+		// instructions over the same lines, and the gathering producers live on the number of requests their L1 takes: EXPERIMENTS.md 6.9)
+		keepUnconditional(pr.y);
+		keepUnconditional(pr.w);
 		const bool mapped = hd.flags & HOP_MAPPED;
 		mp = mapped ? ((b == ci) ? make_float2(pr.x, pr.y) : make_float2(pr.z, pr.w)) : make_float2(float(b), 1.0f);
 		mp1 = mapped ? make_float2(pr.z, pr.w) : make_float2(float(ci + 1), 1.0f);

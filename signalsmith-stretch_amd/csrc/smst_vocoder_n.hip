@@ -222,6 +222,7 @@ __global__ __launch_bounds__(64*kVocWaves) __attribute__((amdgpu_waves_per_eu(4,
 	float2 *stage = ring + CH*R*64;                                      // [CH][128]: carried Band.output, 128-bin window
 	volatile int *sync = reinterpret_cast<volatile int *>(stage + CH*128); // [0..NB) units produced, [NB] blocks consumed, [NB+1] result blocks ready, [NB+2] written
 	HopDesc *hopsLds = reinterpret_cast<HopDesc *>(const_cast<int *>(sync) + 16);
+	int *rowClass = reinterpret_cast<int *>(hopsLds + 64);                 // [4][64]: the writer's classes of rows (two for half lines, four for whole lines), then its slabs
 
 	const int s = blockIdx.x, sg = sBase + s;
 	const int nh = d.nHops[s];
@@ -247,6 +248,150 @@ __global__ __launch_bounds__(64*kVocWaves) __attribute__((amdgpu_waves_per_eu(4,
 			// ---------------- writer: an ALIGNED group of 4 bins of a row = one 32-byte sector per channel, two lanes per row.
 			// With block n row r has completed group n - ceil(lag*r/4) (the bins a row produced in the block itself straddle two
 			// sectors, and partial sectors went to HBM twice -- see kVocoder's writer); one extra pass flushes the last groups.
+			if (d.vocNHalfLines == 2 && (M & 15) == 0) {
+				// WHOLE LINES (round 6, second step): a row's 16 bins = one 128-byte line per request, eight lanes per row, 8 rows per store
+				// instruction.  A row completes an aligned line every fourth block (4-bin group index n - ceil(lag*row/4) = 3 mod 4): four classes
+				// of 16 rows, one of which stores per block; the other three copy their fresh group out of the ring into a slab of LDS (the ring
+				// is only 16 bins deep).  Six slabs of [16 rows][CH][4 bins] do: a line's first group waits three passes (three slabs in rotation),
+				// the second two (two), the third one -- and a pass reads the slabs it frees before it fills them (LDS operations of a wave
+				// execute in order).  24 KB at 8 channels, which the shorter records of round 6 left free.
+				float4 *slabs = reinterpret_cast<float4 *>(rowClass + 4*64);
+				constexpr int SL = 16*CH*2; // float4s per slab
+				{
+					int c0 = 0, c1 = 0, c2 = 0, c3 = 0; // (scalars: a counter array indexed by the class would live in scratch memory)
+					for (int r = 0; r < 64; ++r) { // every lane walks the same list; lane 0 records it
+						const int q = ((lag*r + 3) >> 2) & 3;
+						const int at = (q == 0) ? c0 : ((q == 1) ? c1 : ((q == 2) ? c2 : c3));
+						if (k == 0) rowClass[q*64 + at] = r; // 16 rows per class for every lag from 2 to 7
+						c0 += q == 0; c1 += q == 1; c2 += q == 2; c3 += q == 3;
+					}
+				}
+				static_assert(lag >= 2 && lag <= 7, "the whole-line writer's four classes of 16 rows");
+				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+				__builtin_amdgcn_wave_barrier();
+				__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+				for (int n = 0; n <= totalBlocks; ++n) {
+					if (n < totalBlocks) {
+						while (ldsPeek(&sync[NB + 1]) <= n) __builtin_amdgcn_s_sleep(2);
+					}
+					asm volatile("" ::: "memory");
+					const int base0 = (n%3)*SL, base1 = (3 + (n & 1))*SL, base2 = 5*SL; // where a group 0 / 1 / 2 filed in THIS pass goes -- and where the line stored in this pass finds its own
+					{
+						const int oct = k & 7, rho = k >> 3, g = oct >> 1, part = oct & 1;
+						const int base = (g == 0) ? base0 : ((g == 1) ? base1 : base2);
+						const int cls = (n + 1) & 3; // ceil(lag*row/4) = n - 3 (mod 4)
+#pragma unroll
+						for (int j = 0; j < 2; ++j) {
+							const int idx = 8*j + rho;
+							const int row = rowClass[cls*64 + idx];
+							const int grp = n - ((lag*row + 3) >> 2);
+							const int b = 4*grp + 2*part; // lanes 6-7: this block's group, still in the ring
+							const bool ok = row < nh && grp >= 3 && 4*grp < M; // (M is a multiple of 16: the line lies below M)
+#pragma unroll
+							for (int c = 0; c < CH; ++c) {
+								float4 val = slabs[base + (idx*CH + c)*2 + part];
+								if (g == 3) {
+									const float2 v0 = ring[(c*R + (b & Rm))*64 + row], v1 = ring[(c*R + ((b + 1) & Rm))*64 + row];
+									val = make_float4(v0.x, v0.y, v1.x, v1.y);
+								}
+								if (ok) *reinterpret_cast<float4 *>(d.OUT + rowOf(d, s, row, c) + 4*(grp - 3) + 2*oct) = val;
+							}
+						}
+					}
+					__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+					__builtin_amdgcn_wave_barrier(); // every lane has read the slabs this pass frees (the hardware's lanes run in lockstep; the CPU stand-in's do not)
+					__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+					{
+						const int idx = k >> 2, part = (k >> 1) & 1, odd = k & 1;
+#pragma unroll
+						for (int g = 0; g < 3; ++g) {
+							const int row = rowClass[((n - g) & 3)*64 + idx];
+							const int b = 4*(n - ((lag*row + 3) >> 2)) + 2*part;
+							const int base = (g == 0) ? base0 : ((g == 1) ? base1 : base2);
+#pragma unroll
+							for (int cc = 0; cc < (CH + 1)/2; ++cc) {
+								const int c = 2*cc + odd;
+								if (c < CH) {
+									const float2 v0 = ring[(c*R + (b & Rm))*64 + row], v1 = ring[(c*R + ((b + 1) & Rm))*64 + row];
+									slabs[base + (idx*CH + c)*2 + part] = make_float4(v0.x, v0.y, v1.x, v1.y);
+								}
+							}
+						}
+					}
+					__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+					__builtin_amdgcn_wave_barrier(); // ... and filed its groups before the next pass reads them
+					__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+					if (k == 0) ldsPost(&sync[NB + 2], n + 1);
+				}
+				return;
+			}
+			if (d.vocNHalfLines && (M & 7) == 0) {
+				// HALF LINES (round 6).  The kernel lives on the number of requests its CU's L1 takes (loads and stores alike, hits included:
+				// EXPERIMENTS.md 6.9 -- the stores of 32-byte sectors cost 12 of its 42 ms per step, 7 of them for the count of lines alone), so a
+				// row's 8 bins = 64 bytes go out in ONE request: four lanes per row, 16 rows per store instruction.  A row completes an aligned
+				// 8-bin group every other block (when its 4-bin group index n - ceil(lag*row/4) is odd), so the rows fall into two classes that
+				// store on alternate blocks; on the block in between the row's lanes 0-1 take the first four bins out of the ring into
+				// registers -- the ring keeps its depth and the hand-shake with the recurrence wave its slack.
+				int count[2] = {0, 0};
+				for (int r = 0; r < 64; ++r) { // every lane walks the same list; lane 0 records it
+					const int q = ((lag*r + 3) >> 2) & 1;
+					if (k == 0) rowClass[q*64 + count[q]] = r;
+					++count[q];
+				}
+				__builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+				__builtin_amdgcn_wave_barrier();
+				__builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+				constexpr int PASSES = 2; // 32 rows per class for every lag from 2 to 7 (ceil(lag*row/4) is odd for exactly half of the 64 rows)
+				static_assert(lag >= 2 && lag <= 7, "the half-line writer's two classes of rows");
+				const int rho = k >> 2, quarter = k & 3;
+				float4 held[PASSES][CH];
+#pragma unroll
+				for (int j = 0; j < PASSES; ++j) {
+#pragma unroll
+					for (int c = 0; c < CH; ++c) held[j][c] = make_float4(0.f, 0.f, 0.f, 0.f);
+				}
+				for (int n = 0; n <= totalBlocks; ++n) {
+					if (n < totalBlocks) {
+						while (ldsPeek(&sync[NB + 1]) <= n) __builtin_amdgcn_s_sleep(2);
+					}
+					asm volatile("" ::: "memory");
+					const int qStore = (n + 1) & 1, qHold = n & 1; // ceil(lag*row/4) = n + 1 (mod 2): the block completed an odd group
+#pragma unroll
+					for (int j = 0; j < PASSES; ++j) {
+						const int idx = 16*j + rho;
+						{
+							const bool listed = idx < count[qStore];
+							const int row = rowClass[qStore*64 + (listed ? idx : 0)];
+							const int grp = n - ((lag*row + 3) >> 2);
+							const int b = 4*(grp - 1) + 2*quarter; // lanes 0-1: the bins held since the last block; lanes 2-3: this block's
+							const bool ok = listed && row < nh && grp >= 1 && 4*grp < M;
+#pragma unroll
+							for (int c = 0; c < CH; ++c) {
+								float4 val = held[j][c];
+								if (quarter >= 2) {
+									const float2 v0 = ring[(c*R + (b & Rm))*64 + row], v1 = ring[(c*R + ((b + 1) & Rm))*64 + row];
+									val = make_float4(v0.x, v0.y, v1.x, v1.y);
+								}
+								if (ok) *reinterpret_cast<float4 *>(d.OUT + rowOf(d, s, row, c) + b) = val; // (M is a multiple of 8: the group lies below M)
+							}
+						}
+						{
+							const bool listed = idx < count[qHold];
+							const int row = rowClass[qHold*64 + (listed ? idx : 0)];
+							const int grp = n - ((lag*row + 3) >> 2);
+							const int b = 4*grp + 2*(quarter & 1); // (lanes 2-3 keep copies nobody stores)
+#pragma unroll
+							for (int c = 0; c < CH; ++c) {
+								const float2 v0 = ring[(c*R + (b & Rm))*64 + row], v1 = ring[(c*R + ((b + 1) & Rm))*64 + row];
+								held[j][c] = make_float4(v0.x, v0.y, v1.x, v1.y);
+							}
+						}
+					}
+					asm volatile("" ::: "memory");
+					if (k == 0) ldsPost(&sync[NB + 2], n + 1);
+				}
+				return;
+			}
 			const int g = k >> 1, part = k & 1;
 			for (int n = 0; n <= totalBlocks; ++n) {
 				if (n < totalBlocks) {
@@ -264,10 +409,11 @@ __global__ __launch_bounds__(64*kVocWaves) __attribute__((amdgpu_waves_per_eu(4,
 						float2 v0 = ring[(c*R + (b0 & Rm))*64 + row], v1 = ring[(c*R + ((b0 + 1) & Rm))*64 + row];
 						if (b0 >= M) v0 = make_float2(0.f, 0.f); // not produced in this tile: the slot holds an older bin
 						if (b0 + 1 >= M) v1 = make_float2(0.f, 0.f);
-						if (ok) { // bins M .. M+2 of the last group land in the rows' padding
-							float2 *dst = d.OUT + rowOf(d, s, row, c) + b0;
-							dst[0] = v0;
-							dst[1] = v1;
+						if (ok) { // bins M .. M+2 of the last group land in the rows' padding.  ONE 16-byte store per lane: a lane pair fills its sector with one
+							// instruction (two 8-byte stores per lane interleave the pair's halves: every sector was visited twice, and the writer's
+							// stores share the CU's L1 request queue with the producers' gathers)
+							float2 *dst = d.OUT + rowOf(d, s, row, c) + b0; // (rows are 16-byte aligned, b0 is even)
+							*reinterpret_cast<float4 *>(dst) = make_float4(v0.x, v0.y, v1.x, v1.y);
 						}
 					}
 				}
@@ -588,7 +734,7 @@ template <int CH, int L>
 static void launchVocoderNL(const DevBatch &d, int sBase, int nStreams, int hopBase, bool plain, hipStream_t st) {
 	constexpr int NCH = (recordFloats(CH) + 3)/4;
 	const size_t lds = (size_t)kVocNBlocks*kVocNBlockSteps*NCH*64*sizeof(float4) + (size_t)CH*kVocNRing*64*sizeof(float2)
-	                   + (size_t)CH*128*sizeof(float2) + 64 + 64*sizeof(HopDesc);
+	                   + (size_t)CH*128*sizeof(float2) + 64 + 64*sizeof(HopDesc) + 4*64*sizeof(int) + (size_t)6*16*CH*2*sizeof(float4);
 	if (plain) hipLaunchKernelGGL((kVocoderN<CH, true, L>), dim3(nStreams), dim3(64*kVocWaves), lds, st, d, sBase, hopBase);
 	else hipLaunchKernelGGL((kVocoderN<CH, false, L>), dim3(nStreams), dim3(64*kVocWaves), lds, st, d, sBase, hopBase);
 }

@@ -323,6 +323,30 @@ def case_fused_equals_unfused(lib, monkeypatch, channel_counts=(3, 8), geometry=
         assert np.array_equal(outs[0], outs[1]), (C, float(np.abs(outs[0] - outs[1]).max()))
 
 
+def case_vocn_writer_forms(lib, monkeypatch, channel_counts=(3, 8), n=12000):
+    """kVocoderN's writer wave: whole 128-byte lines through slabs of LDS (the default, round 6), 64-byte half lines held in
+    registers (SMST_VOCN_HALF_LINES=1) and the first form's 32-byte sectors (=0) move the same values: bit-identical, at two
+    vertical steps (two skews of the rows against the line grid), over two calls, with a frequency map on half of the streams."""
+    pkg = package()
+    for geometry in (dict(block=512, interval=128, split=False), dict(block=1024, interval=192, split=False)):
+        for C in channel_counts:
+            xs = np.stack([synth_input(s, C, n, 48000)*(1 + 0.2*np.arange(C))[:, None].astype(np.float32) for s in range(4)])
+            outs = []
+            for form in ("2", "1", "0"):
+                monkeypatch.setenv("SMST_VOCN_HALF_LINES", form)
+                b = pkg.StretchBatch(4, C, lib=lib, **geometry)
+                b.setTransposeSemitones(3.0, 0.2, stream=1)
+                b.setTransposeSemitones(-4.0, 0.0, stream=3)
+                y1 = np.array(b.process(xs[:, :, :n//3], int(n//3*1.3)), copy=True)
+                y2 = np.array(b.process(xs[:, :, n//3:], int((n - n//3)*1.3)), copy=True)
+                b.close()
+                outs.append(np.concatenate([y1, y2], axis=2))
+            monkeypatch.delenv("SMST_VOCN_HALF_LINES", raising=False)
+            assert np.abs(outs[0]).max() > 0.05
+            for o in outs[1:]:
+                assert np.array_equal(outs[0], o), (geometry, C, float(np.abs(outs[0] - o).max()))
+
+
 def case_feed_fusion_equals_separate(lib, monkeypatch, channel_counts=(2, 3), geometry=None, n=9000, formants=False, bases_given=False):
     """Pass A folded into the feed kernel (tiles with a pitch map and no formant processing) against the separate kPredictA
     (SMST_NO_FEED_FUSION=1): the same arithmetic on the same operands, so bit-identical -- mapped and unmapped streams side

@@ -6,7 +6,7 @@ OUT=$ROOT/gpurun_out/r5_ablate_vocn
 mkdir -p $OUT
 cd $ROOT
 export SMST_LIBRARY_ALLOW_MISSING=1 SMST_LIBRARY=$ROOT/signalsmith-stretch_amd/variants/experiments.so
-for mode in 0 1 2; do
+for mode in ${MODES:-0 1 2}; do
   SMST_DEBUG_MODE=$mode timeout 300 python bench.py --config 5 --steps 3 --warmup 1 --no-cpu-baseline --no-self-check > $OUT/mode$mode.json 2> $OUT/mode$mode.err
   python -c "
 import json

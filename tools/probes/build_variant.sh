@@ -32,5 +32,5 @@ done
 C=$TMP/signalsmith-stretch_amd/csrc
 hipcc --offload-arch=gfx950 -I$C -O3 -ffp-contract=on -std=c++17 -fPIC -shared -x hip -Wno-unused-result -Wno-unused-value $EXTRA \
   $C/smst_kernels.hip $C/smst_engine.cpp $C/smst_capi.cpp -o $ROOT/signalsmith-stretch_amd/variants/$NAME.so 2>&1 | grep -E "error" || true
-ls -la $ROOT/signalsmith-stretch_amd/variants/$NAME.so
+ls -la --time-style=full-iso $ROOT/signalsmith-stretch_amd/variants/$NAME.so
 rm -rf $TMP
