@@ -29,6 +29,7 @@ struct DevBatch {
 	int teamsGrid;                // their grid: one workgroup per CU, a multiple of 8
 	int synthEmit;                // synthesis + overlap-add + emission in one kernel (kSynthEmitTeams) where it applies (default 1; SMST_SYNTH_EMIT=0: kSynthTeams + kEmit; =2: also for small tiles -- tests)
 	int vocNWide;                 // 3-8 channels: producer passes of 8 rows x 8 steps instead of 16 rows x 4 (SMST_VOCN_WIDE, smst_switches.h)
+	int vocWide;                  // mono / stereo, gathering producers (mapped tiles): passes of 4 rows x 16 steps instead of 8 x 8 (SMST_VOC_WIDE=0: the first form)
 	int vocNHalfLines;            // 3-8 channels: the writer wave stores aligned 64-byte half lines (1) or whole 128-byte lines (2) instead of 32-byte sectors (SMST_VOCN_HALF_LINES=0: the first form)
 	int noStage;                  // SMST_NO_STAGE: producers of the fused kernel gather from HBM even where staging applies
 	int alignAll;                 // SMST_ALIGN_ALL: the line-aligned producers for every geometry they are valid for (default: L = 4 only)

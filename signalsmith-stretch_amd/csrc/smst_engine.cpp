@@ -177,6 +177,7 @@ void Batch::construct(const FftPlan &plan, long seed) {
 	d.noFeedFusion = sw.noFeedFusion;
 	d.noStage = sw.noStage;
 	d.vocNWide = sw.vocNWide;
+	d.vocWide = sw.vocWide;
 	d.vocNHalfLines = sw.vocNHalfLines;
 	d.noAlign = sw.noAlign;
 	d.alignAll = sw.alignAll;

@@ -37,7 +37,7 @@ namespace smst {
 
 struct Switches {
 	bool overlap = true, noFuse = false, noSingleHop = false, noAcross = false, checkLaunches = false;
-	int noFeedFusion = 0, fftTeams = 1, synthEmit = 1, debugMode = 0, vocNWide = 1, vocNHalfLines = 2, carriedEmit = 1;
+	int noFeedFusion = 0, fftTeams = 1, synthEmit = 1, debugMode = 0, vocNWide = 1, vocWide = 1, vocNHalfLines = 2, carriedEmit = 1;
 	bool noStage = false, noAlign = false, alignAll = false, noFastFft = false, fftLean = false, feedSerial = false, continuous = false;
 	int contWriterWave = 4;
 	double workspaceGiB = 0; // 0: automatic
@@ -68,6 +68,7 @@ struct Switches {
 		s.synthEmit = num("SMST_SYNTH_EMIT", 1);
 		s.carriedEmit = num("SMST_CARRIED_EMIT", 1);
 		s.vocNWide = num("SMST_VOCN_WIDE", 1);
+		s.vocWide = num("SMST_VOC_WIDE", 1);
 		s.vocNHalfLines = num("SMST_VOCN_HALF_LINES", 2);
 #ifdef SMST_EXPERIMENTS
 		s.debugMode = num("SMST_DEBUG_MODE", 0);

@@ -666,6 +666,38 @@ __global__ __launch_bounds__(64*kVocWaves) __attribute__((amdgpu_waves_per_eu(4,
 			vocoderProduceStaged<CH, L, NB, NP>(d, s, sg, nh, pIndex, k, totalBlocks, recs, sync, hopsLds, sbuf, stOut);
 			return;
 		}
+		if (!ACROSS && d.vocWide) {
+			// WIDE passes (round 6): 4 rows x 16 steps -- two blocks of the three-block ring at once.  The gathering producers are what a mapped
+			// tile's recurrence waits for (configs 3 / 4b: the recurrence wave alone needs 13 of config 3's 30 ms, the producers 29, of which
+			// 10 are their requests to the L1: EXPERIMENTS.md 6.9), and a request is one (instruction, line): with 16 consecutive bins of
+			// a row in one load a line is asked for once where two passes of 8 bins asked twice.  Same records, same slots.
+			static_assert(NB >= 2, "a wide pass fills two blocks of the ring");
+			const int st16 = k & 15, r4 = k >> 4;
+			const int half = st16 >> 3, st = st16 & 7;
+			for (int u = pIndex; u < (totalBlocks/2)*16; u += NP) { // (totalBlocks is a multiple of 8)
+				const int pair = u >> 4, it = u & 15;
+				const int row = 4*it + r4;
+				const int b = 2*BS*pair + st16 - lag*row;
+				float f[NCH*4];
+#pragma unroll
+				for (int j = 0; j < NCH*4; ++j) f[j] = 0.0f;
+				if (row < nh && b >= 0 && b < M && !SMST_SKIP_PRODUCER_MATH(d))
+					computeRecord<CH, PLAIN, false, false, NCH*4, ROTL, true>(d, hopsLds[row], hopsLds[row > 0 ? row - 1 : 0], s, sg, row, b, f, rotLds);
+#pragma unroll
+				for (int h = 0; h < 2; ++h) {
+					const int n = 2*pair + h, slot = n%NB;
+					while (n - ldsPeek(&sync[NB]) >= NB) __builtin_amdgcn_s_sleep(2); // slot still being read
+					asm volatile("" ::: "memory");
+					if (half == h) {
+#pragma unroll
+						for (int j = 0; j < NCH; ++j) recs[((slot*BS + st)*NCH + j)*64 + ((row + st) & 63)] = make_float4(f[4*j], f[4*j + 1], f[4*j + 2], f[4*j + 3]);
+					}
+					asm volatile("" ::: "memory");
+					if (k == 0) ldsCount(&sync[slot]); // LDS ops of a wave are in order: data first, then the count
+				}
+			}
+			return;
+		}
 		const int st = k & 7, r = k >> 3; // 8 adjacent lanes = 8 consecutive bins of one row: 64-byte contiguous global loads
 		for (int u = pIndex; u < totalBlocks*8; u += NP) {
 			const int n = u >> 3, it = u & 7;
@@ -712,10 +744,11 @@ __global__ __launch_bounds__(64*kVocWaves) __attribute__((amdgpu_waves_per_eu(4,
 	}
 	// the two hand-off words the NEXT block waits for are read during the current block's last step (an LDS round trip each,
 	// 200 clock cycles, sat on the serial path at every block boundary -- cycle trace); the poll loops remain for the rare miss
+	const int units = (!STAGED && !ACROSS && d.vocWide) ? 16 : 8; // producer passes that make up a block
 	int seenProduced = ldsPeek(&sync[0]), seenWritten = 0;
 	for (int n = 0; n < totalBlocks; ++n) {
 		const int slot = n%NB;
-		const int need = 8*(n/NB + 1);
+		const int need = units*(n/NB + 1);
 		while (seenProduced < need) { __builtin_amdgcn_s_sleep(1); seenProduced = ldsPeek(&sync[slot]); }
 		asm volatile("" ::: "memory");
 		const float4 *blockRecs = recs + (size_t)slot*BS*NCH*64;

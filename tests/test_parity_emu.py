@@ -71,6 +71,10 @@ def test_hop_magnitudes_small(emu, ref):
     print(pc.case_hop_magnitudes(emu, ref, pc.SMALL, 2, 1.0, "magnitudes pitch", hops=24, setup=lambda o: o.setTransposeSemitones(12, 8000/48000)))
 
 
+def test_gather_pass_shapes(emu, monkeypatch):
+    pc.case_gather_pass_shapes(emu, monkeypatch, n=6000)
+
+
 def test_vocn_writer_forms(emu, monkeypatch):
     pc.case_vocn_writer_forms(emu, monkeypatch, channel_counts=(3, 8), n=6000)
 

@@ -528,6 +528,11 @@ def test_feed_fusion_equals_separate(hip, monkeypatch):
     pc.case_feed_fusion_equals_separate(hip, monkeypatch, channel_counts=(2,), geometry=dict(preset="default", sample_rate=48000.0), n=40000, formants=True, bases_given=True)
 
 
+def test_gather_pass_shapes(hip, monkeypatch):
+    """mono / stereo tiles with a frequency map: the gathering producers' two pass shapes give the same records."""
+    pc.case_gather_pass_shapes(hip, monkeypatch)
+
+
 def test_vocn_writer_forms(hip, monkeypatch):
     """3-8 channels: the writer wave's whole lines / half lines / sectors are the same values."""
     pc.case_vocn_writer_forms(hip, monkeypatch, channel_counts=(3, 5, 8))
