@@ -1,12 +1,23 @@
-# usage: r6_env_ab.sh <tag> <ENVVAR> "<values>" "<configs>" [pytest -k expression]: GPU tests (a part), then the configs under each value of the switch, two rounds
-cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/$1
-timeout 600 python -m pytest tests -m gpu -x -q -k "${5:-fused or golden or map or gather}" > gpurun_out/$1/gpu_tests.log 2>&1; tail -2 gpurun_out/$1/gpu_tests.log
-for c in $4; do for round in 1 2; do for v in $3; do
-env $2=$v timeout 600 python bench.py --config $c --steps 5 --warmup 2 --no-cpu-baseline --no-other-configs > gpurun_out/$1/config${c}_${v}_$round.json 2> gpurun_out/$1/config${c}_${v}_$round.err
-python - <<PY
+#!/bin/bash
+# Same-box A/B of ONE library under two environments: tools/gpu/r6_env_ab.sh <tag> "<env A>" "<env B>" [bench args]
+# e.g.  r6_env_ab.sh cont "" "SMST_NO_CONTINUOUS=1"      (an empty string = the default environment)
+ROOT=${GRAFT_REPO_ROOT:-/root/repo}
+TAG=$1; ENVA=$2; ENVB=$3; shift 3
+OUT=$ROOT/gpurun_out/$TAG
+mkdir -p $OUT
+cd $ROOT
+for round in 1 2; do
+for which in A B; do
+  if [ $which = A ]; then E="$ENVA"; else E="$ENVB"; fi
+  env $E timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu-baseline "$@" > $OUT/bench_${which}_$round.json 2> $OUT/bench_${which}_$round.err
+  python - <<PY
 import json
-d = json.loads(open("gpurun_out/$1/config${c}_${v}_$round.json").read().strip().splitlines()[-1])
-print("$2=$v config $c %.3f ms/step frac %.4f chain alone %.2f" % (d["ms_per_step"], d["roofline"]["frac"], d["roofline"]["kernel_ms_per_step_alone"]["chain"]))
+try:
+    d = json.loads(open("$OUT/bench_${which}_$round.json").read().strip().splitlines()[-1])
+    r = d["roofline"]
+    print("%-28s run $round: %.0f Msamples/s  ms/step mean %.3f median %.3f min %.3f | alone %s | recurrence in place %.4f ms | self_check %s" % ("[$E]", d["value"], d["ms_per_step"], r["step_ms"]["median"], r["step_ms"]["min"], {k: v for k, v in r["kernel_ms_per_step_alone"].items() if v > 0.3}, r["dominant_kernel"]["avg_launch_ms"], d.get("self_check", {}).get("rel_rms")))
+except Exception as e:
+    print("[$E] failed:", e, open("$OUT/bench_${which}_$round.err").read()[-600:])
 PY
-done; done; done
+done
+done
