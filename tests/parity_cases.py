@@ -323,11 +323,11 @@ def case_fused_equals_unfused(lib, monkeypatch, channel_counts=(3, 8), geometry=
         assert np.array_equal(outs[0], outs[1]), (C, float(np.abs(outs[0] - outs[1]).max()))
 
 
-def case_gather_pass_shapes(lib, monkeypatch, channel_counts=(1, 2), n=12000):
+def case_gather_pass_shapes(lib, monkeypatch, channel_counts=(1, 2), n=12000, extra_geometries=()):
     """kVocoder's gathering producers (tiles with a frequency map): passes of 4 rows x 16 steps (the default, round 6) against 8 x 8
     (SMST_VOC_WIDE=0) -- the same records into the same slots: bit-identical, over two calls, mapped and unmapped streams side by side."""
     pkg = package()
-    for geometry in (dict(block=512, interval=128, split=False), dict(block=1024, interval=192, split=False)):
+    for geometry in (dict(block=512, interval=128, split=False), dict(block=1024, interval=192, split=False)) + tuple(extra_geometries):
         for C in channel_counts:
             xs = np.stack([synth_input(s, C, n, 48000)*(1 + 0.2*np.arange(C))[:, None].astype(np.float32) for s in range(4)])
             outs = []
@@ -347,16 +347,16 @@ def case_gather_pass_shapes(lib, monkeypatch, channel_counts=(1, 2), n=12000):
             assert np.array_equal(outs[0], outs[1]), (geometry, C, float(np.abs(outs[0] - outs[1]).max()))
 
 
-def case_vocn_writer_forms(lib, monkeypatch, channel_counts=(3, 8), n=12000):
+def case_vocn_writer_forms(lib, monkeypatch, channel_counts=(3, 8), n=12000, extra_geometries=()):
     """kVocoderN's writer wave: whole 128-byte lines through slabs of LDS (the default, round 6), 64-byte half lines held in
     registers (SMST_VOCN_HALF_LINES=1) and the first form's 32-byte sectors (=0) move the same values: bit-identical, at two
     vertical steps (two skews of the rows against the line grid), over two calls, with a frequency map on half of the streams."""
     pkg = package()
     # (block 68 -> 40 bands: not a multiple of 16, the default falls back to half lines; block 36 -> 20 bands: to sectors)
-    for geometry in (dict(block=512, interval=128, split=False), dict(block=1024, interval=192, split=False), dict(block=68, interval=17, split=False), dict(block=36, interval=9, split=False)):
+    for geometry in (dict(block=512, interval=128, split=False), dict(block=1024, interval=192, split=False), dict(block=68, interval=17, split=False), dict(block=36, interval=9, split=False)) + tuple(extra_geometries):
         for C in channel_counts:
             xs = np.stack([synth_input(s, C, n, 48000)*(1 + 0.2*np.arange(C))[:, None].astype(np.float32) for s in range(4)])
-            if geometry["block"] < 100:
+            if geometry.get("block", 1000) < 100:
                 xs = xs[:, :, :n//4]
             outs = []
             for form in ("2", "1", "0"):

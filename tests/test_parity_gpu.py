@@ -530,12 +530,15 @@ def test_feed_fusion_equals_separate(hip, monkeypatch):
 
 def test_gather_pass_shapes(hip, monkeypatch):
     """mono / stereo tiles with a frequency map: the gathering producers' two pass shapes give the same records."""
-    pc.case_gather_pass_shapes(hip, monkeypatch)
+    # (vertical steps 4 and 5, then 2 and 3; the presets' own geometries last)
+    pc.case_gather_pass_shapes(hip, monkeypatch, extra_geometries=(dict(block=512, interval=256, split=False), dict(block=512, interval=170, split=False),
+                                                                  dict(preset="default", sample_rate=48000.0), dict(preset="cheaper", sample_rate=48000.0)), n=30000)
 
 
 def test_vocn_writer_forms(hip, monkeypatch):
     """3-8 channels: the writer wave's whole lines / half lines / sectors are the same values."""
-    pc.case_vocn_writer_forms(hip, monkeypatch, channel_counts=(3, 5, 8))
+    pc.case_vocn_writer_forms(hip, monkeypatch, channel_counts=(3, 4, 5, 6, 7, 8), n=30000,
+                              extra_geometries=(dict(block=512, interval=256, split=False), dict(block=512, interval=170, split=False), dict(preset="cheaper", sample_rate=96000.0)))
 
 
 def test_fused_equals_unfused(hip, monkeypatch):
