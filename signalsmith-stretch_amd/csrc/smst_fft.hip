@@ -963,6 +963,9 @@ __global__ __launch_bounds__(256) void kSynth(DevBatch d, int sBase, int hopBase
 // signalsmith-stretch.h:406-415), and the new carry (the part of the ring that outlives the tile).
 // Sums are formed oldest-frame-first, as the reference's ring accumulates them.
 // ------------------------------------------------------------------------------------------------------
+// KMAX = the frames whose loads are issued together: ceil((B + 3)/I) cover a group of four samples (3 for presetCheaper, 5 for presetDefault);
+// a slot beyond that is a load instruction for nothing, and the kernel lives on the number of those (EXPERIMENTS.md 6.10).
+template <int KMAX>
 __global__ __launch_bounds__(256) void kEmit(DevBatch d, IoArgs io, int sBase, int tileIndex) {
 	// four consecutive output samples per thread: the frame / window-product taps of a group are 16-byte loads
 	// (dword alignment suffices on gfx9), and the two integer divisions are paid once per group
@@ -999,7 +1002,6 @@ __global__ __launch_bounds__(256) void kEmit(DevBatch d, IoArgs io, int sBase, i
 		if (qHi > ed.hopCount - 1) qHi = ed.hopCount - 1;
 		// all covering frames' loads are issued before the first addition (a loop with a load per iteration costs one
 		// memory round trip per frame); the additions then run in ascending q, the order the reference sums in
-		constexpr int KMAX = 6;
 		float4 f[KMAX], w[KMAX];
 		bool fast[KMAX];
 #pragma unroll
@@ -1167,7 +1169,12 @@ void launchSynthEmit(const DevBatch &d, const IoArgs &io, int sBase, int nStream
 	countLaunch(LK_SYNTH_EMIT);
 }
 void launchEmit(const DevBatch &d, const IoArgs &io, int sBase, int nStreams, int tileIndex, int maxSpan, hipStream_t st) {
-	hipLaunchKernelGGL(kEmit, dim3(divUp(divUp(maxSpan + d.carryLen, 4), 256), d.C, nStreams), dim3(256), 0, st, d, io, sBase, tileIndex);
+	const dim3 grid(divUp(divUp(maxSpan + d.carryLen, 4), 256), d.C, nStreams);
+	const int covering = divUp(d.B + 3, d.I); // frames that can cover a group of four output samples
+	if (covering <= 3) hipLaunchKernelGGL(kEmit<3>, grid, dim3(256), 0, st, d, io, sBase, tileIndex);
+	else if (covering <= 4) hipLaunchKernelGGL(kEmit<4>, grid, dim3(256), 0, st, d, io, sBase, tileIndex);
+	else if (covering <= 5) hipLaunchKernelGGL(kEmit<5>, grid, dim3(256), 0, st, d, io, sBase, tileIndex);
+	else hipLaunchKernelGGL(kEmit<6>, grid, dim3(256), 0, st, d, io, sBase, tileIndex); // (more covering frames: the kernel's plain loop takes the rest)
 }
 void launchEmitCarried(const DevBatch &d, const IoArgs &io, hipStream_t st) {
 	hipLaunchKernelGGL(kEmitCarried, dim3(d.S), dim3(256), 0, st, d, io);
